@@ -1,0 +1,210 @@
+"""
+Golden-vector generator  --  TEST INFRASTRUCTURE.
+
+Imports the *reference* (aaronyicongfu/pyfem_gpu_testflight, expected read-only at
+/root/reference) exactly as its own tests do and records inputs/expected outputs of
+the hot path as small .npz fixtures under tests/golden/.  Runs only in the build
+container; the GPU box never sees the reference -- tests read the committed .npz.
+
+pyamg is not installed here.  `import pyfem` needs the module name to exist, and
+Helmholtz.__init__ calls pyamg.ruge_stuben_solver(K): a functional stand-in backed by
+a sparse LU (what the reference's own oracle tests/ref_helmholtz.py:106 uses) is
+injected.  No reference source is copied; only numeric arrays are stored.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("PYFEM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _import_reference():
+    from scipy.sparse.linalg import factorized
+
+    class _LU:
+        def __init__(self, K):
+            self._lu = factorized(K.tocsc())
+
+        def solve(self, b, tol=None):
+            return self._lu(b)
+
+    stub = types.ModuleType("pyamg")
+    stub.ruge_stuben_solver = _LU
+    sys.modules["pyamg"] = stub
+    import matplotlib
+
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "tests"))
+    os.chdir("/tmp")  # the reference's profiler appends ./profiler.log
+    import pyfem
+    import parse_inp
+
+    return pyfem, parse_inp
+
+
+def _csr(K, prefix):
+    K = K.tocsr()
+    K.sort_indices()
+    return {
+        f"{prefix}_indptr": K.indptr.astype(np.int32),
+        f"{prefix}_indices": K.indices.astype(np.int32),
+        f"{prefix}_data": K.data.copy(),
+    }
+
+
+def _qb(pyfem, etype):
+    if etype == "quad":
+        q = pyfem.QuadratureBilinear2D()
+        return q, pyfem.BasisBilinear2D(q)
+    q = pyfem.QuadratureTriangle2D()
+    return q, pyfem.BasisTriangle2D(q)
+
+
+def elasticity_case(pyfem, name, X, conn, dof_fixed, nodal_force, etype, rho=None, p=0.0, full_K=True,
+                    fixed_vals=None):
+    q, b = _qb(pyfem, etype)
+    model = pyfem.LinearElasticity(X, conn, dof_fixed, fixed_vals, nodal_force, q, b, p=p)
+    K = model.compute_jacobian() if rho is None else model.compute_jacobian(rho)
+    out = dict(
+        X=np.asarray(X, dtype=float),
+        conn=np.asarray(conn, dtype=np.int32),
+        dof_fixed=np.asarray(dof_fixed, dtype=np.int32),
+        force_nodes=np.array(list(nodal_force.keys()), dtype=np.int32),
+        force_vals=np.array(list(nodal_force.values()), dtype=float),
+        p=np.float64(p),
+        Ke0=model.Ke_mat[0].copy(),
+        Ke_last=model.Ke_mat[-1].copy(),
+        K_norm=np.float64(np.linalg.norm(K.data)),
+        K_diag=K.diagonal(),
+        K_nnz=np.int64(K.nnz),
+    )
+    if rho is not None:
+        out["rho"] = rho
+    if fixed_vals is not None:
+        out["fixed_vals"] = np.asarray(fixed_vals, dtype=float)
+    if full_K:
+        out.update(_csr(K, "K"))
+    rng = np.random.RandomState(7)
+    v = rng.rand(K.shape[0])
+    out["v"] = v
+    out["Kv"] = K.dot(v)
+    rhs = model.compute_rhs().copy()
+    out["rhs"] = rhs.copy()
+    Kbc, rhs_bc = model.apply_dirichlet_bcs(K.copy(), rhs.copy(), enforce_symmetric_K=True)
+    out["rhs_bc"] = rhs_bc.copy()
+    out["Kbc_nnz"] = np.int64(Kbc.nnz)
+    out["Kbc_v"] = Kbc.dot(v)
+    Kns, rhs_ns = model.apply_dirichlet_bcs(K.copy(), rhs.copy(), enforce_symmetric_K=False)
+    out["Kns_v"] = Kns.dot(v)
+    out["rhs_ns"] = rhs_ns.copy()
+    from scipy.sparse.linalg import spsolve
+
+    out["u"] = spsolve(Kbc.tocsc(), rhs_bc)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: nelems={conn.shape[0]} ndof={K.shape[0]} nnz={K.nnz} |K|={out['K_norm']:.13e}")
+    return out
+
+
+def main():
+    pyfem, parse_inp = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    # --- PS32: the reference's own test case (tests/test_elasticity.py:23-51) ------------
+    c = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    o = elasticity_case(pyfem, "ps32_quad", X, conn, dof_fixed, nodal_force, "quad", full_K=False)
+    np.random.seed(123)
+    pr = np.random.rand(o["u"].shape[0])
+    print("  PS32 p.u =", repr(pr.dot(o["u"])), "(survey: -164.42713355728523)")
+    # and the independent hand-written oracle the reference's test compares against
+    from ref_plane_stress import PlaneStress
+
+    bcs = {int(d) // 2: [0, 1] for d in dof_fixed}
+    u_ref = PlaneStress(conn, X, bcs, nodal_force).solve()
+    print("  max|u - u_ref_plane_stress| =", np.abs(o["u"] - u_ref).max())
+
+    # --- PS32 RAMP p=5, random nodal rho (tests/test_elasticity.py:82-88) ----------------
+    np.random.seed(0)
+    rho = np.random.rand(X.shape[0])
+    elasticity_case(pyfem, "ps32_quad_ramp", X, conn, dof_fixed, nodal_force, "quad", rho=rho, p=5.0, full_K=False)
+
+    # --- small structured quad, full K, rectangular domain ------------------------------
+    c = pyfem.ProblemCreator(nnodes_x=13, nnodes_y=9)
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    elasticity_case(pyfem, "ps13x9_quad", X, conn, dof_fixed, nodal_force, "quad")
+
+    # --- distorted quads + RAMP + non-zero prescribed displacements ---------------------
+    rng = np.random.RandomState(42)
+    Xd = X + 0.02 * (rng.rand(*X.shape) - 0.5)
+    rho = 0.2 + 0.8 * rng.rand(X.shape[0])
+    vals = 0.01 * (rng.rand(len(dof_fixed)) - 0.5)
+    elasticity_case(pyfem, "ps13x9_quad_distorted", Xd, conn, dof_fixed, nodal_force, "quad", rho=rho, p=3.0,
+                    fixed_vals=vals)
+
+    # --- structured tri -----------------------------------------------------------------
+    c = pyfem.ProblemCreator(nnodes_x=11, nnodes_y=8, element_type="tri")
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    elasticity_case(pyfem, "ps11x8_tri", X, conn, dof_fixed, nodal_force, "tri")
+    rng = np.random.RandomState(5)
+    rho = 0.1 + 0.9 * rng.rand(X.shape[0])
+    elasticity_case(pyfem, "ps11x8_tri_ramp", X, conn, dof_fixed, nodal_force, "tri", rho=rho, p=5.0)
+
+    # --- torque arm: unstructured CPS3 mesh (examples/torque_arm/arm.py) ----------------
+    parser = parse_inp.InpParser(os.path.join(REF, "examples", "torque_arm", "arm.inp"))
+    conn_d, X3, groups = parser.parse()
+    X = X3[:, 0:2]
+    conn = conn_d["CPS3"]
+    dof_fixed = np.concatenate((2 * groups["fixed"], 2 * groups["fixed"] + 1))
+    nodal_force = {int(n): [0.0, -1.0] for n in groups["load"]}
+    o = elasticity_case(pyfem, "arm_tri", X, conn, dof_fixed, nodal_force, "tri")
+    np.random.seed(123)
+    pr = np.random.rand(o["u"].shape[0])
+    print("  ARM p.u =", repr(pr.dot(o["u"])), "(survey: 21177.45599189116)")
+
+    # --- Helmholtz filter (tests/test_helmholtz.py:11-44) --------------------------------
+    for name, nx, ny, etype, r0 in [("helm32_quad", 32, 32, "quad", 0.1), ("helm12x9_tri", 12, 9, "tri", 0.07)]:
+        c = pyfem.ProblemCreator(nnodes_x=nx, nnodes_y=ny, element_type=etype)
+        conn, X, x = c.create_helmhotz_problem()
+        q, b = _qb(pyfem, etype)
+        model = pyfem.Helmholtz(r0, X, conn, q, b)
+        np.random.seed(0)
+        g = np.random.rand(x.shape[0])
+        out = dict(
+            X=X, conn=conn.astype(np.int32), x=x, g=g, r0=np.float64(r0),
+            Ke0=model.Ke_mat[0].copy(), Re0=model.Re[0].copy(),
+            rho=model.apply(x).copy(), gradx=model.apply_gradient(g).copy(),
+            Rx=model.R.dot(x),
+        )
+        out.update(_csr(model.K, "K"))
+        out.update(_csr(model.R, "R"))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        np.random.seed(123)
+        pr = np.random.rand(x.shape[0])
+        print(f"{name}: nnz={model.K.nnz}  p.rho = {pr.dot(out['rho'])!r}")
+
+    # --- mesh generator pins (ProblemCreator, pyfem.py:2469-2520, 2728-2773) -------------
+    out = {}
+    for etype in ("quad", "tri"):
+        c = pyfem.ProblemCreator(nnodes_x=6, nnodes_y=4, element_type=etype)
+        conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+        _, _, x = c.create_helmhotz_problem()
+        _, _, pfix = c.create_poisson_problem()
+        out[f"{etype}_conn"] = conn.astype(np.int32)
+        out[f"{etype}_X"] = X
+        out[f"{etype}_dof_fixed"] = np.asarray(dof_fixed, dtype=np.int32)
+        out[f"{etype}_force_nodes"] = np.array(list(nodal_force.keys()), dtype=np.int32)
+        out[f"{etype}_force_vals"] = np.array(list(nodal_force.values()), dtype=float)
+        out[f"{etype}_helm_x"] = x
+        out[f"{etype}_poisson_fixed"] = np.asarray(pfix, dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "mesh6x4.npz"), **out)
+    print("mesh6x4 written")
+
+
+if __name__ == "__main__":
+    main()
