@@ -1,0 +1,149 @@
+/*
+ * pyfem_hip.h -- C ABI of libpyfem_hip.so, the MI355X (gfx950) implementation of the
+ * pyfem hot path: per-element Ke quadrature -> global sparse scatter -> Dirichlet BCs ->
+ * CSR SpMV / Jacobi-PCG.
+ *
+ * The reference (aaronyicongfu/pyfem_gpu_testflight) is pure Python and has no FFI; each
+ * entry point below names the reference method(s) it replaces (file:line relative to the
+ * reference checkout).  The Python shim that binds these with ctypes is
+ * pyfem_gpu_testflight_amd/_lib.py; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (PF_E_*); the message is available
+ *     from pf_last_error(ctx).  Nothing throws across the ABI.
+ *   - all array arguments are DEVICE pointers unless the name ends in _host or the doc says
+ *     otherwise; the caller owns them (the Python shim passes torch tensor data_ptr()s).
+ *   - the library owns the mesh copy and the symbolic pattern it builds (hipMalloc'd,
+ *     released by pf_ctx_destroy).
+ *   - work is enqueued on the stream given to pf_ctx_set_stream (default: the null stream);
+ *     calls that return host scalars synchronise that stream, the others are asynchronous.
+ *   - one ctx per host thread; a ctx is bound to one device.
+ *
+ * Matrix value layout ("vals"): the sparsity pattern is the node graph (nptr/nidx: node n
+ * couples to nodes nidx[nptr[n] .. nptr[n+1]), sorted ascending); each coupling carries a
+ * dense d x d block (d = dofs per node), stored block-contiguous, row-major inside the
+ * block:   vals[(nptr[n]+c)*d*d + k*d + l]  =  K[d*n+k, d*nidx[nptr[n]+c]+l].
+ * For d == 1 this IS scipy's CSR data order; for d == 2 pf_vals_to_csr converts to the
+ * CSR data order `coo_matrix(...).tocsr()` produces (reference pyfem.py:921-931).
+ */
+#ifndef PYFEM_HIP_H
+#define PYFEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_ctx pf_ctx;
+
+enum {
+  PF_OK = 0,
+  PF_E_INVALID = -1,   /* bad argument / call order            */
+  PF_E_HIP = -2,       /* a HIP runtime call failed             */
+  PF_E_UNSUPPORTED = -3, /* element type / size outside the path */
+  PF_E_NOCONV = -4     /* CG hit maxiter (reference: RuntimeError, pyfem.py:2421-2422) */
+};
+
+enum { PF_QUAD4 = 4, PF_TRI3 = 3 };          /* nodes per element selects the element */
+enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
+enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1 };
+
+/* ---- context -------------------------------------------------------------------------- */
+int pf_ctx_create(int device, pf_ctx** out);
+int pf_ctx_destroy(pf_ctx* ctx);
+const char* pf_last_error(pf_ctx* ctx);       /* ctx may be NULL: last global error      */
+int pf_ctx_set_stream(pf_ctx* ctx, void* hip_stream);
+int pf_version(void);
+
+/* ---- mesh: replaces ModelBase.__init__ storage (pyfem.py:659-661, 705-706) -------------- */
+/* X: (nnodes, 2) float64 row-major; conn: (nelems, P) int32 row-major, P in {3,4}.
+ * on_device != 0: pointers are device pointers; else host pointers.  Data is copied.
+ * Checks conn.min()==0 and conn.max()==nnodes-1 like pyfem.py:680-681 (PF_E_INVALID). */
+int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P,
+                const int32_t* conn, int on_device);
+
+/* ---- symbolic pattern: replaces utils.create_dof (utils.py:268-298) +
+ *      ModelBase._compute_nz_pattern (pyfem.py:838-858) + the structure half of
+ *      coo_matrix(...).tocsr() (pyfem.py:930-931) ------------------------------------------- */
+int pf_pattern_build(pf_ctx* ctx, int ndof_per_node /* 1 or 2 */);
+/* nrows = d*nnodes, nnz = d*d*nblocks */
+int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks, int32_t* max_row_blocks);
+/* node graph (device out): nptr int32[nnodes+1], nidx int32[nblocks]; either may be NULL */
+int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx);
+/* scipy-layout CSR structure (device out): indptr int32[nrows+1], indices int32[nnz] */
+int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices);
+
+/* ---- numeric assembly --------------------------------------------------------------------
+ * pf_assemble_elasticity2d replaces LinearElasticity.compute_jacobian (pyfem.py:1771-1795):
+ *   _update_material_property (:1923-1945, RAMP rho/(1+p(1-rho)) at quadrature points),
+ *   _compute_element_jacobian (:2030-2068 = utils.compute_jtrans/jdet/basis_grad,
+ *   _compute_element_Bmat :1976, _einsum_element_jacobian :2016) and
+ *   ModelBase._assemble_jacobian (:921-931), fused: Ke is never written to memory.
+ * rho: nodal density float64[nnodes] or NULL (== 1.0 everywhere, pyfem.py:1780-1781).
+ * mode: PF_SCATTER_GATHER (owner-computes rows, no atomics, deterministic) or
+ *       PF_SCATTER_ATOMIC (one lane per element, fp64 atomics; cross-check only).       */
+int pf_assemble_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
+                             int mode, double* Kvals);
+/* Helmholtz.__init__ / _compute_element_jacobian_and_rhs (pyfem.py:2085-2099, 2139-2177):
+ * Kvals = r0^2*stiffness + mass, Rvals = mass (either may be NULL).  d must be 1.        */
+int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
+
+/* Element matrices to memory, (nelems, D, D) row-major -- model.Ke_mat / model.Re readers
+ * (tests; examples/SciTech2023/performance/performance_test.py:52).                       */
+int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
+                                     double* Ke_out);
+int pf_element_matrices_helmholtz2d(pf_ctx* ctx, double r0, double* Ke_out, double* Re_out);
+
+/* block layout -> scipy CSR data order (identity copy for d == 1) */
+int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr_data);
+
+/* ---- boundary conditions: ModelBase.apply_dirichlet_bcs (pyfem.py:781-835) ---------------
+ * fixed_mask uint8[nrows] (1 = fixed dof); fixed_vals float64[nrows] (value at fixed dofs,
+ * ignored elsewhere) or NULL (all zero, pyfem.py:829-830).  In place on Kvals and rhs:
+ * rhs[free] -= K[free,fixed] vals (symmetric only), rows (and columns if symmetric) of
+ * fixed dofs zeroed, unit diagonal (diag_scale[dof] instead of 1 when diag_scale != NULL:
+ * used by the multi-GPU partition so a shared fixed dof sums to 1 over ranks), rhs[fixed]=vals.
+ * Exact zeros stay in the pattern (the reference's eliminate_zeros() happens on export).  */
+int pf_apply_dirichlet(pf_ctx* ctx, double* Kvals, double* rhs, const uint8_t* fixed_mask,
+                       const double* fixed_vals, int symmetric, const double* diag_scale);
+
+/* ---- sparse linear algebra: scipy CSR matvec / cg call sites (pyfem.py:2119, 2403-2423) -- */
+int pf_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y);
+int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
+
+/* Preconditioned CG on the ctx pattern:  stop when ||r||_2 <= max(rtol*||b||_2, atol)
+ * (the reference's `cg(K, rhs, tol=1e-8, atol=0.0)`, pyfem.py:2418).  x holds the initial
+ * guess on entry.  Returns PF_E_NOCONV when maxiter is hit (iters/relres still written).
+ * iters, relres: HOST out pointers.  check_every: residual is read back to the host every
+ * that many iterations (<=0: default 50); iteration count is exact to that granularity. */
+int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
+          int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
+
+/* CG building blocks for the one-process-per-GPU driver (pyfem_gpu_testflight_amd/dist.py);
+ * all asynchronous, scalars stay on the device.
+ *   pf_dot:  out[0] = sum_i w_i a_i b_i   (w NULL => 1)  -- out is zeroed by the call
+ *   pf_cg_update_xr:  alpha = rz[0]/pAp[0]; x += alpha p; r -= alpha Ap; z = dinv*r (dinv NULL: z=r);
+ *                     rz_new[0] = sum w r z ; rr[0] = sum w r r
+ *   pf_cg_update_p:   beta = rz_new[0]/rz_old[0]; p = z + beta p
+ *   pf_gather / pf_scatter_add: interface pack / unpack-accumulate by index list           */
+int pf_dot(pf_ctx* ctx, int64_t n, const double* a, const double* b, const double* w, double* out);
+int pf_cg_update_xr(pf_ctx* ctx, int64_t n, const double* rz, const double* pAp, const double* p,
+                    const double* Ap, const double* dinv, const double* w, double* x, double* r,
+                    double* z, double* rz_new, double* rr);
+int pf_cg_update_p(pf_ctx* ctx, int64_t n, const double* rz_new, const double* rz_old,
+                   const double* z, double* p);
+int pf_gather(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
+int pf_scatter_add(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
+
+/* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
+ *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */
+enum { PF_K_ASSEMBLE_ELASTICITY = 0, PF_K_SPMV = 1, PF_K_ASSEMBLE_HELMHOLTZ = 2 };
+int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const double* in1,
+                   double* out0, double E, double nu, double p, double* ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYFEM_HIP_H */

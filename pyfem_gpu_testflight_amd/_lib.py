@@ -1,0 +1,89 @@
+"""ctypes binding of libpyfem_hip.so (C ABI: include/pyfem_hip.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded the import of any
+compute entry point raises -- the product path never routes through a numpy stand-in.
+Status codes are turned into the exception types the reference raises at the same places
+(assert -> AssertionError for mesh checks, pyfem.py:680-681; RuntimeError for a failed
+iterative solve, pyfem.py:2421-2422; ValueError for unsupported element types, pyfem.py:2715).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyfem_hip.so")
+
+PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
+PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
+PF_PRECOND_NONE, PF_PRECOND_JACOBI = 0, 1
+PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); must list every symbol include/pyfem_hip.h declares
+SIGNATURES = {
+    "pf_version": (C.c_int, []),
+    "pf_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pf_ctx_destroy": (C.c_int, [_vp]),
+    "pf_last_error": (C.c_char_p, [_vp]),
+    "pf_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "pf_mesh_set": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, C.c_int]),
+    "pf_pattern_build": (C.c_int, [_vp, C.c_int]),
+    "pf_pattern_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
+    "pf_pattern_get_graph": (C.c_int, [_vp, _vp, _vp]),
+    "pf_pattern_get_csr": (C.c_int, [_vp, _vp, _vp]),
+    "pf_assemble_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, C.c_int, _vp]),
+    "pf_assemble_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_element_matrices_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp]),
+    "pf_element_matrices_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_vals_to_csr": (C.c_int, [_vp, _vp, _vp]),
+    "pf_apply_dirichlet": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "pf_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pf_extract_diag": (C.c_int, [_vp, _vp, _vp]),
+    "pf_cg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.c_int, C.POINTER(_i32),
+                        C.POINTER(_f64)]),
+    "pf_dot": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "pf_cg_update_xr": (C.c_int, [_vp, _i64] + [_vp] * 11),
+    "pf_cg_update_p": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "pf_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pf_scatter_add": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
+}
+
+_lib = None
+
+
+class PyfemHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and declare every signature.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m pyfem_gpu_testflight_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback for the accelerated path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc, what=""):
+    """Map a status code to the reference's exception behaviour."""
+    if rc == PF_OK:
+        return
+    msg = load().pf_last_error(ctx)
+    msg = msg.decode() if msg else f"{what}: error {rc}"
+    if rc == PF_E_NOCONV:
+        raise RuntimeError(msg)  # pyfem.py:2421-2422
+    if rc == PF_E_UNSUPPORTED:
+        raise ValueError(msg)  # pyfem.py:2715
+    if rc == PF_E_INVALID and "conn must span" in msg:
+        raise AssertionError(msg)  # pyfem.py:680-681
+    raise PyfemHipError(msg)

@@ -1,0 +1,82 @@
+// Internal header of libpyfem_hip.so (gfx950 only).  Public ABI: include/pyfem_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "pyfem_hip.h"
+
+struct pf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- mesh (device copies) ----
+  int64_t nnodes = 0, nelems = 0;
+  int P = 0;                 // nodes per element: 4 quad, 3 tri
+  double* X = nullptr;       // (nnodes,2)
+  int32_t* conn = nullptr;   // (nelems,P)
+
+  // ---- symbolic pattern ----
+  int d = 0;                 // dofs per node (block size)
+  int64_t nblocks = 0;       // node-graph nnz
+  int32_t max_row_blocks = 0;  // max neighbours of a node (incl. itself)
+  int32_t max_valence = 0;     // max elements around a node
+  int32_t* nptr = nullptr;   // (nnodes+1) node-graph row pointer
+  int32_t* nidx = nullptr;   // (nblocks)  neighbour node ids, ascending per row
+  int32_t* n2e_ptr = nullptr;  // (nnodes+1) node -> incident (element, local index) list
+  int32_t* n2e = nullptr;      // (nelems*P) entries e*P + a, ascending per node
+  uint8_t* n2e_pos = nullptr;  // (nelems*P*P) for incident pair j and element node b:
+                               //   position of conn[e,b] in row n of the node graph
+  uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
+  uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
+
+  // ---- scratch owned by the ctx ----
+  double* scal = nullptr;      // 8 device scalars for pf_cg
+  double* cgw = nullptr;       // CG work vectors (4*nrows), grown on demand
+  int64_t cgw_cap = 0;
+  void* scan_tmp = nullptr;
+  size_t scan_tmp_cap = 0;
+};
+
+extern thread_local std::string g_pf_err;
+
+static inline int pf_fail(pf_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_pf_err = msg;
+  return code;
+}
+
+#define PF_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return pf_fail(ctx, PF_E_HIP,                                                        \
+                     std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" +     \
+                         __FILE__ + ":" + std::to_string(__LINE__) + ")");                 \
+  } while (0)
+
+#define PF_REQUIRE(cond, msg)                                       \
+  do {                                                              \
+    if (!(cond)) return pf_fail(ctx, PF_E_INVALID, std::string(msg)); \
+  } while (0)
+
+#define PF_LAUNCH_CHECK() PF_HIP(hipGetLastError())
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+template <typename T>
+static inline void pf_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// internal entry points shared between translation units
+int pf_pattern_free(pf_ctx* ctx);
+int pf_ensure_e2pos(pf_ctx* ctx);
+int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, const double* rho, int mode,
+                                  double* Kvals);
+int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
+int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out,
+                   const double* dot_w);

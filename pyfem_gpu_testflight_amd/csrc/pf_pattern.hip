@@ -1,0 +1,421 @@
+// Context, mesh upload and the SYMBOLIC phase (sparsity pattern + gather maps), all on device.
+//
+// Replaces, for the accelerated path, the reference's host-side index bookkeeping:
+//   utils.create_dof (utils.py:268-298), ModelBase._compute_nz_pattern (pyfem.py:838-858) and
+//   the structure half of coo_matrix(...).tocsr() (pyfem.py:930-931).
+// The reference materialises 2*E*D^2 int64 COO indices (2.1 GB each at 4M quads) and lets scipy
+// sort them on every assembly.  Here the pattern is derived once from node->element incidence:
+//   1. count/scan/fill the node -> (element, local index) incidence lists (sorted ascending, so
+//      every later summation order is fixed = deterministic assembly),
+//   2. per node, merge the nodes of its incident elements into a sorted unique neighbour row
+//      (this is exactly the sorted, duplicate-free column set scipy's tocsr() ends up with),
+//   3. per (node, incident element, element node) store the 1-byte position of that element
+//      node inside the row: the numeric phase then needs no search and no atomics.
+// One thread per node; rows are short (9 for quads, ~7 for triangles) so the work is linear.
+#include <hipcub/hipcub.hpp>
+
+#include "pf_common.h"
+
+thread_local std::string g_pf_err;
+
+static constexpr int MAXNB = 64;  // max neighbours (incl. self) of one node; pos fits a byte
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_minmax_i32(const int32_t* __restrict__ v, int64_t n, int32_t* __restrict__ mm) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int32_t lo = INT32_MAX, hi = INT32_MIN;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t x = v[i];
+    lo = min(lo, x);
+    hi = max(hi, x);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], lo);
+    atomicMax(&mm[1], hi);
+  }
+}
+
+__global__ void k_count_incidence(const int32_t* __restrict__ conn, int64_t total, int32_t* __restrict__ cnt) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) atomicAdd(&cnt[conn[i]], 1);
+}
+
+__global__ void k_fill_incidence(const int32_t* __restrict__ conn, int64_t total, const int32_t* __restrict__ ptr,
+                                 int32_t* __restrict__ cursor, int32_t* __restrict__ n2e) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) {
+    int32_t n = conn[i];
+    int32_t s = atomicAdd(&cursor[n], 1);
+    n2e[ptr[n] + s] = (int32_t)i;  // i == e*P + a
+  }
+}
+
+// sort each node's incidence list ascending (lists are a handful of entries)
+__global__ void k_sort_incidence(int64_t nnodes, const int32_t* __restrict__ ptr, int32_t* __restrict__ n2e) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t b = ptr[n], e = ptr[n + 1];
+  for (int32_t i = b + 1; i < e; ++i) {
+    int32_t v = n2e[i];
+    int32_t j = i - 1;
+    while (j >= b && n2e[j] > v) {
+      n2e[j + 1] = n2e[j];
+      --j;
+    }
+    n2e[j + 1] = v;
+  }
+}
+
+// sorted-unique merge of the nodes of all incident elements of node n into nb[]; returns count
+// (or -1 on overflow)
+template <int P>
+__device__ inline int collect_row(int64_t n, const int32_t* __restrict__ conn, const int32_t* __restrict__ n2e_ptr,
+                                  const int32_t* __restrict__ n2e, int32_t* nb) {
+  int cnt = 0;
+  for (int32_t j = n2e_ptr[n]; j < n2e_ptr[n + 1]; ++j) {
+    int32_t e = n2e[j] / P;
+    for (int b = 0; b < P; ++b) {
+      int32_t m = conn[(int64_t)e * P + b];
+      int k = 0;
+      while (k < cnt && nb[k] < m) ++k;
+      if (k < cnt && nb[k] == m) continue;
+      if (cnt == MAXNB) return -1;
+      for (int t = cnt; t > k; --t) nb[t] = nb[t - 1];
+      nb[k] = m;
+      ++cnt;
+    }
+  }
+  return cnt;
+}
+
+template <int P>
+__global__ void k_row_count(int64_t nnodes, const int32_t* __restrict__ conn, const int32_t* __restrict__ n2e_ptr,
+                            const int32_t* __restrict__ n2e, int32_t* __restrict__ rowcnt, int32_t* __restrict__ flag) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t nb[MAXNB];
+  int c = collect_row<P>(n, conn, n2e_ptr, n2e, nb);
+  if (c < 0) {
+    atomicOr(flag, 1);
+    c = 0;
+  }
+  rowcnt[n] = c;
+}
+
+template <int P>
+__global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, const int32_t* __restrict__ n2e_ptr,
+                           const int32_t* __restrict__ n2e, const int32_t* __restrict__ nptr,
+                           int32_t* __restrict__ nidx, uint8_t* __restrict__ n2e_pos, uint8_t* __restrict__ diagpos) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t nb[MAXNB];
+  int c = collect_row<P>(n, conn, n2e_ptr, n2e, nb);
+  int32_t base = nptr[n];
+  for (int k = 0; k < c; ++k) {
+    nidx[base + k] = nb[k];
+    if (nb[k] == (int32_t)n) diagpos[n] = (uint8_t)k;
+  }
+  for (int32_t j = n2e_ptr[n]; j < n2e_ptr[n + 1]; ++j) {
+    int32_t e = n2e[j] / P;
+    for (int b = 0; b < P; ++b) {
+      int32_t m = conn[(int64_t)e * P + b];
+      int k = 0;
+      while (nb[k] != m) ++k;
+      n2e_pos[(int64_t)j * P + b] = (uint8_t)k;
+    }
+  }
+}
+
+// position of conn[e,b] in the row of conn[e,a]  (atomic-scatter mode only)
+template <int P>
+__global__ void k_e2pos(int64_t nelems, const int32_t* __restrict__ conn, const int32_t* __restrict__ nptr,
+                        const int32_t* __restrict__ nidx, uint8_t* __restrict__ e2pos) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;  // over e*P*P
+  if (i >= nelems * P * P) return;
+  int64_t e = i / (P * P);
+  int a = (int)(i % (P * P)) / P, b = (int)(i % P);
+  int32_t n = conn[e * P + a], m = conn[e * P + b];
+  int32_t lo = nptr[n], hi = nptr[n + 1] - 1;
+  while (lo < hi) {
+    int32_t mid = (lo + hi) >> 1;
+    if (nidx[mid] < m) lo = mid + 1; else hi = mid;
+  }
+  e2pos[i] = (uint8_t)(lo - nptr[n]);
+}
+
+template <int D>
+__global__ void k_csr_structure(int64_t nnodes, const int32_t* __restrict__ nptr, const int32_t* __restrict__ nidx,
+                                int32_t* __restrict__ indptr, int32_t* __restrict__ indices) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t b = nptr[n], c = nptr[n + 1] - b;
+  for (int k = 0; k < D; ++k) {
+    int64_t rowstart = (int64_t)D * D * b + (int64_t)k * D * c;
+    if (indptr) indptr[D * n + k] = (int32_t)rowstart;
+    if (indices)
+      for (int t = 0; t < c; ++t)
+        for (int l = 0; l < D; ++l) indices[rowstart + t * D + l] = D * nidx[b + t] + l;
+  }
+  if (indptr && n == nnodes - 1) indptr[D * nnodes] = D * D * nptr[nnodes];
+}
+
+template <int D>
+__global__ void k_vals_to_csr(int64_t nnodes, const int32_t* __restrict__ nptr, const double* __restrict__ vals,
+                              double* __restrict__ csr) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t b = nptr[n], c = nptr[n + 1] - b;
+  for (int t = 0; t < c; ++t)
+    for (int k = 0; k < D; ++k)
+      for (int l = 0; l < D; ++l)
+        csr[(int64_t)D * D * b + (int64_t)k * D * c + t * D + l] = vals[((int64_t)b + t) * D * D + k * D + l];
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int pf_version(void) { return 1; }
+
+extern "C" const char* pf_last_error(pf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_pf_err.c_str(); }
+
+extern "C" int pf_ctx_create(int device, pf_ctx** out) {
+  pf_ctx* ctx = nullptr;
+  if (!out) return pf_fail(nullptr, PF_E_INVALID, "pf_ctx_create: out is NULL");
+  int ndev = 0;
+  PF_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    return pf_fail(nullptr, PF_E_INVALID, "pf_ctx_create: no such device " + std::to_string(device));
+  PF_HIP(hipSetDevice(device));
+  ctx = new pf_ctx();
+  ctx->device = device;
+  hipError_t e = hipMalloc(&ctx->scal, 16 * sizeof(double));
+  if (e != hipSuccess) {
+    delete ctx;
+    return pf_fail(nullptr, PF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  *out = ctx;
+  return PF_OK;
+}
+
+int pf_pattern_free(pf_ctx* ctx) {
+  pf_free(ctx->nptr);
+  pf_free(ctx->nidx);
+  pf_free(ctx->n2e_ptr);
+  pf_free(ctx->n2e);
+  pf_free(ctx->n2e_pos);
+  pf_free(ctx->diagpos);
+  pf_free(ctx->e2pos);
+  ctx->d = 0;
+  ctx->nblocks = 0;
+  return PF_OK;
+}
+
+extern "C" int pf_ctx_destroy(pf_ctx* ctx) {
+  if (!ctx) return PF_OK;
+  (void)hipSetDevice(ctx->device);
+  pf_pattern_free(ctx);
+  pf_free(ctx->X);
+  pf_free(ctx->conn);
+  pf_free(ctx->scal);
+  pf_free(ctx->cgw);
+  if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
+  delete ctx;
+  return PF_OK;
+}
+
+extern "C" int pf_ctx_set_stream(pf_ctx* ctx, void* s) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  ctx->stream = (hipStream_t)s;
+  return PF_OK;
+}
+
+extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
+                           int on_device) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(P == PF_QUAD4 || P == PF_TRI3, "pf_mesh_set: only 4-node quads and 3-node triangles are on this path");
+  PF_REQUIRE(nnodes > 0 && nelems > 0 && X && conn, "pf_mesh_set: empty mesh");
+  PF_REQUIRE(nnodes < (int64_t)1 << 30 && nelems * P < (int64_t)1 << 31, "pf_mesh_set: mesh too large for int32 indices");
+  PF_HIP(hipSetDevice(ctx->device));
+  pf_pattern_free(ctx);
+  pf_free(ctx->X);
+  pf_free(ctx->conn);
+  ctx->nnodes = nnodes;
+  ctx->nelems = nelems;
+  ctx->P = P;
+  PF_HIP(hipMalloc(&ctx->X, sizeof(double) * 2 * nnodes));
+  PF_HIP(hipMalloc(&ctx->conn, sizeof(int32_t) * P * nelems));
+  hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  PF_HIP(hipMemcpyAsync(ctx->X, X, sizeof(double) * 2 * nnodes, kind, ctx->stream));
+  PF_HIP(hipMemcpyAsync(ctx->conn, conn, sizeof(int32_t) * P * nelems, kind, ctx->stream));
+  // conn range check (reference asserts: pyfem.py:680-681)
+  int32_t* mm = nullptr;
+  PF_HIP(hipMalloc(&mm, 2 * sizeof(int32_t)));
+  int32_t init[2] = {INT32_MAX, INT32_MIN};
+  PF_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  k_minmax_i32<<<1024, 256, 0, ctx->stream>>>(ctx->conn, nelems * P, mm);
+  int32_t got[2];
+  PF_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(mm);
+  if (got[0] != 0 || got[1] != nnodes - 1)
+    return pf_fail(ctx, PF_E_INVALID,
+                   "pf_mesh_set: conn must span 0..nnodes-1 (min " + std::to_string(got[0]) + ", max " +
+                       std::to_string(got[1]) + ", nnodes " + std::to_string(nnodes) + ")");
+  return PF_OK;
+}
+
+static int exclusive_scan_i32(pf_ctx* ctx, int32_t* in, int32_t* out, int64_t n) {
+  size_t need = 0;
+  PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, ctx->stream));
+  if (need > ctx->scan_tmp_cap) {
+    if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
+    ctx->scan_tmp = nullptr;
+    PF_HIP(hipMalloc(&ctx->scan_tmp, need));
+    ctx->scan_tmp_cap = need;
+  }
+  PF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->scan_tmp, need, in, out, (int)n, ctx->stream));
+  return PF_OK;
+}
+
+static int max_i32(pf_ctx* ctx, const int32_t* v, int64_t n, int32_t* out_host) {
+  int32_t* mm = nullptr;
+  PF_HIP(hipMalloc(&mm, 2 * sizeof(int32_t)));
+  int32_t init[2] = {INT32_MAX, INT32_MIN};
+  PF_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  k_minmax_i32<<<1024, 256, 0, ctx->stream>>>(v, n, mm);
+  int32_t got[2];
+  PF_HIP(hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(mm);
+  *out_host = got[1];
+  return PF_OK;
+}
+
+template <int P>
+static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
+  const int64_t nn = ctx->nnodes;
+  const int T = 128;
+  k_row_count<P><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, rowcnt, flag);
+  PF_LAUNCH_CHECK();
+  int32_t f = 0;
+  PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  if (f) return pf_fail(ctx, PF_E_UNSUPPORTED, "pf_pattern_build: a node has more than 64 neighbours");
+  int rc = exclusive_scan_i32(ctx, rowcnt, ctx->nptr, nn + 1);
+  if (rc) return rc;
+  int32_t total = 0;
+  PF_HIP(hipMemcpyAsync(&total, ctx->nptr + nn, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->nblocks = total;
+  PF_HIP(hipMalloc(&ctx->nidx, sizeof(int32_t) * (size_t)total));
+  PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * P));
+  PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
+  k_row_fill<P><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
+                                                              ctx->nidx, ctx->n2e_pos, ctx->diagpos);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->conn, "pf_pattern_build: call pf_mesh_set first");
+  PF_REQUIRE(d == 1 || d == 2, "pf_pattern_build: ndof_per_node must be 1 or 2");
+  PF_HIP(hipSetDevice(ctx->device));
+  pf_pattern_free(ctx);
+  const int64_t nn = ctx->nnodes, total = ctx->nelems * ctx->P;
+  const int T = 256;
+  int32_t *cnt = nullptr, *cursor = nullptr, *flag = nullptr;
+  PF_HIP(hipMalloc(&cnt, sizeof(int32_t) * (nn + 1)));
+  PF_HIP(hipMalloc(&cursor, sizeof(int32_t) * (nn + 1)));
+  PF_HIP(hipMalloc(&flag, sizeof(int32_t)));
+  PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (nn + 1), ctx->stream));
+  PF_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (nn + 1), ctx->stream));
+  PF_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx->stream));
+  PF_HIP(hipMalloc(&ctx->n2e_ptr, sizeof(int32_t) * (nn + 1)));
+  PF_HIP(hipMalloc(&ctx->n2e, sizeof(int32_t) * total));
+  PF_HIP(hipMalloc(&ctx->nptr, sizeof(int32_t) * (nn + 1)));
+
+  k_count_incidence<<<(unsigned)cdiv(total, T), T, 0, ctx->stream>>>(ctx->conn, total, cnt);
+  PF_LAUNCH_CHECK();
+  int rc = max_i32(ctx, cnt, nn, &ctx->max_valence);
+  if (rc) return rc;
+  rc = exclusive_scan_i32(ctx, cnt, ctx->n2e_ptr, nn + 1);
+  if (rc) return rc;
+  k_fill_incidence<<<(unsigned)cdiv(total, T), T, 0, ctx->stream>>>(ctx->conn, total, ctx->n2e_ptr, cursor, ctx->n2e);
+  PF_LAUNCH_CHECK();
+  k_sort_incidence<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, ctx->n2e);
+  PF_LAUNCH_CHECK();
+  // row counts go into cnt (reused), scanned into nptr
+  PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (nn + 1), ctx->stream));
+  rc = (ctx->P == 4) ? build_rows<4>(ctx, cnt, flag) : build_rows<3>(ctx, cnt, flag);
+  if (rc == PF_OK) rc = max_i32(ctx, cnt, nn, &ctx->max_row_blocks);
+  (void)hipFree(cnt);
+  (void)hipFree(cursor);
+  (void)hipFree(flag);
+  if (rc) {
+    pf_pattern_free(ctx);
+    return rc;
+  }
+  PF_REQUIRE((int64_t)d * d * ctx->nblocks < ((int64_t)1 << 31), "pf_pattern_build: nnz exceeds int32 (scipy CSR index type)");
+  ctx->d = d;
+  return PF_OK;
+}
+
+int pf_ensure_e2pos(pf_ctx* ctx) {
+  if (ctx->e2pos) return PF_OK;
+  const int P = ctx->P;
+  const int64_t n = ctx->nelems * P * P;
+  PF_HIP(hipMalloc(&ctx->e2pos, (size_t)n));
+  if (P == 4)
+    k_e2pos<4><<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(ctx->nelems, ctx->conn, ctx->nptr, ctx->nidx, ctx->e2pos);
+  else
+    k_e2pos<3><<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(ctx->nelems, ctx->conn, ctx->nptr, ctx->nidx, ctx->e2pos);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks, int32_t* max_row_blocks) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_pattern_dims: no pattern built");
+  if (nrows) *nrows = ctx->d * ctx->nnodes;
+  if (nnz) *nnz = (int64_t)ctx->d * ctx->d * ctx->nblocks;
+  if (nblocks) *nblocks = ctx->nblocks;
+  if (max_row_blocks) *max_row_blocks = ctx->max_row_blocks;
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_pattern_get_graph: no pattern built");
+  if (nptr) PF_HIP(hipMemcpyAsync(nptr, ctx->nptr, sizeof(int32_t) * (ctx->nnodes + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  if (nidx) PF_HIP(hipMemcpyAsync(nidx, ctx->nidx, sizeof(int32_t) * ctx->nblocks, hipMemcpyDeviceToDevice, ctx->stream));
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_pattern_get_csr: no pattern built");
+  const int T = 128;
+  unsigned g = (unsigned)cdiv(ctx->nnodes, T);
+  if (ctx->d == 1)
+    k_csr_structure<1><<<g, T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, indptr, indices);
+  else
+    k_csr_structure<2><<<g, T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, indptr, indices);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && vals && csr, "pf_vals_to_csr: no pattern / NULL argument");
+  if (ctx->d == 1) {
+    PF_HIP(hipMemcpyAsync(csr, vals, sizeof(double) * ctx->nblocks, hipMemcpyDeviceToDevice, ctx->stream));
+    return PF_OK;
+  }
+  const int T = 128;
+  k_vals_to_csr<2><<<(unsigned)cdiv(ctx->nnodes, T), T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, vals, csr);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}

@@ -1,0 +1,241 @@
+"""Thin object layer over the C ABI: one HipContext per model, torch tensors as device
+arrays (the library only ever sees their data_ptr()), and DeviceCSR -- the object
+`compute_jacobian()` returns in place of the reference's scipy CSR (pyfem.py:921-931):
+values stay in HBM; a scipy matrix is materialised only if host code touches it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "pyfem_gpu_testflight_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False "
+            "and there is no CPU fallback for the accelerated path")
+    return torch
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipContext:
+    """Owns a pf_ctx: device mesh copy + symbolic pattern.  ref: ModelBase.__init__ (pyfem.py:640-757)."""
+
+    def __init__(self, X, conn, ndof_per_node, device=None):
+        torch = _torch()
+        self.torch = torch
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._ctx = C.c_void_p()
+        _lib.check(None, self.lib.pf_ctx_create(self.device.index, C.byref(self._ctx)), "pf_ctx_create")
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        conn = np.asarray(conn)
+        if X.ndim != 2 or X.shape[1] != 2:
+            raise ValueError("the accelerated path covers 2-D meshes (X of shape (nnodes, 2)) only")
+        if conn.ndim != 2 or conn.shape[1] not in (3, 4):
+            raise ValueError(f"unknown element_type: {conn.shape[1]}-node elements are not on the accelerated path")
+        conn32 = np.ascontiguousarray(conn, dtype=np.int32)
+        self.nnodes, self.nelems, self.P, self.d = X.shape[0], conn.shape[0], conn.shape[1], int(ndof_per_node)
+        self._sync_stream()
+        self._call("pf_mesh_set", _lib._i64(self.nnodes), X.ctypes.data_as(C.c_void_p), _lib._i64(self.nelems),
+                   self.P, conn32.ctypes.data_as(C.c_void_p), 0)
+        self._call("pf_pattern_build", self.d)
+        nrows, nnz, nblocks, maxrow = _lib._i64(), _lib._i64(), _lib._i64(), _lib._i32()
+        self._call("pf_pattern_dims", C.byref(nrows), C.byref(nnz), C.byref(nblocks), C.byref(maxrow))
+        self.nrows, self.nnz, self.nblocks, self.max_row_blocks = nrows.value, nnz.value, nblocks.value, maxrow.value
+        self._csr_structure = None
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _sync_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.pf_ctx_set_stream(self._ctx, C.c_void_p(s))
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self._ctx, *args)
+        _lib.check(self._ctx, rc, name)
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self.lib.pf_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def empty(self, n, dtype=None):
+        return self.torch.empty(int(n), dtype=dtype or self.torch.float64, device=self.device)
+
+    def zeros(self, n, dtype=None):
+        return self.torch.zeros(int(n), dtype=dtype or self.torch.float64, device=self.device)
+
+    def to_device(self, a, dtype=None):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype or a.dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+
+    # -- symbolic -------------------------------------------------------------------------
+    def csr_structure(self):
+        """(indptr, indices) int32 numpy arrays in scipy's layout (sorted columns)."""
+        if self._csr_structure is None:
+            torch = self.torch
+            indptr = self.empty(self.nrows + 1, torch.int32)
+            indices = self.empty(self.nnz, torch.int32)
+            self._sync_stream()
+            self._call("pf_pattern_get_csr", _ptr(indptr), _ptr(indices))
+            self._csr_structure = (indptr.cpu().numpy(), indices.cpu().numpy())
+        return self._csr_structure
+
+    def graph(self):
+        torch = self.torch
+        nptr = self.empty(self.nnodes + 1, torch.int32)
+        nidx = self.empty(self.nblocks, torch.int32)
+        self._sync_stream()
+        self._call("pf_pattern_get_graph", _ptr(nptr), _ptr(nidx))
+        return nptr, nidx
+
+    # -- numeric --------------------------------------------------------------------------
+    def assemble_elasticity(self, E, nu, p, rho=None, mode=_lib.PF_SCATTER_GATHER, out=None):
+        vals = self.empty(self.nnz) if out is None else out
+        self._sync_stream()
+        self._call("pf_assemble_elasticity2d", E, nu, p, _ptr(rho), mode, _ptr(vals))
+        return vals
+
+    def assemble_helmholtz(self, r0):
+        K, R = self.empty(self.nnz), self.empty(self.nnz)
+        self._sync_stream()
+        self._call("pf_assemble_helmholtz2d", r0, _ptr(K), _ptr(R))
+        return K, R
+
+    def element_matrices_elasticity(self, E, nu, p, rho=None):
+        D = self.P * 2
+        out = self.empty(self.nelems * D * D)
+        self._sync_stream()
+        self._call("pf_element_matrices_elasticity2d", E, nu, p, _ptr(rho), _ptr(out))
+        return out.view(self.nelems, D, D)
+
+    def element_matrices_helmholtz(self, r0):
+        Ke, Re = self.empty(self.nelems * self.P * self.P), self.empty(self.nelems * self.P * self.P)
+        self._sync_stream()
+        self._call("pf_element_matrices_helmholtz2d", r0, _ptr(Ke), _ptr(Re))
+        return Ke.view(self.nelems, self.P, self.P), Re.view(self.nelems, self.P, self.P)
+
+    def vals_to_csr(self, vals):
+        out = self.empty(self.nnz)
+        self._sync_stream()
+        self._call("pf_vals_to_csr", _ptr(vals), _ptr(out))
+        return out
+
+    def apply_dirichlet(self, vals, rhs, mask, fixed_vals=None, symmetric=True, diag_scale=None):
+        self._sync_stream()
+        self._call("pf_apply_dirichlet", _ptr(vals), _ptr(rhs), _ptr(mask), _ptr(fixed_vals), int(bool(symmetric)),
+                   _ptr(diag_scale))
+
+    def spmv(self, vals, x, out=None):
+        y = self.empty(self.nrows) if out is None else out
+        self._sync_stream()
+        self._call("pf_spmv", _ptr(vals), _ptr(x), _ptr(y))
+        return y
+
+    def diag(self, vals):
+        out = self.empty(self.nrows)
+        self._sync_stream()
+        self._call("pf_extract_diag", _ptr(vals), _ptr(out))
+        return out
+
+    def cg(self, vals, b, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI, check_every=50):
+        """Jacobi-PCG on device.  Returns (x, iters, relres); raises RuntimeError on non-convergence
+        like the reference (pyfem.py:2421-2422)."""
+        x = self.zeros(self.nrows) if x0 is None else x0.clone()
+        iters, relres = _lib._i32(), _lib._f64()
+        self._sync_stream()
+        self._call("pf_cg", _ptr(vals), _ptr(b), _ptr(x), rtol, atol, int(maxiter), precond, int(check_every),
+                   C.byref(iters), C.byref(relres))
+        return x, iters.value, relres.value
+
+    def time_kernel(self, which, reps, in0=None, in1=None, out0=None, E=0.0, nu=0.0, p=0.0):
+        ms = _lib._f64()
+        self._sync_stream()
+        self._call("pf_time_kernel", which, reps, _ptr(in0), _ptr(in1), _ptr(out0), E, nu, p, C.byref(ms))
+        return ms.value
+
+
+class DeviceCSR:
+    """Device-resident sparse matrix on a HipContext pattern.
+
+    Quacks like the scipy CSR the reference returns wherever its tests/examples touch it
+    (`K.dot(v)`, `K - K2`, `abs(K)`, `.data`, `.indptr`, `.diagonal()`, `.nnz`, `.shape`):
+    `dot` with a vector runs the HIP SpMV; anything else materialises a scipy matrix once
+    (explicit zeros are dropped on export only if `eliminate_zeros` was requested, which is what
+    apply_dirichlet_bcs does in the reference, pyfem.py:826)."""
+
+    def __init__(self, hctx, vals, eliminate_zeros=False):
+        self.hctx = hctx
+        self.vals = vals
+        self._eliminate = eliminate_zeros
+        self._host = None
+
+    @property
+    def shape(self):
+        return (self.hctx.nrows, self.hctx.nrows)
+
+    def invalidate(self):
+        self._host = None
+
+    def to_scipy(self):
+        if self._host is None:
+            from scipy import sparse
+
+            indptr, indices = self.hctx.csr_structure()
+            data = self.hctx.vals_to_csr(self.vals).cpu().numpy()
+            K = sparse.csr_matrix((data, indices.copy(), indptr.copy()), shape=self.shape)
+            if self._eliminate:
+                K.eliminate_zeros()
+            self._host = K
+        return self._host
+
+    tocsr = to_scipy
+
+    def dot(self, v):
+        torch = self.hctx.torch
+        if isinstance(v, torch.Tensor):
+            return self.hctx.spmv(self.vals, v)
+        v = np.asarray(v)
+        if v.ndim == 1 and v.dtype != complex:
+            y = self.hctx.spmv(self.vals, self.hctx.to_device(v, torch.float64))
+            return y.cpu().numpy()
+        return self.to_scipy().dot(v)
+
+    __matmul__ = dot
+
+    def copy(self):
+        return DeviceCSR(self.hctx, self.vals.clone(), self._eliminate)
+
+    def __getattr__(self, name):  # everything else: delegate to the materialised scipy matrix
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.to_scipy(), name)
+
+    def __sub__(self, other):
+        return self.to_scipy() - (other.to_scipy() if isinstance(other, DeviceCSR) else other)
+
+    def __rsub__(self, other):
+        return other - self.to_scipy()
+
+    def __add__(self, other):
+        return self.to_scipy() + (other.to_scipy() if isinstance(other, DeviceCSR) else other)
+
+    def __abs__(self):
+        return abs(self.to_scipy())
+
+    def __getitem__(self, key):
+        return self.to_scipy()[key]

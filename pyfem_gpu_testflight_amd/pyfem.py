@@ -1,0 +1,437 @@
+"""Host-side mirror of the reference's `pyfem` module surface for the accelerated path.
+
+Same class names, constructor signatures and method names as the reference
+(aaronyicongfu/pyfem_gpu_testflight, pyfem.py) so its tests and examples read unchanged:
+
+    creator = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)
+    conn, X, dof_fixed, nodal_force = creator.create_linear_elasticity_problem()
+    quadrature = pyfem.QuadratureBilinear2D(); basis = pyfem.BasisBilinear2D(quadrature)
+    model = pyfem.LinearElasticity(X, conn, dof_fixed, None, nodal_force, quadrature, basis)
+    u = pyfem.Assembler(model).solve(method="cg")
+
+What runs where: everything with an element or nonzero axis (quadrature, scatter, BCs, SpMV,
+CG) runs in hand-written HIP kernels through the C ABI (include/pyfem_hip.h); this file only
+holds the host logic the reference has around those calls.  There is no numpy fallback: without
+the library or a GPU the constructors raise.
+
+Scope: 2-D 4-node quads and 3-node triangles; LinearElasticity (plane
+stress, RAMP density), Helmholtz filter, Assembler.solve.  3-D elements, LinearPoisson,
+NonlinearPoisson2D, A2DWrapper, the sensitivity pass and complex-step dtypes are outside the
+accelerated path and raise NotImplementedError here.
+"""
+import numpy as np
+
+from . import _lib
+from .device import DeviceCSR, HipContext
+from .utils import time_this
+
+# tolerance used by the device PCG wherever the reference asks scipy/pyamg for tol=1e-8
+# (pyfem.py:1827, 2107, 2418).  Tighter than the reference so that ||u - u_direct||_inf stays
+# below 1e-8 ||u||_inf (BASELINE.json north_star) on ill-conditioned large meshes.
+DEFAULT_RTOL = 1e-10
+
+
+# ------------------------------------------------------------------------------------------
+# tables (host copies for API parity; the kernels carry the same constants at compile time)
+# ------------------------------------------------------------------------------------------
+class QuadratureBase:
+    def __init__(self, pts, weights):
+        self.pts = np.asarray(pts, dtype=float)
+        self.weights = np.asarray(weights, dtype=float)
+        self.nquads = self.pts.shape[0]
+
+    def get_nquads(self):
+        return self.nquads
+
+    def get_pt(self, idx=None):
+        return self.pts[idx] if idx else self.pts
+
+    def get_weight(self, idx=None):
+        return self.weights[idx] if idx else self.weights
+
+
+class QuadratureTriangle2D(QuadratureBase):
+    """ref: pyfem.py:68-80 -- one point (1/3, 1/3), weight 1 * 0.5."""
+
+    def __init__(self):
+        super().__init__([[1.0 / 3, 1.0 / 3]], [0.5])
+
+
+class QuadratureBilinear2D(QuadratureBase):
+    """ref: pyfem.py:83-94 -- 2x2 Gauss, order (-,-),(+,-),(+,+),(-,+), unit weights."""
+
+    def __init__(self):
+        g = 1.0 / np.sqrt(3.0)
+        super().__init__([[-g, -g], [g, -g], [g, g], [-g, g]], [1.0, 1.0, 1.0, 1.0])
+
+
+class BasisBase:
+    def __init__(self, ndims, nnodes_per_elem, quadrature):
+        self.ndims = ndims
+        self.nnodes_per_elem = nnodes_per_elem
+        self.quadrature = quadrature
+        self.nquads = quadrature.get_nquads()
+        self.N = None
+        self.Nderiv = None
+
+    def eval_shape_fun(self):
+        if self.N is None:
+            self.N = np.array([self._eval_shape_fun_on_quad_pt(q) for q in self.quadrature.get_pt()])
+        return self.N
+
+    def eval_shape_fun_deriv(self):
+        if self.Nderiv is None:
+            self.Nderiv = np.array([self._eval_shape_deriv_on_quad_pt(q) for q in self.quadrature.get_pt()]).reshape(
+                (self.nquads, self.nnodes_per_elem, self.ndims))
+        return self.Nderiv
+
+
+class BasisBilinear2D(BasisBase):
+    """ref: pyfem.py:253-284."""
+
+    def __init__(self, quadrature):
+        super().__init__(2, 4, quadrature)
+
+    def _eval_shape_fun_on_quad_pt(self, q):
+        return [0.25 * (1 - q[0]) * (1 - q[1]), 0.25 * (1 + q[0]) * (1 - q[1]),
+                0.25 * (1 + q[0]) * (1 + q[1]), 0.25 * (1 - q[0]) * (1 + q[1])]
+
+    def _eval_shape_deriv_on_quad_pt(self, q):
+        return [-0.25 * (1 - q[1]), -0.25 * (1 - q[0]), 0.25 * (1 - q[1]), -0.25 * (1 + q[0]),
+                0.25 * (1 + q[1]), 0.25 * (1 + q[0]), -0.25 * (1 + q[1]), 0.25 * (1 - q[0])]
+
+
+class BasisTriangle2D(BasisBase):
+    """ref: pyfem.py:341-377."""
+
+    def __init__(self, quadrature):
+        super().__init__(2, 3, quadrature)
+
+    def _eval_shape_fun_on_quad_pt(self, q):
+        return [q[0], q[1], 1 - q[0] - q[1]]
+
+    def _eval_shape_deriv_on_quad_pt(self, q):
+        return [1.0, 0.0, 0.0, 1.0, -1.0, -1.0]
+
+
+def _check_tables(quadrature, basis):
+    """The kernels hard-wire the two (quadrature, basis) pairs on the path; refuse anything else."""
+    ok = (isinstance(quadrature, QuadratureBilinear2D) and isinstance(basis, BasisBilinear2D)) or (
+        isinstance(quadrature, QuadratureTriangle2D) and isinstance(basis, BasisTriangle2D))
+    if not ok:
+        raise NotImplementedError(
+            "accelerated path: only (QuadratureBilinear2D, BasisBilinear2D) and "
+            "(QuadratureTriangle2D, BasisTriangle2D) are implemented as HIP kernels")
+
+
+# ------------------------------------------------------------------------------------------
+# models
+# ------------------------------------------------------------------------------------------
+class ModelBase:
+    """ref: pyfem.py:634-931.  Holds the host copies the reference exposes (X, conn, dof arrays, rhs)
+    and a HipContext with the device mesh + symbolic pattern."""
+
+    def __init__(self, ndof_per_node, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=None):
+        _check_tables(quadrature, basis)
+        self.ndof_per_node = ndof_per_node
+        self.X = np.array(X, dtype=float)
+        self.conn = np.array(conn, dtype=int)
+        self.dof_fixed = np.array(dof_fixed, dtype=int)
+        self.dof_fixed_vals = None if dof_fixed_vals is None else np.array(dof_fixed_vals, dtype=float)
+        self.quadrature = quadrature
+        self.basis = basis
+        self.nelems, self.nnodes_per_elem = self.conn.shape
+        self.nnodes, self.ndims = self.X.shape
+        self.nquads = quadrature.get_nquads()
+        if self.nnodes_per_elem != basis.nnodes_per_elem:
+            raise ValueError("conn does not match the basis' nodes per element")
+        self.nodes = np.arange(self.nnodes)
+        # conn range is asserted on device by pf_mesh_set (ref: pyfem.py:680-681)
+        self.hctx = HipContext(self.X, self.conn, ndof_per_node, device=device)
+        self.ndof = self.nnodes * ndof_per_node
+        self.dof = np.arange(self.ndof)
+        self.dof_each_node = self.dof.reshape(self.nnodes, ndof_per_node) if ndof_per_node > 1 else self.nodes
+        self._fixed_mask_host = np.zeros(self.ndof, dtype=np.uint8)
+        self._fixed_mask_host[self.dof_fixed] = 1
+        self.dof_free = np.flatnonzero(self._fixed_mask_host == 0)
+        torch = self.hctx.torch
+        self._fixed_mask = self.hctx.to_device(self._fixed_mask_host, torch.uint8)
+        if self.dof_fixed_vals is None:
+            self._fixed_vals = None
+        else:
+            fv = np.zeros(self.ndof)
+            fv[self.dof_fixed] = self.dof_fixed_vals
+            self._fixed_vals = self.hctx.to_device(fv, torch.float64)
+        self.rhs = np.zeros(self.ndof)
+
+    @property
+    def conn_dof(self):
+        """ref: utils.py:268-298 (host view for readers; the kernels derive dofs from conn)."""
+        d = self.ndof_per_node
+        if d == 1:
+            return self.conn
+        out = np.empty((self.nelems, self.nnodes_per_elem * d), dtype=int)
+        for k in range(d):
+            out[:, k::d] = d * self.conn + k
+        return out
+
+    @time_this
+    def apply_dirichlet_bcs(self, K, rhs, enforce_symmetric_K=True):
+        """ref: pyfem.py:781-835.  K: DeviceCSR from compute_jacobian (modified in place, like the
+        reference mutates its argument); rhs: numpy array (modified in place) or device tensor."""
+        if not isinstance(K, DeviceCSR):
+            raise TypeError("apply_dirichlet_bcs expects the DeviceCSR returned by compute_jacobian()")
+        torch = self.hctx.torch
+        on_device = isinstance(rhs, torch.Tensor)
+        rhs_d = rhs if on_device else self.hctx.to_device(rhs, torch.float64)
+        self.hctx.apply_dirichlet(K.vals, rhs_d, self._fixed_mask, self._fixed_vals, enforce_symmetric_K)
+        K.invalidate()
+        K._eliminate = True  # the reference ends with K.eliminate_zeros() (pyfem.py:826)
+        if on_device:
+            return K, rhs_d
+        rhs[:] = rhs_d.cpu().numpy()
+        return K, rhs
+
+
+class LinearElasticity(ModelBase):
+    """ref: pyfem.py:1667-2068 (2-D plane stress branch)."""
+
+    @time_this
+    def __init__(self, X, conn, dof_fixed, dof_fixed_vals, nodal_force, quadrature, basis, E=10.0, nu=0.3, p=0.0,
+                 device=None):
+        X = np.asarray(X)
+        if X.shape[1] != 2:
+            raise NotImplementedError("accelerated path: 3-D elasticity is out of scope (SURVEY.md section 2, row 6)")
+        super().__init__(2, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
+        self.nodal_force = nodal_force
+        self.E, self.nu, self.p = float(E), float(nu), float(p)
+        self.C0 = E * np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, 0.5 * (1.0 - nu)]])
+        self.C0 *= 1.0 / (1.0 - nu**2)
+        self.scatter_mode = _lib.PF_SCATTER_GATHER
+        self._last_rho = None
+
+    @time_this
+    def compute_rhs(self):
+        """ref: pyfem.py:1761-1768 -- point loads by assignment into the persistent model.rhs."""
+        nodes = list(self.nodal_force.keys())
+        self.rhs[self.dof_each_node[nodes].flatten()] = np.array(list(self.nodal_force.values())).flatten()
+        return self.rhs
+
+    def _rho_device(self, rho):
+        torch = self.hctx.torch
+        if isinstance(rho, torch.Tensor):
+            if rho.is_complex():
+                raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
+            return rho.to(device=self.hctx.device, dtype=torch.float64).contiguous()
+        if not hasattr(rho, "__len__"):
+            if rho == 1.0:
+                return None  # rho == 1 => Cq == 1 for every p (pyfem.py:1780-1781, 1944)
+            rho = np.ones(self.nnodes) * rho
+        rho = np.asarray(rho)
+        if np.iscomplexobj(rho):
+            raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
+        if rho.shape != (self.nnodes,):
+            raise ValueError("rho must be nodal: shape (nnodes,)")
+        return self.hctx.to_device(rho.astype(float), torch.float64)
+
+    @time_this
+    def compute_jacobian(self, rho=1.0, out=None):
+        """ref: pyfem.py:1771-1795.  Returns a DeviceCSR; Ke never exists in memory."""
+        rho_d = self._rho_device(rho)
+        self._last_rho = rho_d
+        vals = self.hctx.assemble_elasticity(self.E, self.nu, self.p, rho_d, self.scatter_mode,
+                                             out=None if out is None else out.vals)
+        if out is not None:
+            out.invalidate()
+            out._eliminate = False
+            return out
+        return DeviceCSR(self.hctx, vals)
+
+    @property
+    def Ke_mat(self):
+        """(nelems, 8|6, 8|6) element matrices for the last density (ref attribute: pyfem.py:717-723)."""
+        return self.hctx.element_matrices_elasticity(self.E, self.nu, self.p, self._last_rho).cpu().numpy()
+
+    @time_this
+    def compliance(self, rho, solver="cg"):
+        """ref: pyfem.py:1798-1834."""
+        assert solver == "direct" or solver == "cg" or solver == "gmres"
+        K = self.compute_jacobian(rho)
+        rhs = self.compute_rhs()
+        K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+        u = Assembler(self)._solve_linear_system(K, rhs, solver)
+        return rhs.dot(u), u
+
+    def volume(self, rho):
+        """ref: pyfem.py:1851-1859."""
+        return rho.sum() / self.nnodes
+
+    def volume_grad(self, rho):
+        """ref: pyfem.py:1862-1870."""
+        return np.ones(self.nnodes) / self.nnodes
+
+    def compliance_grad(self, rho, u):
+        raise NotImplementedError("sensitivity pass (_compute_K_dv_sens, pyfem.py:1873-1920) is a 'next' row "
+                                  "(SURVEY.md 8f, f2) and not on the accelerated path yet")
+
+    _compute_K_dv_sens = compliance_grad
+
+
+class Helmholtz(ModelBase):
+    """ref: pyfem.py:2069-2177.  K = r0^2 A + M and R = M assembled once on device; apply() solves
+    K rho = R x with device Jacobi-PCG (the reference uses pyamg ruge_stuben V-cycles to tol 1e-8)."""
+
+    @time_this
+    def __init__(self, r0, X, conn, quadrature, basis, device=None):
+        super().__init__(1, X, conn, [], None, quadrature, basis, device=device)
+        self.r0 = float(r0)
+        Kv, Rv = self.hctx.assemble_helmholtz(self.r0)
+        self.K = DeviceCSR(self.hctx, Kv)
+        self.R = DeviceCSR(self.hctx, Rv)
+        self.RT = self.R  # the mass matrix is symmetric (ref keeps R.transpose(), pyfem.py:2096)
+        self.rtol = DEFAULT_RTOL
+        self.last_iters = 0
+
+    def _solve(self, b_dev):
+        x, it, _ = self.hctx.cg(self.K.vals, b_dev, rtol=self.rtol)
+        self.last_iters = it
+        return x
+
+    @time_this
+    def apply(self, x):
+        """ref: pyfem.py:2102-2107."""
+        torch = self.hctx.torch
+        on_device = isinstance(x, torch.Tensor)
+        xd = x if on_device else self.hctx.to_device(x, torch.float64)
+        rho = self._solve(self.hctx.spmv(self.R.vals, xd))
+        return rho if on_device else rho.cpu().numpy()
+
+    @time_this
+    def apply_gradient(self, gradrho):
+        """ref: pyfem.py:2110-2115."""
+        torch = self.hctx.torch
+        on_device = isinstance(gradrho, torch.Tensor)
+        gd = gradrho if on_device else self.hctx.to_device(gradrho, torch.float64)
+        gx = self.hctx.spmv(self.RT.vals, self._solve(gd))
+        return gx if on_device else gx.cpu().numpy()
+
+    @time_this
+    def compute_rhs(self, x):
+        """ref: pyfem.py:2118-2120."""
+        self.rhs[:] = self.R.dot(np.asarray(x, dtype=float))
+        return self.rhs
+
+    def compute_jacobian(self):
+        return self.K
+
+    @property
+    def Ke_mat(self):
+        return self.hctx.element_matrices_helmholtz(self.r0)[0].cpu().numpy()
+
+    @property
+    def Re(self):
+        return self.hctx.element_matrices_helmholtz(self.r0)[1].cpu().numpy()
+
+
+def _not_on_path(name, where):
+    class _Stub:
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} ({where}) is outside the accelerated hot path (SURVEY.md section 2)")
+
+    _Stub.__name__ = name
+    return _Stub
+
+
+LinearPoisson = _not_on_path("LinearPoisson", "pyfem.py:934-1329")
+NonlinearPoisson2D = _not_on_path("NonlinearPoisson2D", "pyfem.py:1332-1664")
+A2DWrapper = _not_on_path("A2DWrapper", "pyfem.py:2180-2283")
+
+
+# ------------------------------------------------------------------------------------------
+class Assembler:
+    """ref: pyfem.py:2286-2423."""
+
+    @time_this
+    def __init__(self, model):
+        self.model = model
+        self.rtol = DEFAULT_RTOL
+        self.last_iters = None
+        self.last_relres = None
+
+    @time_this
+    def solve(self, method="gmres"):
+        """ref: pyfem.py:2299-2317."""
+        assert method == "direct" or method == "cg" or method == "gmres"
+        K = self.model.compute_jacobian()
+        rhs = self.model.compute_rhs()
+        K, rhs = self.model.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+        return self._solve_linear_system(K, rhs, method)
+
+    @time_this
+    def _solve_linear_system(self, K, rhs, method):
+        """ref: pyfem.py:2403-2423.
+        "direct": scipy spsolve on the exported matrix -- the reference's own third-party call, kept
+                  for small meshes / parity checks (not an accelerated leg).
+        "cg" and "gmres": device Jacobi-PCG.  K is SPD after symmetric BC elimination, so CG reaches
+                  the same solution GMRES does; the reference's pyamg preconditioner is not available."""
+        if method == "direct":
+            from scipy.sparse.linalg import spsolve
+
+            return spsolve(K.to_scipy().tocsc(), np.asarray(rhs))
+        hctx = K.hctx
+        torch = hctx.torch
+        on_device = isinstance(rhs, torch.Tensor)
+        b = rhs if on_device else hctx.to_device(rhs, torch.float64)
+        try:
+            x, it, rr = hctx.cg(K.vals, b, rtol=self.rtol)
+        except RuntimeError as e:
+            raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
+        self.last_iters, self.last_relres = it, rr
+        return x if on_device else x.cpu().numpy()
+
+    def solve_nonlinear(self, *a, **k):
+        raise NotImplementedError("Newton solve (pyfem.py:2320-2355) is outside the accelerated hot path")
+
+
+# ------------------------------------------------------------------------------------------
+class ProblemCreator:
+    """Vectorised equivalent of the reference's loop-based generator (pyfem.py:2426-2773) for the
+    2-D element types on the path; produces identical conn / X / dof_fixed / nodal_force."""
+
+    def __init__(self, nnodes_x, nnodes_y, nnodes_z=None, Lx=None, Ly=None, Lz=None, element_type="quad"):
+        if nnodes_z is not None:
+            raise NotImplementedError("accelerated path: 3-D meshes are out of scope")
+        assert element_type == "quad" or element_type == "tri"
+        self.ndims = 2
+        Lx = (nnodes_x - 1) / (nnodes_y - 1) if Lx is None else Lx
+        Ly = 1.0 if Ly is None else Ly
+        x = np.linspace(0, Lx, nnodes_x)
+        y = np.linspace(0, Ly, nnodes_y)
+        self.X = np.stack([np.tile(x, nnodes_y), np.repeat(y, nnodes_x)], axis=1)
+        self.nodes3d = np.arange(nnodes_x * nnodes_y).reshape((1, nnodes_y, nnodes_x))
+        n00 = self.nodes3d[0, :-1, :-1].ravel()
+        n10, n11, n01 = n00 + 1, n00 + 1 + nnodes_x, n00 + nnodes_x
+        if element_type == "quad":
+            conn = np.stack([n00, n10, n11, n01], axis=1)
+        else:
+            conn = np.empty((2 * n00.size, 3), dtype=int)
+            conn[0::2] = np.stack([n00, n10, n11], axis=1)
+            conn[1::2] = np.stack([n11, n01, n00], axis=1)
+        self.conn = conn.astype(int)
+        self.nnodes_x, self.nnodes_y, self.nnodes_z = nnodes_x, nnodes_y, 1
+        self.nnodes = nnodes_x * nnodes_y
+
+    def create_poisson_problem(self):
+        return self.conn, self.X, list(self.nodes3d[0, :, 0])
+
+    def create_linear_elasticity_problem(self):
+        col0 = self.nodes3d[0, :, 0]
+        dof_fixed = list(np.stack([2 * col0, 2 * col0 + 1], axis=1).ravel())
+        nodal_force = {int(self.nodes3d[0, 0, -1]): [0.0, -1.0]}
+        return self.conn, self.X, dof_fixed, nodal_force
+
+    def create_helmhotz_problem(self):
+        i = np.tile(np.arange(self.nnodes_x), self.nnodes_y)
+        j = np.repeat(np.arange(self.nnodes_y), self.nnodes_x)
+        x = np.where((i < self.nnodes_x / 2) & (j < self.nnodes_y / 2), 0.95, 1e-3)
+        return self.conn, self.X, x

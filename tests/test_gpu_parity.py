@@ -1,0 +1,304 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the product path:
+pyfem_gpu_testflight_amd.pyfem -> ctypes -> libpyfem_hip.so.  The oracle (oracle/pyfem_oracle.py)
+and the committed reference fixtures (tests/golden) are only the checkers.
+
+Bars (BASELINE.json north_star): max|K - K_ref| <= 1e-10 max|K_ref| ;  ||u - u_ref||_inf <= 1e-8 ||u_ref||_inf.
+"""
+import numpy as np
+import pytest
+
+from tests._golden import ELASTICITY_CASES, HELMHOLTZ_CASES, csr_of, force_dict, load, relmax
+
+pytestmark = pytest.mark.gpu
+
+K_TOL = 1e-10
+U_TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from pyfem_gpu_testflight_amd import pyfem
+
+    return pyfem
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import pyfem_oracle
+
+    return pyfem_oracle
+
+
+def _qb(pf, etype):
+    if etype == "quad":
+        q = pf.QuadratureBilinear2D()
+        return q, pf.BasisBilinear2D(q)
+    q = pf.QuadratureTriangle2D()
+    return q, pf.BasisTriangle2D(q)
+
+
+def _model(pf, g, etype):
+    q, b = _qb(pf, etype)
+    return pf.LinearElasticity(g["X"], g["conn"], g["dof_fixed"], g.get("fixed_vals"), force_dict(g), q, b,
+                               p=float(g["p"]))
+
+
+def test_native_library_is_loaded(pf):
+    """The product path must be the HIP library, not a fallback."""
+    import ctypes
+
+    from pyfem_gpu_testflight_amd import _lib
+
+    lib = _lib.load()
+    assert isinstance(lib, ctypes.CDLL) and lib.pf_version() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libpyfem_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", list(ELASTICITY_CASES))
+@pytest.mark.parametrize("mode", ["gather", "atomic"])
+def test_elasticity_K_matches_reference(pf, orc, name, mode):
+    from pyfem_gpu_testflight_amd import _lib
+
+    g = load(name)
+    etype = ELASTICITY_CASES[name]
+    model = _model(pf, g, etype)
+    model.scatter_mode = _lib.PF_SCATTER_GATHER if mode == "gather" else _lib.PF_SCATTER_ATOMIC
+    K = model.compute_jacobian() if "rho" not in g else model.compute_jacobian(g["rho"])
+    Ks = K.to_scipy()
+    n = 2 * g["X"].shape[0]
+    assert Ks.shape == (n, n) and Ks.nnz == int(g["K_nnz"])
+    kmax = np.abs(g["K_diag"]).max()
+    # fixtures from the reference itself
+    assert abs(np.linalg.norm(Ks.data) - float(g["K_norm"])) <= 1e-10 * float(g["K_norm"])
+    assert np.abs(Ks.diagonal() - g["K_diag"]).max() <= K_TOL * kmax
+    assert relmax(K.dot(g["v"]), g["Kv"]) < K_TOL  # HIP SpMV on the HIP-assembled K
+    if "K_data" in g:
+        Kref = csr_of(g, "K", n)
+        assert np.array_equal(Ks.indptr, Kref.indptr) and np.array_equal(Ks.indices, Kref.indices)
+        assert np.abs(Ks.data - Kref.data).max() <= K_TOL * np.abs(Kref.data).max()
+    # oracle on the same inputs, entry by entry
+    Ko = orc.assemble_csr(orc.elasticity_Ke(g["X"], g["conn"].astype(np.int64), etype, rho=g.get("rho"),
+                                            p=float(g["p"])), orc.create_conn_dof(g["conn"].astype(np.int64), 2))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+
+
+@pytest.mark.parametrize("name", ["ps13x9_quad_distorted", "ps11x8_tri_ramp", "arm_tri"])
+def test_element_matrices(pf, orc, name):
+    g = load(name)
+    etype = ELASTICITY_CASES[name]
+    model = _model(pf, g, etype)
+    if "rho" in g:
+        model.compute_jacobian(g["rho"])
+    else:
+        model.compute_jacobian()
+    Ke = model.Ke_mat
+    Ko = orc.elasticity_Ke(g["X"], g["conn"].astype(np.int64), etype, rho=g.get("rho"), p=float(g["p"]))
+    assert Ke.shape == Ko.shape
+    assert np.abs(Ke - Ko).max() <= K_TOL * np.abs(Ko).max()
+    assert np.abs(Ke[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
+    assert np.abs(Ke[-1] - g["Ke_last"]).max() <= K_TOL * np.abs(g["Ke_last"]).max()
+
+
+@pytest.mark.parametrize("name", list(ELASTICITY_CASES))
+def test_dirichlet_and_solve(pf, name):
+    g = load(name)
+    etype = ELASTICITY_CASES[name]
+    for symmetric, kv, rv in ((True, "Kbc_v", "rhs_bc"), (False, "Kns_v", "rhs_ns")):
+        model = _model(pf, g, etype)
+        K = model.compute_jacobian() if "rho" not in g else model.compute_jacobian(g["rho"])
+        rhs = model.compute_rhs()
+        assert np.array_equal(rhs, g["rhs"])
+        K, rhs = model.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=symmetric)
+        assert rhs is model.rhs  # mutated in place like the reference (pyfem.py:829-834)
+        assert np.abs(rhs - g[rv]).max() <= 1e-12 * max(1.0, np.abs(g[rv]).max())
+        assert relmax(K.dot(g["v"]), g[kv]) < K_TOL
+        assert relmax(K.to_scipy().dot(g["v"]), g[kv]) < K_TOL
+    # K now holds the symmetric=False system; redo symmetric for the solves
+    model = _model(pf, g, etype)
+    K = model.compute_jacobian() if "rho" not in g else model.compute_jacobian(g["rho"])
+    K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
+    asm = pf.Assembler(model)
+    u_direct = asm._solve_linear_system(K, rhs, "direct")
+    assert relmax(u_direct, g["u"]) < U_TOL
+    if name != "arm_tri":  # arm: all detJ < 0 => K negative definite, see test_arm_negative_definite_cg
+        u_cg = asm._solve_linear_system(K, rhs, "cg")
+        assert relmax(u_cg, g["u"]) < U_TOL
+        assert asm.last_iters > 0
+
+
+def test_assembler_solve_ps32_like_reference_test(pf):
+    """tests/test_elasticity.py:23-51 of the reference, against its recorded answer."""
+    creator = pf.ProblemCreator(nnodes_x=32, nnodes_y=32)
+    conn, X, dof_fixed, nodal_force = creator.create_linear_elasticity_problem()
+    quadrature = pf.QuadratureBilinear2D()
+    basis = pf.BasisBilinear2D(quadrature)
+    g = load("ps32_quad")
+    np.random.seed(123)
+    p = np.random.rand(g["u"].shape[0])
+    for method in ("direct", "cg", "gmres"):
+        model = pf.LinearElasticity(X, conn, dof_fixed, None, nodal_force, quadrature, basis)
+        u = pf.Assembler(model).solve(method=method)
+        pTu, pTu_ref = p.dot(u), p.dot(g["u"])
+        assert abs((pTu - pTu_ref) / pTu) < (1e-10 if method == "direct" else 1e-8)
+        assert abs(pTu / -164.42713355728523 - 1) < 1e-8
+
+
+def test_arm_negative_definite_cg(pf):
+    """arm.inp: every triangle has detJ < 0 and the reference does not take |detJ|, so
+    K is negative definite on the free dofs (+1 on fixed).  CG must still reproduce the reference u."""
+    g = load("arm_tri")
+    model = _model(pf, g, "tri")
+    u = pf.Assembler(model).solve(method="cg")
+    assert relmax(u, g["u"]) < U_TOL
+    np.random.seed(123)
+    p = np.random.rand(u.shape[0])
+    assert abs(p.dot(u) / 21177.45599189116 - 1) < 1e-8
+
+
+@pytest.mark.parametrize("name", list(HELMHOLTZ_CASES))
+def test_helmholtz(pf, name):
+    g = load(name)
+    etype = HELMHOLTZ_CASES[name]
+    q, b = _qb(pf, etype)
+    model = pf.Helmholtz(float(g["r0"]), g["X"], g["conn"], q, b)
+    n = g["X"].shape[0]
+    for M, pre in ((model.K, "K"), (model.R, "R")):
+        ref = csr_of(g, pre, n)
+        Ms = M.to_scipy()
+        assert np.array_equal(Ms.indptr, ref.indptr) and np.array_equal(Ms.indices, ref.indices)
+        assert np.abs(Ms.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
+    assert np.abs(model.Ke_mat[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
+    assert np.abs(model.Re[0] - g["Re0"]).max() <= K_TOL * np.abs(g["Re0"]).max()
+    assert relmax(model.compute_rhs(g["x"]), g["Rx"]) < K_TOL
+    rho = model.apply(g["x"])
+    gradx = model.apply_gradient(g["g"])
+    assert relmax(rho, g["rho"]) < U_TOL
+    assert relmax(gradx, g["gradx"]) < U_TOL
+    if name == "helm32_quad":  # tests/test_helmholtz.py:32-42
+        np.random.seed(123)
+        p = np.random.rand(n)
+        assert abs(p.dot(rho) / 116.98194101446458 - 1) < 1e-8
+
+
+def test_gather_assembly_is_bitwise_deterministic(pf):
+    g = load("arm_tri")
+    model = _model(pf, g, "tri")
+    a = model.compute_jacobian().vals.clone()
+    for _ in range(3):
+        b = model.compute_jacobian().vals
+        assert bool((a == b).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (3, 2), (65, 2), (2, 70), (64, 3), (129, 5)])
+@pytest.mark.parametrize("etype", ["quad", "tri"])
+def test_ragged_sizes(pf, orc, shape, etype):
+    """single element, and node counts around the 64-node wave tile."""
+    nx, ny = shape
+    conn, X = orc.structured_mesh(nx, ny, etype)
+    rng = np.random.RandomState(nx * 100 + ny)
+    X = X + 0.1 / max(nx, ny) * (rng.rand(*X.shape) - 0.5)
+    rho = 0.3 + 0.7 * rng.rand(X.shape[0])
+    q, b = _qb(pf, etype)
+    model = pf.LinearElasticity(X, conn, [0, 1], None, {X.shape[0] - 1: [0.0, -1.0]}, q, b, p=2.0)
+    Ks = model.compute_jacobian(rho).to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X, conn, etype, rho=rho, p=2.0), orc.create_conn_dof(conn, 2))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    hm = pf.Helmholtz(0.3, X, conn, q, b)
+    f = orc.HelmholtzFilter(0.3, X, conn, etype)
+    assert np.abs(hm.K.to_scipy().data - f.K.data).max() <= K_TOL * np.abs(f.K.data).max()
+    assert np.abs(hm.R.to_scipy().data - f.R.data).max() <= K_TOL * np.abs(f.R.data).max()
+
+
+def test_shuffled_unstructured_numbering(pf, orc):
+    """random node and element permutation of a tri mesh: valence / row lengths vary per wave."""
+    conn, X = orc.structured_mesh(37, 23, "tri")
+    rng = np.random.RandomState(3)
+    perm = rng.permutation(X.shape[0])
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    X2 = X[perm]
+    conn2 = inv[conn][rng.permutation(conn.shape[0])]
+    q, b = _qb(pf, "tri")
+    model = pf.LinearElasticity(X2, conn2, [0, 1, 2], None, {5: [1.0, -1.0]}, q, b)
+    Ks = model.compute_jacobian().to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X2, conn2, "tri"), orc.create_conn_dof(conn2, 2))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    v = rng.rand(Ko.shape[0])
+    assert relmax(model.compute_jacobian().dot(v), Ko.dot(v)) < K_TOL
+
+
+def test_error_behaviour(pf):
+    q, b = _qb(pf, "quad")
+    c = pf.ProblemCreator(4, 4)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    bad = conn.copy()
+    bad[bad == bad.max()] = bad.max() + 3  # conn.max() != nnodes-1  -> reference asserts (pyfem.py:680-681)
+    with pytest.raises(AssertionError):
+        pf.LinearElasticity(np.vstack([X, X[:3]]), bad, dof_fixed, None, force, q, b)
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    with pytest.raises(AssertionError):
+        pf.Assembler(model).solve(method="lu")  # pyfem.py:2306
+    with pytest.raises(NotImplementedError):
+        model.compute_jacobian(np.ones(X.shape[0]) + 1j * 1e-30)
+    # singular system (no BCs) with a tiny iteration cap -> RuntimeError like pyfem.py:2421-2422
+    free = pf.LinearElasticity(X, conn, [], None, force, q, b)
+    K = free.compute_jacobian()
+    import torch
+
+    with pytest.raises(RuntimeError, match="failed with code"):
+        free.hctx.cg(K.vals, free.hctx.to_device(free.compute_rhs(), torch.float64), rtol=1e-14, maxiter=3)
+
+
+def test_large_mesh_properties(pf):
+    """1024^2 quads (BASELINE config 2): size-independent properties instead of an oracle run."""
+    import torch
+
+    n = 1025
+    c = pf.ProblemCreator(n, n)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q, b = _qb(pf, "quad")
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    K = model.compute_jacobian()
+    h = model.hctx
+    assert h.nnz == 4 * (3 * 1024 + 1) ** 2  # SURVEY.md section 8 header
+    ndof = 2 * n * n
+    # rigid translations and the linearised rotation are in the null space of the unconstrained K
+    tx = torch.zeros(ndof, dtype=torch.float64, device=h.device)
+    tx[0::2] = 1.0
+    Xd = h.to_device(X, torch.float64)
+    rot = torch.empty(ndof, dtype=torch.float64, device=h.device)
+    rot[0::2] = -Xd[:, 1]
+    rot[1::2] = Xd[:, 0]
+    kmax = float(K.vals.abs().max())
+    assert float(K.dot(tx).abs().max()) < 1e-11 * kmax
+    assert float(K.dot(rot).abs().max()) < 1e-11 * kmax
+    # uniform square mesh: the reference's Ke row is mesh-size independent; diag of an
+    # interior node is 4 * Ke[0,0]
+    d = h.diag(K.vals)
+    interior = 2 * (n * (n // 2) + n // 2)
+    assert abs(float(d[interior]) / (4 * 4.945054945055) - 1) < 1e-11
+    # symmetry: x.Ky == y.Kx
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.rand(ndof, generator=g, dtype=torch.float64).to(h.device)
+    y = torch.rand(ndof, generator=g, dtype=torch.float64).to(h.device)
+    a, bb = float(x.dot(K.dot(y))), float(y.dot(K.dot(x)))
+    assert abs(a - bb) < 1e-10 * abs(a)
+    # atomic scatter agrees with the deterministic gather scatter
+    from pyfem_gpu_testflight_amd import _lib
+
+    Ka = h.assemble_elasticity(model.E, model.nu, model.p, None, _lib.PF_SCATTER_ATOMIC)
+    assert float((Ka - K.vals).abs().max()) < 1e-12 * kmax
+    # BCs + PCG: residual and the fixed dofs
+    rhs = h.to_device(model.compute_rhs(), torch.float64)
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+    u, it, relres = h.cg(K.vals, rhs, rtol=1e-6, maxiter=20000)
+    r = rhs - K.dot(u)
+    assert float(r.norm()) <= 1.5e-6 * float(rhs.norm())
+    assert float(u[torch.as_tensor(np.asarray(dof_fixed), device=h.device)].abs().max()) == 0.0
