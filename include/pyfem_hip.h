@@ -136,6 +136,26 @@ int pf_cg_update_p(pf_ctx* ctx, int64_t n, const double* rz_new, const double* r
                    const double* z, double* p);
 int pf_gather(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
 int pf_scatter_add(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
+int pf_scatter_set(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
+/* dst[dst_idx[i]] = src[src_idx[i]], i < n  (either index list may be NULL = identity): packs the
+ * interface rows of a vector into the all-reduce buffer and unpacks the reduced values. */
+int pf_copy_indexed(pf_ctx* ctx, int64_t n, const int32_t* src_idx, const int32_t* dst_idx,
+                    const double* src, double* dst);
+
+/* Single-reduction (Chronopoulos-Gear) PCG steps for the partitioned solve: ONE all-reduce per
+ * iteration carries the interface partial sums of w = A z together with gamma = r.z, delta = z.w
+ * and r.r.  `state` is a device array [alpha, beta, gamma]; `red` the reduced [gamma, delta, rr].
+ *   pf_spmv_dot:        y = A x ; dot_out[0] += x . y          (dot_out NOT cleared by the call)
+ *   pf_cgcg_update_xrz: x += alpha p; r -= alpha s; z = dinv*r; gamma += sum w r z; rr += sum w r r
+ *   pf_cgcg_scalars:    beta = first ? 0 : gamma_new/gamma; alpha = gamma_new/(delta - beta*gamma_new/alpha)
+ *   pf_cgcg_update_ps:  p = z + beta p ; s = w + beta s                                     */
+int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out);
+int pf_cgcg_update_xrz(pf_ctx* ctx, int64_t n, const double* state, const double* p, const double* s,
+                       const double* dinv, const double* w, double* x, double* r, double* z,
+                       double* gamma_out, double* rr_out);
+int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, int first);
+int pf_cgcg_update_ps(pf_ctx* ctx, int64_t n, const double* state, const double* z, const double* w,
+                      double* p, double* s);
 
 /* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
  *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */

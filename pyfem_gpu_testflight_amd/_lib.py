@@ -46,6 +46,12 @@ SIGNATURES = {
     "pf_cg_update_p": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "pf_scatter_add": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pf_scatter_set": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pf_copy_indexed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pf_cgcg_update_xrz": (C.c_int, [_vp, _i64] + [_vp] * 10),
+    "pf_cgcg_scalars": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "pf_cgcg_update_ps": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
 }
 
@@ -61,6 +67,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  If this library (linked
+    # against the system ROCm) is dlopen'ed first, the process ends up with two HSA runtimes and the
+    # second one sees no device.  Loading torch first makes both share torch's copy.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m pyfem_gpu_testflight_amd.build` "

@@ -253,6 +253,71 @@ __global__ void k_scatter_add(int64_t n, const int32_t* __restrict__ idx, const 
   if (i < n) dst[idx[i]] += src[i];  // idx entries are unique within one call
 }
 
+__global__ void k_scatter_set(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src,
+                              double* __restrict__ dst) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[idx[i]] = src[i];
+}
+
+__global__ void k_copy_indexed(int64_t n, const int32_t* __restrict__ si, const int32_t* __restrict__ di,
+                               const double* __restrict__ src, double* __restrict__ dst) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[di ? di[i] : i] = src[si ? si[i] : i];
+}
+
+// ---- single-reduction (Chronopoulos-Gear) PCG steps; state = [alpha, beta, gamma] ----------
+__global__ __launch_bounds__(256) void k_cgcg_update_xrz(int64_t n, const double* __restrict__ state,
+                                                         const double* __restrict__ p, const double* __restrict__ s,
+                                                         const double* __restrict__ dinv, const double* __restrict__ w,
+                                                         double* __restrict__ x, double* __restrict__ r,
+                                                         double* __restrict__ z, double* __restrict__ gamma_out,
+                                                         double* __restrict__ rr_out) {
+  const double alpha = state[0];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * s[i];
+    r[i] = ri;
+    const double zi = dinv ? dinv[i] * ri : ri;
+    z[i] = zi;
+    const double wi = w ? w[i] : 1.0;
+    s1 += wi * ri * zi;
+    s2 += wi * ri * ri;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) {
+    unsafeAtomicAdd(gamma_out, s1);
+    unsafeAtomicAdd(rr_out, s2);
+  }
+}
+
+__global__ void k_cgcg_scalars(double* __restrict__ state, const double* __restrict__ red, int first) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double gamma_new = red[0], delta = red[1];
+  double alpha, beta;
+  if (first) {
+    beta = 0.0;
+    alpha = gamma_new / delta;
+  } else {
+    beta = gamma_new / state[2];
+    alpha = gamma_new / (delta - beta * gamma_new / state[0]);
+  }
+  state[0] = alpha;
+  state[1] = beta;
+  state[2] = gamma_new;
+}
+
+__global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double* __restrict__ state,
+                                                        const double* __restrict__ z, const double* __restrict__ w,
+                                                        double* __restrict__ p, double* __restrict__ s) {
+  const double beta = state[1];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    p[i] = z[i] + beta * p[i];
+    s[i] = w[i] + beta * s[i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 static inline unsigned vec_grid(int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8); }
 static inline unsigned spmv_grid(int64_t nnodes) { return (unsigned)std::min<int64_t>(cdiv(nnodes, SPMV_TILE), 256 * 16); }
@@ -346,6 +411,59 @@ extern "C" int pf_scatter_add(pf_ctx* ctx, int64_t n, const int32_t* idx, const 
   if (n == 0) return PF_OK;
   PF_REQUIRE(idx && src && dst, "pf_scatter_add: NULL argument");
   k_scatter_add<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, idx, src, dst);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_scatter_set(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (n == 0) return PF_OK;
+  PF_REQUIRE(idx && src && dst, "pf_scatter_set: NULL argument");
+  k_scatter_set<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, idx, src, dst);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_copy_indexed(pf_ctx* ctx, int64_t n, const int32_t* src_idx, const int32_t* dst_idx,
+                               const double* src, double* dst) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (n == 0) return PF_OK;
+  PF_REQUIRE(src && dst, "pf_copy_indexed: NULL argument");
+  k_copy_indexed<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, src_idx, dst_idx, src, dst);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_spmv_dot: no pattern built");
+  PF_REQUIRE(vals && x && y && dot_out && x != y, "pf_spmv_dot: NULL argument or x aliases y");
+  return pf_launch_spmv(ctx, vals, x, y, dot_out, nullptr);
+}
+
+extern "C" int pf_cgcg_update_xrz(pf_ctx* ctx, int64_t n, const double* state, const double* p, const double* s,
+                                  const double* dinv, const double* w, double* x, double* r, double* z,
+                                  double* gamma_out, double* rr_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(state && p && s && x && r && z && gamma_out && rr_out, "pf_cgcg_update_xrz: NULL argument");
+  k_cgcg_update_xrz<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, p, s, dinv, w, x, r, z, gamma_out, rr_out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, int first) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(state && red, "pf_cgcg_scalars: NULL argument");
+  k_cgcg_scalars<<<1, 64, 0, ctx->stream>>>(state, red, first);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_cgcg_update_ps(pf_ctx* ctx, int64_t n, const double* state, const double* z, const double* w,
+                                 double* p, double* s) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(state && z && w && p && s, "pf_cgcg_update_ps: NULL argument");
+  k_cgcg_update_ps<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, z, w, p, s);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

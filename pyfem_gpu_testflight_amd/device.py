@@ -152,14 +152,17 @@ class HipContext:
         self._call("pf_extract_diag", _ptr(vals), _ptr(out))
         return out
 
-    def cg(self, vals, b, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI, check_every=50):
+    def cg(self, vals, b, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI, check_every=50,
+           allow_maxiter=False):
         """Jacobi-PCG on device.  Returns (x, iters, relres); raises RuntimeError on non-convergence
-        like the reference (pyfem.py:2421-2422)."""
+        like the reference (pyfem.py:2421-2422) unless allow_maxiter (fixed-iteration benchmarking)."""
         x = self.zeros(self.nrows) if x0 is None else x0.clone()
         iters, relres = _lib._i32(), _lib._f64()
         self._sync_stream()
-        self._call("pf_cg", _ptr(vals), _ptr(b), _ptr(x), rtol, atol, int(maxiter), precond, int(check_every),
-                   C.byref(iters), C.byref(relres))
+        rc = self.lib.pf_cg(self._ctx, _ptr(vals), _ptr(b), _ptr(x), rtol, atol, int(maxiter), precond,
+                            int(check_every), C.byref(iters), C.byref(relres))
+        if not (allow_maxiter and rc == _lib.PF_E_NOCONV):
+            _lib.check(self._ctx, rc, "pf_cg")
         return x, iters.value, relres.value
 
     def time_kernel(self, which, reps, in0=None, in1=None, out0=None, E=0.0, nu=0.0, p=0.0):

@@ -1,0 +1,289 @@
+"""One-process-per-GPU partitioned assembly and solve (torch.distributed: RCCL on GPUs, gloo in
+the CPU tests).  Nothing like this exists in the reference (it is single-process numpy); the
+partition follows BASELINE.json north_star: contiguous ELEMENT blocks per rank.
+
+Layout
+  * rank r owns elements [r*E/W, (r+1)*E/W).  Its local mesh is those elements over the nodes
+    they touch, renumbered in ascending global order (so local rows/columns keep the global
+    relative order).  Assembly of the local K needs no communication; rows of interface nodes
+    hold partial sums.
+  * vectors (x, r, z, p, s, b) are CONSISTENT: an interface dof carries the full value on
+    every rank that has it.  Products w = K z are completed by summing interface rows over ranks.
+  * all interface dofs of the job form one packed "interface vector" (G entries).  Each CG
+    iteration does ONE all-reduce of G+3 doubles: interface partial sums of w plus the three
+    scalars gamma = r.z, delta = z.w, r.r (Chronopoulos-Gear single-reduction PCG), so the
+    iteration has a single synchronisation point and no host round trip.  delta uses
+    z.(K z) = sum_ranks z_loc.(K_loc z_loc), so it is taken from the un-summed local product;
+    gamma and r.r count every dof once through the ownership mask (lowest rank owns).
+  * xGMI is point-to-point: for strip partitions (structured meshes) G is tiny (one node row per
+    cut) and the all-reduce is latency-bound -- see DESIGN.md for the numbers and the next step
+    (neighbour P2P + overlap with the interior SpMV).
+
+`LocalOps` is what the driver needs from a rank-local backend.  The product backend is
+HipLocalOps (C ABI -> HIP kernels).  tests/ provides a numpy stand-in so the partition logic and
+the iteration can be exercised under gloo with world_size 2 on a CPU-only host.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------
+# partition
+# ------------------------------------------------------------------------------------------
+class ElementBlockPartition:
+    """Element-block partition of (conn, nnodes) for `world` ranks, seen from `rank`."""
+
+    def __init__(self, conn, nnodes, world, rank, ndof_per_node):
+        conn = np.asarray(conn)
+        E = conn.shape[0]
+        if E < world:
+            raise ValueError("fewer elements than ranks")
+        self.world, self.rank, self.d = world, rank, ndof_per_node
+        bounds = [(r * E) // world for r in range(world + 1)]
+        self.elem_range = (bounds[rank], bounds[rank + 1])
+        count = np.zeros(nnodes, dtype=np.int32)
+        owner = np.full(nnodes, world, dtype=np.int32)
+        mine = None
+        for r in range(world):
+            nodes_r = np.unique(conn[bounds[r]:bounds[r + 1]])
+            count[nodes_r] += 1
+            owner[nodes_r] = np.minimum(owner[nodes_r], r)
+            if r == rank:
+                mine = nodes_r
+        self.nodes = mine  # ascending global node ids of this rank
+        self.nnodes_local = mine.size
+        self.conn_local = np.searchsorted(mine, conn[bounds[rank]:bounds[rank + 1]]).astype(np.int32)
+        iface_nodes = np.flatnonzero(count > 1)  # global interface nodes, ascending
+        self.n_iface_dofs = iface_nodes.size * ndof_per_node  # G
+        slot_of = np.full(nnodes, -1, dtype=np.int64)
+        slot_of[iface_nodes] = np.arange(iface_nodes.size)
+        shared_local = np.flatnonzero(count[mine] > 1)  # local node ids on an interface
+        d = ndof_per_node
+        k = np.arange(d)
+        self.iface_local_dofs = (shared_local[:, None] * d + k).ravel().astype(np.int32)
+        self.iface_slots = (slot_of[mine[shared_local]][:, None] * d + k).ravel().astype(np.int32)
+        self.owned_mask_nodes = owner[mine] == rank
+        self.own_weight = np.repeat(self.owned_mask_nodes.astype(np.float64), d)  # per local dof
+        self.multiplicity = np.repeat(count[mine].astype(np.float64), d)
+
+    def local_dofs_of(self, global_dofs):
+        """Map global dof ids to local ones; returns (local_ids, mask_present)."""
+        g = np.asarray(global_dofs, dtype=np.int64)
+        node, k = g // self.d, g % self.d
+        pos = np.searchsorted(self.nodes, node)
+        pos = np.minimum(pos, self.nodes.size - 1)
+        present = self.nodes[pos] == node
+        return (pos[present] * self.d + k[present]).astype(np.int64), present
+
+    def global_dofs(self):
+        return (self.nodes[:, None] * self.d + np.arange(self.d)).ravel()
+
+
+# ------------------------------------------------------------------------------------------
+# rank-local backend on the HIP library
+# ------------------------------------------------------------------------------------------
+class HipLocalOps:
+    """Rank-local kernels through the C ABI.  Vectors are torch.float64 tensors on the rank's GPU."""
+
+    def __init__(self, hctx):
+        from . import _lib
+
+        self.h = hctx
+        self.lib = hctx.lib
+        self._lib = _lib
+        self.torch = hctx.torch
+        self.device = hctx.device
+        self.n = hctx.nrows
+
+    def _p(self, t):
+        return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+    def _call(self, name, *a):
+        self.h._sync_stream()
+        self._lib.check(self.h._ctx, getattr(self.lib, name)(self.h._ctx, *a), name)
+
+    def zeros(self, n, dtype=None):
+        return self.torch.zeros(int(n), dtype=dtype or self.torch.float64, device=self.device)
+
+    def from_numpy(self, a, dtype=None):
+        return self.h.to_device(a, dtype)
+
+    def diag(self, K):
+        return self.h.diag(K)
+
+    def spmv_dot(self, K, x, y, dot_out):
+        self._call("pf_spmv_dot", self._p(K), self._p(x), self._p(y), self._p(dot_out))
+
+    def copy_indexed(self, n, src_idx, dst_idx, src, dst):
+        self._call("pf_copy_indexed", C.c_int64(n), self._p(src_idx), self._p(dst_idx), self._p(src), self._p(dst))
+
+    def dot(self, a, b, w, out):
+        self._call("pf_dot", C.c_int64(a.numel()), self._p(a), self._p(b), self._p(w), self._p(out))
+
+    def cgcg_update_xrz(self, state, p, s, dinv, w, x, r, z, gamma_out, rr_out):
+        self._call("pf_cgcg_update_xrz", C.c_int64(self.n), self._p(state), self._p(p), self._p(s), self._p(dinv),
+                   self._p(w), self._p(x), self._p(r), self._p(z), self._p(gamma_out), self._p(rr_out))
+
+    def cgcg_scalars(self, state, red, first):
+        self._call("pf_cgcg_scalars", self._p(state), self._p(red), int(first))
+
+    def cgcg_update_ps(self, state, z, w, p, s):
+        self._call("pf_cgcg_update_ps", C.c_int64(self.n), self._p(state), self._p(z), self._p(w), self._p(p),
+                   self._p(s))
+
+
+# ------------------------------------------------------------------------------------------
+# distributed pieces
+# ------------------------------------------------------------------------------------------
+def _all_reduce(t, group):
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+class Interface:
+    """Packed interface vector of the job + this rank's (local dof, slot) lists on the device."""
+
+    def __init__(self, ops, part, group=None):
+        torch = ops.torch
+        self.ops, self.group = ops, group
+        self.G = part.n_iface_dofs
+        self.n = part.iface_local_dofs.size
+        self.local = ops.from_numpy(part.iface_local_dofs, torch.int32)
+        self.slots = ops.from_numpy(part.iface_slots, torch.int32)
+        self.buf = ops.zeros(self.G + 3)  # [interface partial sums | gamma, delta, rr]
+
+    def sum(self, v):
+        """v[interface dofs] <- sum over ranks (in place); other entries untouched."""
+        self.buf.zero_()
+        self.ops.copy_indexed(self.n, self.local, self.slots, v, self.buf)
+        _all_reduce(self.buf, self.group)
+        self.ops.copy_indexed(self.n, self.slots, self.local, self.buf, v)
+        return v
+
+
+def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, check_every=50):
+    """Chronopoulos-Gear single-reduction Jacobi-PCG over ranks, x0 = 0.
+    Stops when ||r||_2 <= max(rtol ||b||_2, atol)  (the reference's convention, pyfem.py:2418).
+    Returns (x_local, iters, relres); raises RuntimeError("cg failed with code <iters>") at maxiter
+    (pyfem.py:2421-2422)."""
+    n = ops.n
+    G = iface.G
+    buf = iface.buf
+    red = buf[G:]  # gamma, delta, rr
+    x, r, z, w, p, s = ops.zeros(n), b.clone(), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
+    state = ops.zeros(3)
+    bb = ops.zeros(1)
+    ops.dot(b, b, own_w, bb)
+    _all_reduce(bb, iface.group)
+    bnorm = float(bb.item()) ** 0.5
+    tol = max(rtol * bnorm, atol)
+    if maxiter is None:
+        maxiter = 10 * n
+    it, rnorm = 0, float("inf")
+    while it < maxiter:
+        buf.zero_()
+        ops.cgcg_update_xrz(state, p, s, dinv, own_w, x, r, z, red[0:1], red[2:3])
+        ops.spmv_dot(K, z, w, red[1:2])
+        ops.copy_indexed(iface.n, iface.local, iface.slots, w, buf)
+        _all_reduce(buf, iface.group)
+        ops.copy_indexed(iface.n, iface.slots, iface.local, buf, w)
+        # r.r in `red` belongs to the residual after `it` updates
+        if it % check_every == 0 or it + 1 == maxiter:
+            rnorm = float(red[2].item()) ** 0.5
+            if not rnorm == rnorm or rnorm <= tol:
+                break
+        ops.cgcg_scalars(state, red, it == 0)
+        ops.cgcg_update_ps(state, z, w, p, s)
+        it += 1
+    relres = rnorm / bnorm if bnorm > 0 else rnorm
+    if not rnorm <= tol:
+        raise RuntimeError(f"cg failed with code {it}")
+    return x, it, relres
+
+
+# ------------------------------------------------------------------------------------------
+# the model-level wrapper
+# ------------------------------------------------------------------------------------------
+class PartitionedElasticity:
+    """LinearElasticity (pyfem.py:1667-2068) over an element-block partition.
+
+    Same constructor arguments as pyfem.LinearElasticity (global mesh, global dof ids), plus the
+    process group.  compute_jacobian()/apply BCs/solve act on the rank-local block; `solve`
+    returns the local solution and `gather_global` assembles the global vector on every rank."""
+
+    def __init__(self, X, conn, dof_fixed, dof_fixed_vals, nodal_force, quadrature, basis, E=10.0, nu=0.3, p=0.0,
+                 group=None, rank=None, world=None, device=None):
+        import torch.distributed as dist
+
+        from . import pyfem
+
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.group, self.rank, self.world = group, rank, world
+        X = np.asarray(X, dtype=float)
+        self.nnodes_global = X.shape[0]
+        self.part = ElementBlockPartition(conn, X.shape[0], world, rank, 2)
+        pt = self.part
+        fixed_local, present = pt.local_dofs_of(dof_fixed)
+        vals_local = None if dof_fixed_vals is None else np.asarray(dof_fixed_vals, dtype=float)[present]
+        force_local = {}
+        for node, f in nodal_force.items():
+            pos = np.searchsorted(pt.nodes, node)
+            if pos < pt.nodes.size and pt.nodes[pos] == node:
+                force_local[int(pos)] = f
+        self.model = pyfem.LinearElasticity(X[pt.nodes], pt.conn_local, fixed_local, vals_local, force_local,
+                                            quadrature, basis, E=E, nu=nu, p=p, device=device)
+        if not force_local:  # compute_rhs of the reference indexes with the (possibly empty) key list
+            self.model.compute_rhs = lambda: self.model.rhs
+        self.ops = HipLocalOps(self.model.hctx)
+        self.iface = Interface(self.ops, pt, group)
+        torch = self.ops.torch
+        self.own_w = self.ops.from_numpy(pt.own_weight, torch.float64)
+        self.inv_mult = self.ops.from_numpy(1.0 / pt.multiplicity, torch.float64)
+        self.last_iters = None
+
+    @property
+    def nelems_local(self):
+        return self.part.conn_local.shape[0]
+
+    def compute_jacobian(self, rho=1.0, out=None):
+        """Local block of K; rho is the GLOBAL nodal density (or a scalar)."""
+        if hasattr(rho, "__len__"):
+            rho = np.asarray(rho)[self.part.nodes]
+        return self.model.compute_jacobian(rho, out=out)
+
+    def apply_dirichlet_bcs(self, K, rhs_local_consistent):
+        """BCs on the local block.  rhs is consistent on entry and on return."""
+        m = self.model
+        b = rhs_local_consistent * self.inv_mult  # split so that the interface sum restores it
+        m.hctx.apply_dirichlet(K.vals, b, m._fixed_mask, m._fixed_vals, True, diag_scale=self.own_w)
+        K.invalidate()
+        self.iface.sum(b)
+        fixed = self.ops.from_numpy(m.dof_fixed, self.ops.torch.int64)
+        if fixed.numel():
+            b[fixed] = 0.0 if m._fixed_vals is None else m._fixed_vals[fixed]
+        return K, b
+
+    def solve(self, rho=1.0, rtol=1e-10, maxiter=None, check_every=50):
+        """Assembler.solve(method="cg") over the partition (pyfem.py:2299-2317)."""
+        K = self.compute_jacobian(rho)
+        rhs = self.ops.from_numpy(self.model.compute_rhs(), self.ops.torch.float64)
+        K, b = self.apply_dirichlet_bcs(K, rhs)
+        dinv = 1.0 / self.iface.sum(self.ops.diag(K.vals))
+        x, it, rr = dist_cg(self.ops, K.vals, b, dinv, self.own_w, self.iface, rtol=rtol, maxiter=maxiter,
+                            check_every=check_every)
+        self.last_iters, self.last_relres = it, rr
+        return x
+
+    def gather_global(self, x_local):
+        """Global vector on every rank (tests / small problems)."""
+        torch = self.ops.torch
+        out = torch.zeros(2 * self.nnodes_global, dtype=torch.float64, device=x_local.device)
+        gd = self.ops.from_numpy(self.part.global_dofs(), torch.int64)
+        out[gd] = x_local * self.own_w
+        _all_reduce(out, self.group)
+        return out

@@ -1,0 +1,131 @@
+"""N>1 host logic under gloo, world_size 2 and 3, on CPU: element-block partition, interface
+packing, consistent BCs and the single-reduction CG of pyfem_gpu_testflight_amd/dist.py, with the
+numpy test double standing in for the rank-local HIP kernels.  Checked against the oracle's
+direct solve of the unpartitioned problem."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem(kind):
+    from oracle import pyfem_oracle as orc
+
+    if kind == "quad":
+        nx, ny = 19, 14
+        conn, X = orc.structured_mesh(nx, ny, "quad")
+        dof_fixed, force = orc.elasticity_problem(nx, ny)
+        return "quad", conn, X, dof_fixed, None, force
+    # shuffled triangles: element blocks are scattered, interface nodes shared by up to 3 ranks
+    nx, ny = 13, 11
+    conn, X = orc.structured_mesh(nx, ny, "tri")
+    dof_fixed, force = orc.elasticity_problem(nx, ny)
+    rng = np.random.RandomState(11)
+    conn = conn[rng.permutation(conn.shape[0])]
+    vals = 0.01 * (rng.rand(dof_fixed.size) - 0.5)  # non-zero prescribed displacements
+    return "tri", conn, X, dof_fixed, vals, force
+
+
+def _worker(rank, world, port, kind):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyfem_oracle as orc
+        from pyfem_gpu_testflight_amd.dist import ElementBlockPartition, Interface, dist_cg
+        from tests._cpu_ops import NumpyLocalOps
+
+        etype, conn, X, dof_fixed, vals, force = _problem(kind)
+        part = ElementBlockPartition(conn, X.shape[0], world, rank, 2)
+        # every element is owned exactly once; local numbering is monotone
+        assert part.conn_local.shape[0] == part.elem_range[1] - part.elem_range[0]
+        assert np.all(np.diff(part.nodes) > 0)
+        assert np.array_equal(part.nodes[part.conn_local], conn[part.elem_range[0]:part.elem_range[1]])
+        Xl = X[part.nodes]
+        Kl = orc.assemble_csr(orc.elasticity_Ke(Xl, part.conn_local.astype(np.int64), etype),
+                              orc.create_conn_dof(part.conn_local.astype(np.int64), 2))
+        n = 2 * part.nnodes_local
+        assert Kl.shape == (n, n)
+        ops = NumpyLocalOps(n)
+        iface = Interface(ops, part)
+        own_w = torch.from_numpy(part.own_weight)
+        # ownership: every global dof owned exactly once
+        tot = torch.zeros(2 * X.shape[0], dtype=torch.float64)
+        tot[torch.from_numpy(part.global_dofs())] += own_w
+        dist.all_reduce(tot)
+        assert bool((tot == 1).all())
+        # interface sum of the local partial products == global product
+        rng = np.random.RandomState(0)
+        vg = rng.rand(2 * X.shape[0])
+        Kg = orc.assemble_csr(orc.elasticity_Ke(X, conn, etype), orc.create_conn_dof(conn, 2))
+        yl = torch.from_numpy(Kl.dot(vg[part.global_dofs()]))
+        iface.sum(yl)
+        assert np.abs(yl.numpy() - Kg.dot(vg)[part.global_dofs()]).max() < 1e-12 * np.abs(Kg.data).max()
+        # consistent rhs + BCs on the local block (what PartitionedElasticity.apply_dirichlet_bcs does)
+        rhs_g = orc.elasticity_rhs(2 * X.shape[0], force)
+        b = torch.from_numpy(rhs_g[part.global_dofs()] / part.multiplicity)
+        fixed_local, present = part.local_dofs_of(dof_fixed)
+        vals_local = None if vals is None else vals[present]
+        mask = np.zeros(n, dtype=bool)
+        mask[fixed_local] = True
+        fv = np.zeros(n)
+        if vals_local is not None:
+            fv[fixed_local] = vals_local
+        Kl = Kl.tolil()
+        bl = b.numpy()
+        Kd = Kl.toarray()
+        bl[~mask] -= Kd[np.ix_(~mask, mask)] @ fv[mask]
+        Kd[mask, :] = 0.0
+        Kd[:, mask] = 0.0
+        Kd[mask, mask] = part.own_weight[mask]  # unit diagonal only on the owner
+        from scipy import sparse
+
+        Kl = sparse.csr_matrix(Kd)
+        iface.sum(b)
+        b[torch.from_numpy(fixed_local)] = torch.from_numpy(fv[fixed_local])
+        dinv = 1.0 / iface.sum(ops.diag(Kl))
+        x, it, relres = dist_cg(ops, Kl, b, dinv, own_w, iface, rtol=1e-12, check_every=7)
+        assert it > 5 and relres <= 1e-12
+        ug = torch.zeros(2 * X.shape[0], dtype=torch.float64)
+        ug[torch.from_numpy(part.global_dofs())] = x * own_w
+        dist.all_reduce(ug)
+        Kbc, rhs_bc = orc.apply_dirichlet_bcs(Kg, rhs_g, dof_fixed, vals, True)
+        from scipy.sparse.linalg import spsolve
+
+        u_ref = spsolve(Kbc.tocsc(), rhs_bc)
+        err = np.abs(ug.numpy() - u_ref).max() / np.abs(u_ref).max()
+        assert err < 1e-8, err
+        # consistency: interface copies agree across ranks
+        assert np.abs(x.numpy() - ug.numpy()[part.global_dofs()]).max() < 1e-9 * np.abs(u_ref).max()
+        # non-convergence raises like the reference (pyfem.py:2421-2422)
+        with pytest.raises(RuntimeError, match="cg failed with code 3"):
+            dist_cg(ops, Kl, b, dinv, own_w, iface, rtol=1e-14, maxiter=3)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "quad"), (2, "tri"), (3, "tri")])
+def test_partitioned_cg_gloo(world, kind):
+    mp.spawn(_worker, args=(world, _free_port(), kind), nprocs=world, join=True)
+
+
+def test_partition_single_rank_is_identity():
+    from oracle import pyfem_oracle as orc
+    from pyfem_gpu_testflight_amd.dist import ElementBlockPartition
+
+    conn, X = orc.structured_mesh(7, 5, "quad")
+    part = ElementBlockPartition(conn, X.shape[0], 1, 0, 2)
+    assert part.n_iface_dofs == 0 and np.array_equal(part.conn_local, conn)
+    assert np.array_equal(part.nodes, np.arange(X.shape[0])) and part.own_weight.min() == 1.0

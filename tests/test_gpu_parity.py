@@ -241,7 +241,9 @@ def test_error_behaviour(pf):
     bad = conn.copy()
     bad[bad == bad.max()] = bad.max() + 3  # conn.max() != nnodes-1  -> reference asserts (pyfem.py:680-681)
     with pytest.raises(AssertionError):
-        pf.LinearElasticity(np.vstack([X, X[:3]]), bad, dof_fixed, None, force, q, b)
+        pf.LinearElasticity(X, bad, dof_fixed, None, force, q, b)
+    with pytest.raises(AssertionError):
+        pf.LinearElasticity(X, conn + 1, dof_fixed, None, force, q, b)  # conn.min() != 0
     model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
     with pytest.raises(AssertionError):
         pf.Assembler(model).solve(method="lu")  # pyfem.py:2306
