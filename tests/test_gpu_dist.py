@@ -1,0 +1,85 @@
+"""Partitioned path on the real HIP kernels.  A 1-GPU box cannot host two RCCL ranks, so the
+2-rank case runs two processes that share the one GPU and use gloo for the collective (gloo
+accepts device tensors): the kernels, the partition and the iteration are the product's, only
+the transport differs from the 8-GPU run."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(etype):
+    from pyfem_gpu_testflight_amd import pyfem
+
+    c = pyfem.ProblemCreator(41, 29, element_type=etype)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    if etype == "quad":
+        q = pyfem.QuadratureBilinear2D()
+        return conn, X, dof_fixed, force, q, pyfem.BasisBilinear2D(q)
+    q = pyfem.QuadratureTriangle2D()
+    return conn, X, dof_fixed, force, q, pyfem.BasisTriangle2D(q)
+
+
+def _reference_u(etype, conn, X, dof_fixed, force, rho, p):
+    from oracle import pyfem_oracle as orc
+
+    u, *_ = orc.solve_elasticity(X, conn, etype, np.asarray(dof_fixed), force, rho=rho, p=p)
+    return u
+
+
+def test_partitioned_single_rank():
+    from pyfem_gpu_testflight_amd.dist import PartitionedElasticity
+
+    conn, X, dof_fixed, force, q, b = _setup("quad")
+    rho = 0.3 + 0.7 * np.random.RandomState(1).rand(X.shape[0])
+    pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0, rank=0, world=1)
+    x = pm.solve(rho=rho, rtol=1e-12)
+    u = pm.gather_global(x).cpu().numpy()
+    u_ref = _reference_u("quad", conn, X, dof_fixed, force, rho, 3.0)
+    assert np.abs(u - u_ref).max() < 1e-8 * np.abs(u_ref).max()
+    assert pm.last_iters > 10
+
+
+def _worker(rank, world, port, etype):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyfem_gpu_testflight_amd.dist import PartitionedElasticity
+
+        conn, X, dof_fixed, force, q, b = _setup(etype)
+        rng = np.random.RandomState(5)
+        if etype == "tri":
+            conn = conn[rng.permutation(conn.shape[0])]
+        rho = 0.3 + 0.7 * rng.rand(X.shape[0])
+        pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+        assert pm.world == world and pm.iface.G > 0
+        x = pm.solve(rho=rho, rtol=1e-12, check_every=25)
+        u = pm.gather_global(x).cpu().numpy()
+        u_ref = _reference_u(etype, conn, X, dof_fixed, force, rho, 3.0)
+        err = np.abs(u - u_ref).max() / np.abs(u_ref).max()
+        assert err < 1e-8, err
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("etype", ["quad", "tri"])
+def test_partitioned_two_ranks_one_gpu(etype):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(2, _free_port(), etype), nprocs=2, join=True)
