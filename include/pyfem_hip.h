@@ -121,40 +121,31 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
 
-/* CG building blocks for the one-process-per-GPU driver (pyfem_gpu_testflight_amd/dist.py);
- * all asynchronous, scalars stay on the device.
- *   pf_dot:  out[0] = sum_i w_i a_i b_i   (w NULL => 1)  -- out is zeroed by the call
- *   pf_cg_update_xr:  alpha = rz[0]/pAp[0]; x += alpha p; r -= alpha Ap; z = dinv*r (dinv NULL: z=r);
- *                     rz_new[0] = sum w r z ; rr[0] = sum w r r
- *   pf_cg_update_p:   beta = rz_new[0]/rz_old[0]; p = z + beta p
- *   pf_gather / pf_scatter_add: interface pack / unpack-accumulate by index list           */
+/* Building blocks for the one-process-per-GPU driver (pyfem_gpu_testflight_amd/dist.py): the
+ * single-reduction (Chronopoulos-Gear) Jacobi-PCG.  ONE all-reduce per iteration carries the
+ * interface partial sums of w = A z together with gamma = r.z, delta = z.w and r.r.  All calls are
+ * asynchronous on the ctx stream; scalars stay on the device.  Vector length is the ctx's nrows.
+ * Reductions never use same-address atomics: kernels leave per-block partial sums in the ctx and
+ * pf_cgcg_reduce / pf_dot sum them in a fixed order (bitwise reproducible).
+ *   pf_dot:             out[0] = sum_i w_i a_i b_i   (w NULL => 1), any n
+ *   pf_copy_indexed:    dst[dst_idx[i]] = src[src_idx[i]], i < n (either list NULL = identity):
+ *                       packs interface rows into the all-reduce buffer / unpacks the sums
+ *   pf_spmv_dot:        y = A x ; partials of x . y
+ *   pf_cgcg_update_xrz: alpha = state[0]; x += alpha p; r -= alpha s; z = dinv*r (dinv NULL: z = r);
+ *                       partials of sum w r z and sum w r r
+ *   pf_cgcg_reduce:     red_out[0..2] = [gamma, delta, rr] from the partials of the two calls above
+ *   pf_cgcg_scalars:    state = [alpha, beta, gamma]; beta = first ? 0 : gamma_new/gamma;
+ *                       alpha = gamma_new/(delta - beta*gamma_new/alpha); red = reduced [gamma_new, delta, rr]
+ *   pf_cgcg_update_ps:  beta = state[1]; p = z + beta p ; s = w + beta s                        */
 int pf_dot(pf_ctx* ctx, int64_t n, const double* a, const double* b, const double* w, double* out);
-int pf_cg_update_xr(pf_ctx* ctx, int64_t n, const double* rz, const double* pAp, const double* p,
-                    const double* Ap, const double* dinv, const double* w, double* x, double* r,
-                    double* z, double* rz_new, double* rr);
-int pf_cg_update_p(pf_ctx* ctx, int64_t n, const double* rz_new, const double* rz_old,
-                   const double* z, double* p);
-int pf_gather(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
-int pf_scatter_add(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
-int pf_scatter_set(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst);
-/* dst[dst_idx[i]] = src[src_idx[i]], i < n  (either index list may be NULL = identity): packs the
- * interface rows of a vector into the all-reduce buffer and unpacks the reduced values. */
 int pf_copy_indexed(pf_ctx* ctx, int64_t n, const int32_t* src_idx, const int32_t* dst_idx,
                     const double* src, double* dst);
-
-/* Single-reduction (Chronopoulos-Gear) PCG steps for the partitioned solve: ONE all-reduce per
- * iteration carries the interface partial sums of w = A z together with gamma = r.z, delta = z.w
- * and r.r.  `state` is a device array [alpha, beta, gamma]; `red` the reduced [gamma, delta, rr].
- *   pf_spmv_dot:        y = A x ; dot_out[0] += x . y          (dot_out NOT cleared by the call)
- *   pf_cgcg_update_xrz: x += alpha p; r -= alpha s; z = dinv*r; gamma += sum w r z; rr += sum w r r
- *   pf_cgcg_scalars:    beta = first ? 0 : gamma_new/gamma; alpha = gamma_new/(delta - beta*gamma_new/alpha)
- *   pf_cgcg_update_ps:  p = z + beta p ; s = w + beta s                                     */
-int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out);
-int pf_cgcg_update_xrz(pf_ctx* ctx, int64_t n, const double* state, const double* p, const double* s,
-                       const double* dinv, const double* w, double* x, double* r, double* z,
-                       double* gamma_out, double* rr_out);
+int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y);
+int pf_cgcg_update_xrz(pf_ctx* ctx, const double* state, const double* p, const double* s,
+                       const double* dinv, const double* w, double* x, double* r, double* z);
+int pf_cgcg_reduce(pf_ctx* ctx, double* red_out);
 int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, int first);
-int pf_cgcg_update_ps(pf_ctx* ctx, int64_t n, const double* state, const double* z, const double* w,
+int pf_cgcg_update_ps(pf_ctx* ctx, const double* state, const double* z, const double* w,
                       double* p, double* s);
 
 /* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one

@@ -42,16 +42,12 @@ SIGNATURES = {
     "pf_cg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.c_int, C.POINTER(_i32),
                         C.POINTER(_f64)]),
     "pf_dot": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "pf_cg_update_xr": (C.c_int, [_vp, _i64] + [_vp] * 11),
-    "pf_cg_update_p": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "pf_gather": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    "pf_scatter_add": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
-    "pf_scatter_set": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "pf_copy_indexed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
-    "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
-    "pf_cgcg_update_xrz": (C.c_int, [_vp, _i64] + [_vp] * 10),
+    "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pf_cgcg_update_xrz": (C.c_int, [_vp] * 9),
+    "pf_cgcg_reduce": (C.c_int, [_vp, _vp]),
     "pf_cgcg_scalars": (C.c_int, [_vp, _vp, _vp, C.c_int]),
-    "pf_cgcg_update_ps": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "pf_cgcg_update_ps": (C.c_int, [_vp] * 6),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
 }
 

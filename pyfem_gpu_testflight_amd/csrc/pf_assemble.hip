@@ -227,32 +227,44 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 }
 
 // ------------------------------------------------------------------------------------------
-// GATHER assembly: one wave (= one workgroup) per 64 consecutive nodes
+// GATHER assembly: one workgroup of NW waves per 64 consecutive nodes.
+//   lane  = node (owns the node's d rows of K)
+//   wave w handles incident elements w, w+NW, ... of every node of the tile, so the dependent
+//   n2e -> conn -> X load chain is paid once per wave instead of once per incident element and
+//   NW times more waves are in flight per LDS byte (the r01 profile showed 61 % of wave cycles
+//   waiting on that chain at 8 waves/CU).
+//   The LDS tile is shared by the NW waves; the adds into it are ordered by incident-element
+//   index with workgroup barriers, so the summation order (ascending element id) and hence the
+//   result is bitwise reproducible.
 // dynamic LDS: double acc[max_row_blocks*V*65] ; int32 prefix[64] ; uint8 owner[64*max_row_blocks]
 // ------------------------------------------------------------------------------------------
-template <int P, class Phys, bool RHO>
-__global__ __launch_bounds__(64) void k_assemble_gather(int64_t nnodes, int32_t maxrow, const double* __restrict__ X,
-                                                        const int32_t* __restrict__ conn,
-                                                        const int32_t* __restrict__ nptr,
-                                                        const int32_t* __restrict__ n2e_ptr,
-                                                        const int32_t* __restrict__ n2e,
-                                                        const uint8_t* __restrict__ n2e_pos,
-                                                        typename Phys::Params pr, double* __restrict__ out0,
-                                                        double* __restrict__ out1) {
+template <int P, class Phys, bool RHO, int NW>
+__global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes, int32_t maxrow, int32_t maxval,
+                                                             const double* __restrict__ X,
+                                                             const int32_t* __restrict__ conn,
+                                                             const int32_t* __restrict__ nptr,
+                                                             const int32_t* __restrict__ n2e_ptr,
+                                                             const int32_t* __restrict__ n2e,
+                                                             const uint8_t* __restrict__ n2e_pos,
+                                                             typename Phys::Params pr, double* __restrict__ out0,
+                                                             double* __restrict__ out1) {
   constexpr int V = Phys::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* acc = reinterpret_cast<double*>(smem);
   int32_t* prefix = reinterpret_cast<int32_t*>(acc + (size_t)maxrow * V * LDS_STRIDE);
   uint8_t* owner = reinterpret_cast<uint8_t*>(prefix + 64);
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * 64;
   const int64_t n = n0 + lane;
   const bool valid = n < nnodes;
   const int32_t rowbase = valid ? nptr[n] : 0;
   const int32_t cnt = valid ? nptr[n + 1] - rowbase : 0;
+  const int32_t jb = valid ? n2e_ptr[n] : 0;
+  const int32_t nj = valid ? n2e_ptr[n + 1] - jb : 0;
 
-  // exclusive wave scan of cnt
+  // exclusive wave scan of cnt (every wave computes it; wave 0 publishes)
   int32_t incl = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -262,38 +274,49 @@ __global__ __launch_bounds__(64) void k_assemble_gather(int64_t nnodes, int32_t 
   const int32_t pre = incl - cnt;
   const int32_t total = __shfl(incl, 63);
   const int32_t wavebase = __shfl(rowbase, 0);
-  prefix[lane] = pre;
-  for (int c = 0; c < cnt; ++c) owner[pre + c] = (uint8_t)lane;
-  for (int s = 0; s < cnt * V; ++s) acc[s * LDS_STRIDE + lane] = 0.0;
+  if (wave == 0) {
+    prefix[lane] = pre;
+    for (int c = 0; c < cnt; ++c) owner[pre + c] = (uint8_t)lane;
+  }
+  for (int s = wave; s < cnt * V; s += NW) acc[s * LDS_STRIDE + lane] = 0.0;
+  __syncthreads();
 
-  if (valid) {
-    const int32_t jb = n2e_ptr[n], je = n2e_ptr[n + 1];
-    for (int32_t j = jb; j < je; ++j) {
-      const int32_t ea = n2e[j];
+  for (int32_t r0 = 0; r0 < maxval; r0 += NW) {
+    const int32_t j = r0 + wave;
+    const bool has = j < nj;
+    double v[P][V];
+    uint8_t pos[P];
+    if (has) {
+      const int32_t jj = jb + j;
+      const int32_t ea = n2e[jj];
       const int32_t e = ea / P;
       const int a = ea - e * P;
       int32_t nd[P];
       load_conn<P>(conn, e, nd);
-      uint8_t pos[P];
       if constexpr (P == 4) {
-        const uint32_t pk = *reinterpret_cast<const uint32_t*>(n2e_pos + 4 * (int64_t)j);
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(n2e_pos + 4 * (int64_t)jj);
         pos[0] = pk & 255; pos[1] = (pk >> 8) & 255; pos[2] = (pk >> 16) & 255; pos[3] = pk >> 24;
       } else {
 #pragma unroll
-        for (int b = 0; b < P; ++b) pos[b] = n2e_pos[(int64_t)P * j + b];
+        for (int b = 0; b < P; ++b) pos[b] = n2e_pos[(int64_t)P * jj + b];
       }
-      double v[P][V];
       element_rows<P, Phys, RHO>(pr, X, nd, a, v);
+    }
+    // ordered accumulate: incident element r0+0, r0+1, ... (fixed order => reproducible sums)
 #pragma unroll
-      for (int b = 0; b < P; ++b)
+    for (int w = 0; w < NW; ++w) {
+      if (w == wave && has) {
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+      }
+      __syncthreads();
     }
   }
-  __syncthreads();
 
-  // coalesced write-out: lane t takes coupling (block) t of the wave's contiguous range
-  for (int32_t tb = lane; tb < total; tb += 64) {
+  // coalesced write-out: thread t takes coupling (block) t of the tile's contiguous range
+  for (int32_t tb = threadIdx.x; tb < total; tb += 64 * NW) {
     const int o = owner[tb];
     const int c = tb - prefix[o];
     const int64_t g = (int64_t)wavebase + tb;
@@ -391,17 +414,20 @@ static size_t gather_lds_bytes(int maxrow, int V) {
   return (b + 15) & ~(size_t)15;
 }
 
+static constexpr int GATHER_NW = 4;  // waves per 64-node tile
+
 template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   const size_t lds = gather_lds_bytes(ctx->max_row_blocks, Phys::V);
   if (lds > 160 * 1024)
     return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");
-  auto kern = k_assemble_gather<P, Phys, RHO>;
+  auto kern = k_assemble_gather<P, Phys, RHO, GATHER_NW>;
   if (lds > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)cdiv(ctx->nnodes, 64);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks, ctx->X, ctx->conn,
-                     ctx->nptr, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, pr, out0, out1);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GATHER_NW), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
+                     ctx->max_valence, ctx->X, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, pr, out0,
+                     out1);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -7,6 +7,10 @@
 
 #include "pyfem_hip.h"
 
+// reduction scratch: PF_NPART_ARRAYS arrays of PF_NPART per-block partial sums (pf_solve.hip)
+#define PF_NPART 4096
+#define PF_NPART_ARRAYS 8
+
 struct pf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -33,7 +37,7 @@ struct pf_ctx {
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 
   // ---- scratch owned by the ctx ----
-  double* scal = nullptr;      // 8 device scalars for pf_cg
+  double* scal = nullptr;      // PF_NPART_ARRAYS x PF_NPART per-block partial sums
   double* cgw = nullptr;       // CG work vectors (4*nrows), grown on demand
   int64_t cgw_cap = 0;
   void* scan_tmp = nullptr;
@@ -78,5 +82,4 @@ int pf_ensure_e2pos(pf_ctx* ctx);
 int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, const double* rho, int mode,
                                   double* Kvals);
 int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
-int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out,
-                   const double* dot_w);
+int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part);

@@ -9,14 +9,28 @@
 // SpMV design: HBM-bound streaming of the value array (8 B/nnz) plus one 4-byte node index per
 // d x d block (so 9 B/nnz at d=2 instead of CSR's 12).  One wave owns 64 consecutive nodes whose
 // blocks are ONE contiguous range: lanes stream that range block-per-lane (32 B values + 4 B index,
-// fully coalesced), gather x[node] as one 16-byte load, and drop the d-vector product into an LDS
-// strip; then lane-per-node sums its row's strip entries (conflict-free: consecutive rows start
-// 9 x 16 B apart) and writes y coalesced.  Waves are persistent (grid-stride over 64-node tiles)
-// so p.Ap for CG costs one atomic per wave.
+// fully coalesced, three blocks per lane in flight), gather x[node] as one 16-byte load, and drop
+// the d-vector product into an LDS strip; then lane-per-node sums its row's strip entries
+// (conflict-free: consecutive rows start 9 x 16 B apart) and writes y coalesced.  Waves are
+// persistent (grid-stride over 64-node tiles).
+//
+// Reductions: NO same-address atomics (the r01 profile: 16 k atomics on one word cost ~190 us per
+// CG update).  Every producing block stores one partial; the consuming kernel's blocks each re-sum
+// the (<= 4096, L2-resident) partials in a fixed order.  That removes the serialisation, needs no
+// extra launch and no fence (the kernel boundary publishes the partials), and makes CG bitwise
+// reproducible run to run.
 #include "pf_common.h"
 
-static constexpr int SPMV_TILE = 64;       // nodes per wave tile
-static constexpr int SPMV_CHUNK = 1024;    // blocks staged in LDS per pass (d=2: 16 KB)
+static constexpr int SPMV_TILE = 64;     // nodes per wave tile
+static constexpr int SPMV_CHUNK = 640;   // blocks staged in LDS per pass (d=2: 10 KB -> 16 waves/CU)
+static constexpr int SPMV_MAXGRID = 4096;
+static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
+static constexpr int NPART = PF_NPART;   // capacity of one partial array
+
+// partial arrays inside ctx->scal (each NPART doubles)
+enum { PA_PAP = 0, PA_RZ0 = 1, PA_RZ1 = 2, PA_RR = 3, PA_BB = 4, PA_GAMMA = 5, PA_DELTA = 6, PA_RR2 = 7 };
+static_assert(PA_RR2 < PF_NPART_ARRAYS, "partial arrays exceed the ctx scratch");
+static_assert(PA_BB == PA_RR + 1, "pf_cg copies RR and BB with one transfer");
 
 template <int D>
 struct Vec;
@@ -29,27 +43,52 @@ struct Vec<2> {
   using T = double2;
 };
 
+// butterfly sum: every lane ends with the same bits (a+b == b+a), order fixed => reproducible
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
-// y = A x ; optionally dot_out[0] += sum_i w_i x_i y_i   (w == nullptr -> 1)
-// zero_a / zero_b: device scalars this launch clears for the NEXT kernel in the CG pipeline
+// all threads of a 256-thread block: sum of part[0..n) in a fixed order, same value in every thread
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ part, int n, double* sh) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double t = 0.0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) t += sh[w];
+  __syncthreads();
+  return t;
+}
+
+// block-level sum of per-thread values -> out[blockIdx.x]
+__device__ __forceinline__ void block_store_partial(double s, double* __restrict__ out, double* sh) {
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nw; ++w) t += sh[w];
+    out[blockIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// y = A x ; optionally dot_part[blockIdx.x] = sum over this wave's rows of x_i y_i
+// ------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
-                                             double* __restrict__ dot_out, const double* __restrict__ dot_w,
-                                             double* __restrict__ zero_a, double* __restrict__ zero_b) {
+                                             double* __restrict__ dot_part) {
   using V = typename Vec<D>::T;
   __shared__ V prod[SPMV_CHUNK];
   const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && lane == 0) {
-    if (zero_a) *zero_a = 0.0;
-    if (zero_b) *zero_b = 0.0;
-  }
   double dacc = 0.0;
   const int64_t ntiles = (nnodes + SPMV_TILE - 1) / SPMV_TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -64,23 +103,45 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
     if constexpr (D == 1) acc = 0.0; else acc = make_double2(0.0, 0.0);
     for (int32_t c0 = base; c0 < end; c0 += SPMV_CHUNK) {
       const int32_t c1 = min(end, c0 + SPMV_CHUNK);
-      // phase A: stream blocks [c0, c1)
-      for (int32_t g = c0 + lane; g < c1; g += 64) {
-        const int32_t m = nidx[g];
+      // phase A: stream blocks [c0, c1), three per lane in flight
+      constexpr int U = 3;
+      for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
+        int32_t g[U], m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          g[u] = min(g0 + 64 * u, c1 - 1);  // clamped: loads stay in range, result discarded
+          m[u] = nidx[g[u]];
+        }
         if constexpr (D == 1) {
-          prod[g - c0] = vals[g] * x[m];
+          double kv[U], xv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) kv[u] = vals[g[u]];
+#pragma unroll
+          for (int u = 0; u < U; ++u) xv[u] = x[m[u]];
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (g0 + 64 * u < c1) prod[g[u] - c0] = kv[u] * xv[u];
         } else {
-          const double2 k0 = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g);
-          const double2 k1 = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g + 2);
-          const double2 xv = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m);
-          prod[g - c0] = make_double2(k0.x * xv.x + k0.y * xv.y, k1.x * xv.x + k1.y * xv.y);
+          double2 k0[U], k1[U], xv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            k0[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u]);
+            k1[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u] + 2);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m[u]);
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (g0 + 64 * u < c1)
+              prod[g[u] - c0] = make_double2(k0[u].x * xv[u].x + k0[u].y * xv[u].y,
+                                             k1[u].x * xv[u].x + k1[u].y * xv[u].y);
         }
       }
       __syncthreads();
       // phase B: lane-per-node partial row sums over this chunk
       const int32_t lo = max(rb, c0), hi = min(re, c1);
-      for (int32_t g = lo; g < hi; ++g) {
-        const V pv = prod[g - c0];
+      for (int32_t gq = lo; gq < hi; ++gq) {
+        const V pv = prod[gq - c0];
         if constexpr (D == 1) acc += pv; else { acc.x += pv.x; acc.y += pv.y; }
       }
       __syncthreads();
@@ -88,24 +149,19 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
     if (valid) {
       if constexpr (D == 1) {
         y[n] = acc;
-        if (dot_out) dacc += (dot_w ? dot_w[n] : 1.0) * x[n] * acc;
+        if (dot_part) dacc += x[n] * acc;
       } else {
         *reinterpret_cast<double2*>(y + 2 * n) = acc;
-        if (dot_out) {
+        if (dot_part) {
           const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
-          if (dot_w) {
-            const double2 wv = *reinterpret_cast<const double2*>(dot_w + 2 * n);
-            dacc += wv.x * xv.x * acc.x + wv.y * xv.y * acc.y;
-          } else {
-            dacc += xv.x * acc.x + xv.y * acc.y;
-          }
+          dacc += xv.x * acc.x + xv.y * acc.y;
         }
       }
     }
   }
-  if (dot_out) {
+  if (dot_part) {
     dacc = wave_sum(dacc);
-    if (lane == 0) unsafeAtomicAdd(dot_out, dacc);
+    if (lane == 0) dot_part[blockIdx.x] = dacc;
   }
 }
 
@@ -165,62 +221,104 @@ __global__ void k_apply_dirichlet(int64_t nnodes, const int32_t* __restrict__ np
 }
 
 // ------------------------------------------------------------------------------------------
-// vector kernels (grid-stride, double2 vectorised where n is even)
+// vector kernels: persistent 256-thread blocks, 16-byte accesses, per-block partial sums
 // ------------------------------------------------------------------------------------------
+#define PF_VEC_LOOP(i, n2) \
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n2); i += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return reinterpret_cast<const double2*>(p)[i]; }
+__device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+
+// out_part[b] = sum w a b
 __global__ __launch_bounds__(256) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
-                                             const double* __restrict__ w, double* __restrict__ out) {
+                                             const double* __restrict__ w, double* __restrict__ out_part) {
+  __shared__ double sh[4];
   double s = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    s += (w ? w[i] : 1.0) * a[i] * b[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(out, s);
+  PF_VEC_LOOP(i, n) s += (w ? w[i] : 1.0) * a[i] * b[i];
+  block_store_partial(s, out_part, sh);
 }
 
-// alpha = rz/pAp; x += alpha p; r -= alpha Ap; z = dinv r; rz_new += w r z; rr += w r r
-__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* __restrict__ rz,
-                                                      const double* __restrict__ pAp, const double* __restrict__ p,
-                                                      const double* __restrict__ Ap, const double* __restrict__ dinv,
-                                                      const double* __restrict__ w, double* __restrict__ x,
+// out[k] = sum of partial array k, k < narr; one 256-thread block
+__global__ __launch_bounds__(256) void k_finalize(int narr, const double* __restrict__ p0, int n0,
+                                                  const double* __restrict__ p1, int n1,
+                                                  const double* __restrict__ p2, int n2, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double t = block_sum_partials(p0, n0, sh);
+  if (threadIdx.x == 0) out[0] = t;
+  if (narr > 1) {
+    t = block_sum_partials(p1, n1, sh);
+    if (threadIdx.x == 0) out[1] = t;
+  }
+  if (narr > 2) {
+    t = block_sum_partials(p2, n2, sh);
+    if (threadIdx.x == 0) out[2] = t;
+  }
+}
+
+// alpha = rz/pAp; x += alpha p; r -= alpha Ap; z = dinv r; partials of r.z and r.r
+__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* __restrict__ rz_part, int n_rz,
+                                                      const double* __restrict__ pAp_part, int n_pAp,
+                                                      const double* __restrict__ p, const double* __restrict__ Ap,
+                                                      const double* __restrict__ dinv, double* __restrict__ x,
                                                       double* __restrict__ r, double* __restrict__ z,
-                                                      double* __restrict__ rz_new, double* __restrict__ rr) {
-  const double alpha = rz[0] / pAp[0];
+                                                      double* __restrict__ rz_new_part, double* __restrict__ rr_part) {
+  __shared__ double sh[4];
+  const double rz = block_sum_partials(rz_part, n_rz, sh);
+  const double pAp = block_sum_partials(pAp_part, n_pAp, sh);
+  const double alpha = rz / pAp;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t n2 = n >> 1;
+  PF_VEC_LOOP(i, n2) {
+    const double2 pv = ld2(p, i), av = ld2(Ap, i);
+    double2 xv = ld2(x, i), rv = ld2(r, i), zv;
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * av.x; rv.y -= alpha * av.y;
+    if (dinv) { const double2 dv = ld2(dinv, i); zv.x = dv.x * rv.x; zv.y = dv.y * rv.y; } else zv = rv;
+    st2(x, i, xv); st2(r, i, rv); st2(z, i, zv);
+    s1 += rv.x * zv.x + rv.y * zv.y;
+    s2 += rv.x * rv.x + rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * Ap[i];
     r[i] = ri;
     const double zi = dinv ? dinv[i] * ri : ri;
     z[i] = zi;
-    const double wi = w ? w[i] : 1.0;
-    s1 += wi * ri * zi;
-    s2 += wi * ri * ri;
+    s1 += ri * zi;
+    s2 += ri * ri;
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) {
-    unsafeAtomicAdd(rz_new, s1);
-    unsafeAtomicAdd(rr, s2);
-  }
+  block_store_partial(s1, rz_new_part, sh);
+  block_store_partial(s2, rr_part, sh);
 }
 
-// beta = rz_new/rz_old; p = z + beta p ; clears `zero_a` for the next SpMV's p.Ap
-__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* __restrict__ rz_new,
-                                                     const double* __restrict__ rz_old, const double* __restrict__ z,
-                                                     double* __restrict__ p, double* __restrict__ zero_a) {
-  const double beta = rz_new[0] / rz_old[0];
-  if (zero_a && blockIdx.x == 0 && threadIdx.x == 0) *zero_a = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = z[i] + beta * p[i];
+// beta = rz_new/rz_old; p = z + beta p
+__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* __restrict__ rz_new_part,
+                                                     const double* __restrict__ rz_old_part, int n_rz,
+                                                     const double* __restrict__ z, double* __restrict__ p) {
+  __shared__ double sh[4];
+  const double rzn = block_sum_partials(rz_new_part, n_rz, sh);
+  const double rzo = block_sum_partials(rz_old_part, n_rz, sh);
+  const double beta = rzn / rzo;
+  const int64_t n2 = n >> 1;
+  PF_VEC_LOOP(i, n2) {
+    const double2 zv = ld2(z, i);
+    double2 pv = ld2(p, i);
+    pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
+    st2(p, i, pv);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = z[n - 1] + beta * p[n - 1];
 }
 
-// r = b - Ap ; z = dinv r ; p = z ; rz += r z ; bb += b b
+// r = b - Ap ; z = dinv r ; p = z ; partials of r.z, b.b, r.r
 __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double* __restrict__ b, const double* __restrict__ Ap,
                                                  const double* __restrict__ dinv, double* __restrict__ r,
                                                  double* __restrict__ z, double* __restrict__ p,
-                                                 double* __restrict__ rz, double* __restrict__ bb,
-                                                 double* __restrict__ rr) {
+                                                 double* __restrict__ rz_part, double* __restrict__ bb_part,
+                                                 double* __restrict__ rr_part) {
+  __shared__ double sh[4];
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  PF_VEC_LOOP(i, n) {
     const double bi = b[i];
     const double ri = bi - Ap[i];
     r[i] = ri;
@@ -231,32 +329,9 @@ __global__ __launch_bounds__(256) void k_cg_init(int64_t n, const double* __rest
     s2 += bi * bi;
     s3 += ri * ri;
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  s3 = wave_sum(s3);
-  if ((threadIdx.x & 63) == 0) {
-    unsafeAtomicAdd(rz, s1);
-    unsafeAtomicAdd(bb, s2);
-    unsafeAtomicAdd(rr, s3);
-  }
-}
-
-__global__ void k_gather(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src,
-                         double* __restrict__ dst) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[idx[i]];
-}
-
-__global__ void k_scatter_add(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src,
-                              double* __restrict__ dst) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) dst[idx[i]] += src[i];  // idx entries are unique within one call
-}
-
-__global__ void k_scatter_set(int64_t n, const int32_t* __restrict__ idx, const double* __restrict__ src,
-                              double* __restrict__ dst) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) dst[idx[i]] = src[i];
+  block_store_partial(s1, rz_part, sh);
+  block_store_partial(s2, bb_part, sh);
+  block_store_partial(s3, rr_part, sh);
 }
 
 __global__ void k_copy_indexed(int64_t n, const int32_t* __restrict__ si, const int32_t* __restrict__ di,
@@ -270,11 +345,12 @@ __global__ __launch_bounds__(256) void k_cgcg_update_xrz(int64_t n, const double
                                                          const double* __restrict__ p, const double* __restrict__ s,
                                                          const double* __restrict__ dinv, const double* __restrict__ w,
                                                          double* __restrict__ x, double* __restrict__ r,
-                                                         double* __restrict__ z, double* __restrict__ gamma_out,
-                                                         double* __restrict__ rr_out) {
+                                                         double* __restrict__ z, double* __restrict__ gamma_part,
+                                                         double* __restrict__ rr_part) {
+  __shared__ double sh[4];
   const double alpha = state[0];
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  PF_VEC_LOOP(i, n) {
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * s[i];
     r[i] = ri;
@@ -284,12 +360,8 @@ __global__ __launch_bounds__(256) void k_cgcg_update_xrz(int64_t n, const double
     s1 += wi * ri * zi;
     s2 += wi * ri * ri;
   }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) {
-    unsafeAtomicAdd(gamma_out, s1);
-    unsafeAtomicAdd(rr_out, s2);
-  }
+  block_store_partial(s1, gamma_part, sh);
+  block_store_partial(s2, rr_part, sh);
 }
 
 __global__ void k_cgcg_scalars(double* __restrict__ state, const double* __restrict__ red, int first) {
@@ -312,36 +384,36 @@ __global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double*
                                                         const double* __restrict__ z, const double* __restrict__ w,
                                                         double* __restrict__ p, double* __restrict__ s) {
   const double beta = state[1];
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  PF_VEC_LOOP(i, n) {
     p[i] = z[i] + beta * p[i];
     s[i] = w[i] + beta * s[i];
   }
 }
 
 // ------------------------------------------------------------------------------------------
-static inline unsigned vec_grid(int64_t n) { return (unsigned)std::min<int64_t>(cdiv(n, 256), 256 * 8); }
-static inline unsigned spmv_grid(int64_t nnodes) { return (unsigned)std::min<int64_t>(cdiv(nnodes, SPMV_TILE), 256 * 16); }
+static inline unsigned vec_grid(int64_t n) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 512), VEC_BLOCKS));
+}
+static inline unsigned spmv_grid(int64_t nnodes) {
+  return (unsigned)std::min<int64_t>(cdiv(nnodes, SPMV_TILE), SPMV_MAXGRID);
+}
+static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
 
-static int launch_spmv_full(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out,
-                            const double* dot_w, double* za, double* zb) {
+int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part) {
   const unsigned grid = spmv_grid(ctx->nnodes);
   if (ctx->d == 1)
-    k_spmv<1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_out, dot_w, za, zb);
+    k_spmv<1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
   else
-    k_spmv<2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_out, dot_w, za, zb);
+    k_spmv<2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
   PF_LAUNCH_CHECK();
   return PF_OK;
-}
-
-int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out, const double* dot_w) {
-  return launch_spmv_full(ctx, vals, x, y, dot_out, dot_w, nullptr, nullptr);
 }
 
 extern "C" int pf_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d, "pf_spmv: no pattern built");
   PF_REQUIRE(vals && x && y && x != y, "pf_spmv: NULL argument or x aliases y");
-  return pf_launch_spmv(ctx, vals, x, y, nullptr, nullptr);
+  return pf_launch_spmv(ctx, vals, x, y, nullptr);
 }
 
 extern "C" int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag) {
@@ -370,56 +442,9 @@ extern "C" int pf_apply_dirichlet(pf_ctx* ctx, double* Kvals, double* rhs, const
 extern "C" int pf_dot(pf_ctx* ctx, int64_t n, const double* a, const double* b, const double* w, double* out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(a && b && out && n >= 0, "pf_dot: NULL argument");
-  PF_HIP(hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
-  if (n) k_dot<<<vec_grid(n), 256, 0, ctx->stream>>>(n, a, b, w, out);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_cg_update_xr(pf_ctx* ctx, int64_t n, const double* rz, const double* pAp, const double* p,
-                               const double* Ap, const double* dinv, const double* w, double* x, double* r, double* z,
-                               double* rz_new, double* rr) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(rz && pAp && p && Ap && x && r && z && rz_new && rr, "pf_cg_update_xr: NULL argument");
-  PF_HIP(hipMemsetAsync(rz_new, 0, sizeof(double), ctx->stream));
-  PF_HIP(hipMemsetAsync(rr, 0, sizeof(double), ctx->stream));
-  k_cg_update_xr<<<vec_grid(n), 256, 0, ctx->stream>>>(n, rz, pAp, p, Ap, dinv, w, x, r, z, rz_new, rr);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_cg_update_p(pf_ctx* ctx, int64_t n, const double* rz_new, const double* rz_old, const double* z,
-                              double* p) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(rz_new && rz_old && z && p, "pf_cg_update_p: NULL argument");
-  k_cg_update_p<<<vec_grid(n), 256, 0, ctx->stream>>>(n, rz_new, rz_old, z, p, nullptr);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_gather(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  if (n == 0) return PF_OK;
-  PF_REQUIRE(idx && src && dst, "pf_gather: NULL argument");
-  k_gather<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, idx, src, dst);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_scatter_add(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  if (n == 0) return PF_OK;
-  PF_REQUIRE(idx && src && dst, "pf_scatter_add: NULL argument");
-  k_scatter_add<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, idx, src, dst);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_scatter_set(pf_ctx* ctx, int64_t n, const int32_t* idx, const double* src, double* dst) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  if (n == 0) return PF_OK;
-  PF_REQUIRE(idx && src && dst, "pf_scatter_set: NULL argument");
-  k_scatter_set<<<(unsigned)cdiv(n, 256), 256, 0, ctx->stream>>>(n, idx, src, dst);
+  const unsigned g = vec_grid(n);
+  k_dot<<<g, 256, 0, ctx->stream>>>(n, a, b, w, part(ctx, PA_BB));
+  k_finalize<<<1, 256, 0, ctx->stream>>>(1, part(ctx, PA_BB), (int)g, nullptr, 0, nullptr, 0, out);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -434,19 +459,32 @@ extern "C" int pf_copy_indexed(pf_ctx* ctx, int64_t n, const int32_t* src_idx, c
   return PF_OK;
 }
 
-extern "C" int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_out) {
+// ---- single-reduction CG steps (partials live in the ctx; pf_cgcg_reduce turns them into scalars) ----
+extern "C" int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d, "pf_spmv_dot: no pattern built");
-  PF_REQUIRE(vals && x && y && dot_out && x != y, "pf_spmv_dot: NULL argument or x aliases y");
-  return pf_launch_spmv(ctx, vals, x, y, dot_out, nullptr);
+  PF_REQUIRE(vals && x && y && x != y, "pf_spmv_dot: NULL argument or x aliases y");
+  return pf_launch_spmv(ctx, vals, x, y, part(ctx, PA_DELTA));
 }
 
-extern "C" int pf_cgcg_update_xrz(pf_ctx* ctx, int64_t n, const double* state, const double* p, const double* s,
-                                  const double* dinv, const double* w, double* x, double* r, double* z,
-                                  double* gamma_out, double* rr_out) {
+extern "C" int pf_cgcg_update_xrz(pf_ctx* ctx, const double* state, const double* p, const double* s,
+                                  const double* dinv, const double* w, double* x, double* r, double* z) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(state && p && s && x && r && z && gamma_out && rr_out, "pf_cgcg_update_xrz: NULL argument");
-  k_cgcg_update_xrz<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, p, s, dinv, w, x, r, z, gamma_out, rr_out);
+  PF_REQUIRE(ctx->d && state && p && s && x && r && z, "pf_cgcg_update_xrz: no pattern / NULL argument");
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  k_cgcg_update_xrz<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, p, s, dinv, w, x, r, z, part(ctx, PA_GAMMA),
+                                                          part(ctx, PA_RR2));
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_cgcg_reduce(pf_ctx* ctx, double* red_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && red_out, "pf_cgcg_reduce: no pattern / NULL argument");
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  const int nv = (int)vec_grid(n), ns = (int)spmv_grid(ctx->nnodes);
+  k_finalize<<<1, 256, 0, ctx->stream>>>(3, part(ctx, PA_GAMMA), nv, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), nv,
+                                         red_out);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -459,20 +497,26 @@ extern "C" int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, in
   return PF_OK;
 }
 
-extern "C" int pf_cgcg_update_ps(pf_ctx* ctx, int64_t n, const double* state, const double* z, const double* w,
-                                 double* p, double* s) {
+extern "C" int pf_cgcg_update_ps(pf_ctx* ctx, const double* state, const double* z, const double* w, double* p,
+                                 double* s) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(state && z && w && p && s, "pf_cgcg_update_ps: NULL argument");
+  PF_REQUIRE(ctx->d && state && z && w && p && s, "pf_cgcg_update_ps: no pattern / NULL argument");
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   k_cgcg_update_ps<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, z, w, p, s);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-// native PCG loop: three launches per iteration, scalars stay on the device, the host only
-// reads ||r||^2 back every `check_every` iterations.
-// scal layout: [0] rz_a  [1] rz_b  [2] pAp  [3] rr  [4] bb
+// native PCG loop: three launches per iteration, reductions through partial arrays, the host only
+// reads the r.r partials back every `check_every` iterations.
 // ------------------------------------------------------------------------------------------
+static double host_sum(const double* v, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += v[i];
+  return s;
+}
+
 extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
                      int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
@@ -488,9 +532,9 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
     ctx->cgw_cap = 5 * n;
   }
   double *r = ctx->cgw, *z = r + n, *p = z + n, *Ap = p + n, *dinv = Ap + n;
-  double* S = ctx->scal;
   hipStream_t st = ctx->stream;
   const unsigned vg = vec_grid(n);
+  const int ns = (int)spmv_grid(ctx->nnodes);
 
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
@@ -500,35 +544,35 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   } else {
     dinv = nullptr;
   }
-  PF_HIP(hipMemsetAsync(S, 0, 8 * sizeof(double), st));
-  int rc = launch_spmv_full(ctx, vals, x, Ap, nullptr, nullptr, nullptr, nullptr);  // Ap = A x0
+  int rc = pf_launch_spmv(ctx, vals, x, Ap, nullptr);  // Ap = A x0
   if (rc) return rc;
-  k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, S + 0, S + 4, S + 3);
+  k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
   PF_LAUNCH_CHECK();
-  double h[5];
-  PF_HIP(hipMemcpyAsync(h, S, sizeof(h), hipMemcpyDeviceToHost, st));
+  static thread_local double h[2 * NPART];
+  PF_HIP(hipMemcpyAsync(h, part(ctx, PA_RR), sizeof(double) * 2 * NPART, hipMemcpyDeviceToHost, st));  // RR | BB
   PF_HIP(hipStreamSynchronize(st));
-  const double bnorm = sqrt(h[4]);
+  const double bnorm = sqrt(host_sum(h + NPART, (int)vg));
   const double tol = std::max(rtol * bnorm, atol);
-  double rnorm = sqrt(h[3]);
+  double rnorm = sqrt(host_sum(h, (int)vg));
   int it = 0;
-  int cur = 0;  // index of the live rz scalar
+  int cur = 0;  // which rz partial array is live
   while (rnorm > tol && it < maxiter) {
     const int burst = std::min(check_every, maxiter - it);
     for (int k = 0; k < burst; ++k) {
-      double *rz_old = S + cur, *rz_new = S + (cur ^ 1);
-      // Ap = A p, pAp = p.Ap ; clears rz_new and rr for the update kernel
-      rc = launch_spmv_full(ctx, vals, p, Ap, S + 2, nullptr, rz_new, S + 3);
+      double* rz_old = part(ctx, cur ? PA_RZ1 : PA_RZ0);
+      double* rz_new = part(ctx, cur ? PA_RZ0 : PA_RZ1);
+      rc = pf_launch_spmv(ctx, vals, p, Ap, part(ctx, PA_PAP));  // Ap = A p, partials of p.Ap
       if (rc) return rc;
-      k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, S + 2, p, Ap, dinv, nullptr, x, r, z, rz_new, S + 3);
-      k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, rz_old, z, p, S + 2);
+      k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, (int)vg, part(ctx, PA_PAP), ns, p, Ap, dinv, x, r, z, rz_new,
+                                         part(ctx, PA_RR));
+      k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, rz_old, (int)vg, z, p);
       cur ^= 1;
     }
     PF_LAUNCH_CHECK();
     it += burst;
-    PF_HIP(hipMemcpyAsync(h, S, sizeof(h), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(h, part(ctx, PA_RR), sizeof(double) * vg, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
-    rnorm = sqrt(h[3]);
+    rnorm = sqrt(host_sum(h, (int)vg));
     if (!(rnorm == rnorm)) break;  // NaN: breakdown
   }
   if (iters_host) *iters_host = it;
@@ -552,7 +596,7 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
     PF_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < nrep && rc == PF_OK; ++i) {
       if (which == PF_K_ASSEMBLE_ELASTICITY) rc = pf_launch_assemble_elasticity(ctx, E, nu, p, in0, PF_SCATTER_GATHER, out0);
-      else if (which == PF_K_SPMV) rc = pf_launch_spmv(ctx, in0, in1, out0, nullptr, nullptr);
+      else if (which == PF_K_SPMV) rc = pf_launch_spmv(ctx, in0, in1, out0, nullptr);
       else if (which == PF_K_ASSEMBLE_HELMHOLTZ) rc = pf_launch_assemble_helmholtz(ctx, E, out0, nullptr);
       else rc = pf_fail(ctx, PF_E_INVALID, "pf_time_kernel: unknown kernel");
     }

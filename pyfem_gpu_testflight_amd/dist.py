@@ -112,8 +112,8 @@ class HipLocalOps:
     def diag(self, K):
         return self.h.diag(K)
 
-    def spmv_dot(self, K, x, y, dot_out):
-        self._call("pf_spmv_dot", self._p(K), self._p(x), self._p(y), self._p(dot_out))
+    def spmv_dot(self, K, x, y):
+        self._call("pf_spmv_dot", self._p(K), self._p(x), self._p(y))
 
     def copy_indexed(self, n, src_idx, dst_idx, src, dst):
         self._call("pf_copy_indexed", C.c_int64(n), self._p(src_idx), self._p(dst_idx), self._p(src), self._p(dst))
@@ -121,16 +121,18 @@ class HipLocalOps:
     def dot(self, a, b, w, out):
         self._call("pf_dot", C.c_int64(a.numel()), self._p(a), self._p(b), self._p(w), self._p(out))
 
-    def cgcg_update_xrz(self, state, p, s, dinv, w, x, r, z, gamma_out, rr_out):
-        self._call("pf_cgcg_update_xrz", C.c_int64(self.n), self._p(state), self._p(p), self._p(s), self._p(dinv),
-                   self._p(w), self._p(x), self._p(r), self._p(z), self._p(gamma_out), self._p(rr_out))
+    def cgcg_update_xrz(self, state, p, s, dinv, w, x, r, z):
+        self._call("pf_cgcg_update_xrz", self._p(state), self._p(p), self._p(s), self._p(dinv), self._p(w),
+                   self._p(x), self._p(r), self._p(z))
+
+    def cgcg_reduce(self, red):
+        self._call("pf_cgcg_reduce", self._p(red))
 
     def cgcg_scalars(self, state, red, first):
         self._call("pf_cgcg_scalars", self._p(state), self._p(red), int(first))
 
     def cgcg_update_ps(self, state, z, w, p, s):
-        self._call("pf_cgcg_update_ps", C.c_int64(self.n), self._p(state), self._p(z), self._p(w), self._p(p),
-                   self._p(s))
+        self._call("pf_cgcg_update_ps", self._p(state), self._p(z), self._p(w), self._p(p), self._p(s))
 
 
 # ------------------------------------------------------------------------------------------
@@ -185,8 +187,9 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
     it, rnorm = 0, float("inf")
     while it < maxiter:
         buf.zero_()
-        ops.cgcg_update_xrz(state, p, s, dinv, own_w, x, r, z, red[0:1], red[2:3])
-        ops.spmv_dot(K, z, w, red[1:2])
+        ops.cgcg_update_xrz(state, p, s, dinv, own_w, x, r, z)
+        ops.spmv_dot(K, z, w)
+        ops.cgcg_reduce(red)  # local [gamma, delta, rr] into the tail of the all-reduce buffer
         ops.copy_indexed(iface.n, iface.local, iface.slots, w, buf)
         _all_reduce(buf, iface.group)
         ops.copy_indexed(iface.n, iface.slots, iface.local, buf, w)

@@ -23,9 +23,9 @@ class NumpyLocalOps:
     def diag(self, K):
         return torch.from_numpy(K.diagonal().copy())
 
-    def spmv_dot(self, K, x, y, dot_out):
+    def spmv_dot(self, K, x, y):
         y[:] = torch.from_numpy(K.dot(x.numpy()))
-        dot_out += x.dot(y)
+        self._delta = float(x.dot(y))
 
     def copy_indexed(self, n, src_idx, dst_idx, src, dst):
         v = src[src_idx.long()] if src_idx is not None else src[:n]
@@ -37,14 +37,17 @@ class NumpyLocalOps:
     def dot(self, a, b, w, out):
         out[0] = (a * b * w).sum() if w is not None else a.dot(b)
 
-    def cgcg_update_xrz(self, state, p, s, dinv, w, x, r, z, gamma_out, rr_out):
+    def cgcg_update_xrz(self, state, p, s, dinv, w, x, r, z):
         alpha = state[0]
         x += alpha * p
         r -= alpha * s
         z[:] = dinv * r if dinv is not None else r
         ww = w if w is not None else 1.0
-        gamma_out += (ww * r * z).sum()
-        rr_out += (ww * r * r).sum()
+        self._gamma = float((ww * r * z).sum())
+        self._rr = float((ww * r * r).sum())
+
+    def cgcg_reduce(self, red):
+        red[0], red[1], red[2] = self._gamma, self._delta, self._rr
 
     def cgcg_scalars(self, state, red, first):
         g, d = float(red[0]), float(red[1])

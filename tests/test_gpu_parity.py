@@ -304,3 +304,22 @@ def test_large_mesh_properties(pf):
     r = rhs - K.dot(u)
     assert float(r.norm()) <= 1.5e-6 * float(rhs.norm())
     assert float(u[torch.as_tensor(np.asarray(dof_fixed), device=h.device)].abs().max()) == 0.0
+
+
+def test_cg_is_bitwise_reproducible(pf):
+    """No atomics anywhere in assembly, SpMV or the reductions: two solves give identical bits."""
+    import torch
+
+    c = pf.ProblemCreator(150, 97)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q, b = _qb(pf, "quad")
+    sols = []
+    for _ in range(2):
+        model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+        K = model.compute_jacobian()
+        rhs = model.hctx.to_device(model.compute_rhs(), torch.float64)
+        K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+        x, it, _ = model.hctx.cg(K.vals, rhs, rtol=1e-10)
+        sols.append((x.clone(), it))
+    assert sols[0][1] == sols[1][1]
+    assert bool((sols[0][0] == sols[1][0]).all())
