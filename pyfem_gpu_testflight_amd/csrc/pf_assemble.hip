@@ -23,6 +23,8 @@
 //
 //   ATOMIC scatter (cross-check / evidence only): one lane per element, full Ke, fp64
 //   global_atomic_add_f64 into the same value array.
+#include <stdlib.h>
+
 #include "pf_common.h"
 
 static constexpr double GP = 0.5773502691896258;  // 1/sqrt(3), == 1.0/np.sqrt(3.0)  (pyfem.py:87-90)
@@ -199,16 +201,10 @@ struct Helmholtz {
   }
 };
 
+// rows of Ke owned by local node a, from element coordinates (and nodal densities) in registers
 template <int P, class Phys, bool RHO>
-__device__ __forceinline__ void element_rows(const typename Phys::Params& pr, const double* __restrict__ X,
-                                             const int32_t nd[P], int a, double v[P][Phys::V]) {
-  Elem<P> el;
-  load_elem<P>(X, nd, el);
-  double rho_e[P];
-  if constexpr (RHO) {
-#pragma unroll
-    for (int l = 0; l < P; ++l) rho_e[l] = pr.rho[nd[l]];  // utils.py:155-168
-  }
+__device__ __forceinline__ void element_rows_core(const typename Phys::Params& pr, const Elem<P>& el,
+                                                  const double rho_e[P], int a, double v[P][Phys::V]) {
 #pragma unroll
   for (int b = 0; b < P; ++b)
 #pragma unroll
@@ -226,6 +222,258 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
   }
 }
 
+template <int P, class Phys, bool RHO>
+__device__ __forceinline__ void element_rows(const typename Phys::Params& pr, const double* __restrict__ X,
+                                             const int32_t nd[P], int a, double v[P][Phys::V]) {
+  Elem<P> el;
+  load_elem<P>(X, nd, el);
+  double rho_e[P];
+  if constexpr (RHO) {
+#pragma unroll
+    for (int l = 0; l < P; ++l) rho_e[l] = pr.rho[nd[l]];  // utils.py:155-168
+  }
+  element_rows_core<P, Phys, RHO>(pr, el, rho_e, a, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// GATHER assembly v2 (default): persistent single-wave workgroups, software-pipelined over tiles.
+//
+// What the r01/r02 measurements said about the first version (one short-lived workgroup per
+// 64-node tile): skeleton loads ~155 us + quadrature ~280 us + write-out ~270 us ADD UP (714 us) --
+// every tile pays a 4-deep dependent load chain (row pointers -> incidence -> conn -> X), then
+// computes, then holds its LDS and wave slots while its stores drain, and VGPR/LDS occupancy is
+// too low for other tiles to cover that.  This version removes the serialisation instead of
+// relying on occupancy:
+//   * lane = node.  The coordinates (and densities) of the node's ROW NEIGHBOURS are staged once
+//     per tile in LDS ([neighbour slot][lane]); an incident element's corner nodes are neighbour
+//     slots (the 1-byte positions the symbolic phase stored), so the quadrature reads its inputs
+//     from LDS: the kernel touches neither conn nor the incidence list, and X is gathered 9 times
+//     per node instead of 16.
+//   * one wave walks a contiguous run of tiles.  Row pointers for tile t+1 are requested at the top
+//     of tile t, neighbour ids / position words after the first incident element, the X gathers
+//     after the last; they are waited for and parked in LDS BEFORE tile t's stores are issued.
+//     vmcnt retires in issue order on gfx950 (stores included), so a load waited for after a store
+//     would expose the full store drain; here no wait ever sits behind a fresh store, and the drain
+//     of tile t overlaps the quadrature of tile t+1.
+//   * a single wave accumulates its incident elements in ascending order with plain LDS
+//     read-modify-writes: no barriers, no atomics, bitwise reproducible.
+// dynamic LDS (doubles first): acc[maxrow*V*65] | xs[maxrow*65] double2 | rs[maxrow*65] (RHO) |
+//                              pws[maxval*64] u32 | prefix[2][64] i32 | owner[2][64*maxrow] u8
+// ------------------------------------------------------------------------------------------
+static constexpr int V2_CH = 12;   // neighbour ids prefetched in registers (rest: slow path)
+static constexpr int V2_JCH = 8;   // position words prefetched in registers (rest: slow path)
+
+struct V2Ptrs {
+  int32_t rowbase, cnt, jb, nj, dpos;
+};
+
+struct V2Lds {
+  double* acc;
+  double2* xs;
+  double* rs;
+  uint32_t* pws;
+  int32_t* prefix;
+  uint8_t* owner;
+  int maxrow;
+};
+
+__device__ __forceinline__ V2Ptrs v2_load_ptrs(int64_t tile, int lane, int64_t nnodes, const int32_t* __restrict__ nptr,
+                                               const int32_t* __restrict__ n2e_ptr,
+                                               const uint8_t* __restrict__ diagpos) {
+  V2Ptrs q;
+  const int64_t n = tile * 64 + lane;
+  if (n < nnodes) {
+    const int32_t a0 = nptr[n], a1 = nptr[n + 1], b0 = n2e_ptr[n], b1 = n2e_ptr[n + 1];
+    q.rowbase = a0; q.cnt = a1 - a0; q.jb = b0; q.nj = b1 - b0; q.dpos = diagpos[n];
+  } else {
+    q.rowbase = 0; q.cnt = 0; q.jb = 0; q.nj = 0; q.dpos = 0;
+  }
+  return q;
+}
+
+// neighbour ids and position words of the lane's node, fixed-size register sets (0 beyond the row)
+#define V2_LOAD_LISTS(q)                                                                  \
+  _Pragma("unroll") for (int c = 0; c < V2_CH; ++c) nid[c] = (c < (q).cnt) ? nidx[(q).rowbase + c] : 0; \
+  _Pragma("unroll") for (int j = 0; j < V2_JCH; ++j) pw[j] = (j < (q).nj) ? n2e_pos4[(q).jb + j] : 0u;
+
+// stage the tile described by q in LDS: X (rho) of the row neighbours, position words, write-out maps
+template <bool RHO>
+__device__ __forceinline__ void v2_stage(const V2Ptrs& q, const int32_t (&nid)[V2_CH], const uint32_t (&pw)[V2_JCH],
+                                         int pb, int lane, const V2Lds& L, const double* __restrict__ X,
+                                         const double* __restrict__ rho, const int32_t* __restrict__ nidx,
+                                         const uint32_t* __restrict__ n2e_pos4, int32_t& total, int32_t& wavebase,
+                                         int32_t& maxnj) {
+  // X (and rho) gathers of the row neighbours: issue all, then park in LDS
+  double2 xv[V2_CH];
+  double rv[V2_CH];
+#pragma unroll
+  for (int c = 0; c < V2_CH; ++c) {  // nid[c] == 0 beyond the row: a harmless in-range load
+    xv[c] = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nid[c]);
+    if constexpr (RHO) rv[c] = rho[nid[c]]; else rv[c] = 0.0;
+  }
+  // exclusive wave scan of cnt, tile totals (independent work while the gathers fly)
+  int32_t incl = q.cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  const int32_t pre = incl - q.cnt;
+  total = __shfl(incl, 63);
+  wavebase = __shfl(q.rowbase, 0);
+  int32_t mx = q.nj;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  maxnj = mx;
+  L.prefix[pb * 64 + lane] = pre;
+  uint8_t* own = L.owner + (size_t)pb * 64 * L.maxrow;
+  for (int c = 0; c < q.cnt; ++c) own[pre + c] = (uint8_t)lane;
+#pragma unroll
+  for (int j = 0; j < V2_JCH; ++j)
+    if (j < q.nj) L.pws[j * 64 + lane] = pw[j];
+  for (int j = V2_JCH; j < q.nj; ++j) L.pws[j * 64 + lane] = n2e_pos4[q.jb + j];  // slow path
+#pragma unroll
+  for (int c = 0; c < V2_CH; ++c) {
+    if (c < q.cnt) {
+      L.xs[c * LDS_STRIDE + lane] = xv[c];
+      if constexpr (RHO) L.rs[c * LDS_STRIDE + lane] = rv[c];
+    }
+  }
+  for (int c = V2_CH; c < q.cnt; ++c) {  // slow path: very high valence
+    const int32_t m = nidx[q.rowbase + c];
+    L.xs[c * LDS_STRIDE + lane] = *reinterpret_cast<const double2*>(X + 2 * (int64_t)m);
+    if constexpr (RHO) L.rs[c * LDS_STRIDE + lane] = rho[m];
+  }
+}
+
+template <int P, class Phys, bool RHO, int ABL = 0>
+__global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxrow, int32_t maxval,
+                                                    const double* __restrict__ X,
+                                                    const int32_t* __restrict__ nptr,
+                                                    const int32_t* __restrict__ nidx,
+                                                    const int32_t* __restrict__ n2e_ptr,
+                                                    const uint32_t* __restrict__ n2e_pos4,
+                                                    const uint8_t* __restrict__ diagpos,
+                                                    typename Phys::Params pr, double* __restrict__ out0,
+                                                    double* __restrict__ out1) {
+  constexpr int V = Phys::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  V2Lds L;
+  L.maxrow = maxrow;
+  L.acc = reinterpret_cast<double*>(smem);
+  L.xs = reinterpret_cast<double2*>(L.acc + (size_t)maxrow * V * LDS_STRIDE);
+  L.rs = reinterpret_cast<double*>(L.xs + (size_t)maxrow * LDS_STRIDE);
+  L.pws = reinterpret_cast<uint32_t*>(L.rs + (RHO ? (size_t)maxrow * LDS_STRIDE : 0));
+  L.prefix = reinterpret_cast<int32_t*>(L.pws + (size_t)maxval * 64);
+  L.owner = reinterpret_cast<uint8_t*>(L.prefix + 128);
+  double* const acc = L.acc;
+  double2* const xs = L.xs;
+  double* const rs = L.rs;
+  uint32_t* const pws = L.pws;
+  int32_t* const prefix = L.prefix;
+  uint8_t* const owner = L.owner;
+
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (nnodes + 63) / 64;
+  const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+  if (t0 >= t1) return;
+  typedef V2Ptrs Ptrs;
+
+  // ---- prologue: first tile, nothing to overlap with -------------------------------------------
+  Ptrs cur = v2_load_ptrs(t0, lane, nnodes, nptr, n2e_ptr, diagpos);
+  int32_t nid[V2_CH];
+  uint32_t pw[V2_JCH];
+  V2_LOAD_LISTS(cur)
+  int pb = 0;
+  int32_t total, wavebase, maxnj;
+  v2_stage<RHO>(cur, nid, pw, pb, lane, L, X, pr.rho, nidx, n2e_pos4, total, wavebase, maxnj);
+  for (int s = 0; s < cur.cnt * V; ++s) acc[s * LDS_STRIDE + lane] = 0.0;
+
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const bool more = tile + 1 < t1;
+    Ptrs nxt = cur;
+    if (more) nxt = v2_load_ptrs(tile + 1, lane, nnodes, nptr, n2e_ptr, diagpos);  // in flight during element 0
+
+    // ---- incident elements of this tile, ascending ------------------------------------------
+    for (int32_t j = 0; j < maxnj; ++j) {
+      if (j < cur.nj) {
+        const uint32_t pk = pws[j * 64 + lane];
+        int pos[P];
+#pragma unroll
+        for (int b = 0; b < P; ++b) pos[b] = (pk >> (8 * b)) & 255;
+        int a = 0;
+#pragma unroll
+        for (int b = 1; b < P; ++b) a = (pos[b] == cur.dpos) ? b : a;
+        double v[P][V];
+        if constexpr (ABL & 1) {
+#pragma unroll
+          for (int b = 0; b < P; ++b)
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[b][k] = (double)(pos[b] + k + a);
+        } else {
+          Elem<P> el;
+          double rho_e[P];
+#pragma unroll
+          for (int b = 0; b < P; ++b) {
+            const double2 xy = xs[pos[b] * LDS_STRIDE + lane];
+            el.x[b] = xy.x;
+            el.y[b] = xy.y;
+            if constexpr (RHO) rho_e[b] = rs[pos[b] * LDS_STRIDE + lane];
+          }
+          element_rows_core<P, Phys, RHO>(pr, el, rho_e, a, v);
+        }
+#pragma unroll
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+      }
+      if (j == 0 && more) { V2_LOAD_LISTS(nxt) }  // row pointers of tile+1 have landed by now
+    }
+    if (maxnj == 0 && more) { V2_LOAD_LISTS(nxt) }
+
+    // ---- stage tile+1 (its loads complete BEFORE this tile's stores are issued) ---------------
+    int32_t total_n = 0, wavebase_n = 0, maxnj_n = 0;
+    if (more) v2_stage<RHO>(nxt, nid, pw, pb ^ 1, lane, L, X, pr.rho, nidx, n2e_pos4, total_n, wavebase_n, maxnj_n);
+
+    // ---- write-out of this tile: lane q stores the q-th 16-byte piece of the tile's range ------
+    {
+      const int32_t* pf = prefix + pb * 64;
+      const uint8_t* own = owner + (size_t)pb * 64 * maxrow;
+      if constexpr (V == 4) {
+        const int32_t total2 = (ABL & 4) ? min(total, 1) : 2 * total;
+        double2* dst = reinterpret_cast<double2*>(out0 + 4 * (int64_t)wavebase);
+        for (int32_t q = lane; q < total2; q += 64) {
+          const int32_t tb = q >> 1;
+          const int hb = (q & 1) * 2;
+          const int o = own[tb];
+          const int c = tb - pf[o];
+          double2 v2;
+          v2.x = acc[(c * 4 + hb) * LDS_STRIDE + o];
+          v2.y = acc[(c * 4 + hb + 1) * LDS_STRIDE + o];
+          dst[q] = v2;
+        }
+      } else {
+        for (int32_t tb = lane; tb < ((ABL & 4) ? min(total, 1) : total); tb += 64) {
+          const int o = own[tb];
+          const int c = tb - pf[o];
+          const int64_t g = (int64_t)wavebase + tb;
+          if (out0) out0[g] = acc[(c * 2 + 0) * LDS_STRIDE + o];
+          if (out1) out1[g] = acc[(c * 2 + 1) * LDS_STRIDE + o];
+        }
+      }
+    }
+    // ---- next tile becomes current -----------------------------------------------------------------
+    if (more) {
+      cur = nxt;
+      pb ^= 1;
+      total = total_n;
+      wavebase = wavebase_n;
+      maxnj = maxnj_n;
+      for (int s = 0; s < cur.cnt * V; ++s) acc[s * LDS_STRIDE + lane] = 0.0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // GATHER assembly: one workgroup of NW waves per 64 consecutive nodes.
 //   lane  = node (owns the node's d rows of K)
@@ -238,7 +486,7 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 //   result is bitwise reproducible.
 // dynamic LDS: double acc[max_row_blocks*V*65] ; int32 prefix[64] ; uint8 owner[64*max_row_blocks]
 // ------------------------------------------------------------------------------------------
-template <int P, class Phys, bool RHO, int NW>
+template <int P, class Phys, bool RHO, int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes, int32_t maxrow, int32_t maxval,
                                                              const double* __restrict__ X,
                                                              const int32_t* __restrict__ conn,
@@ -298,38 +546,59 @@ __global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes,
         pos[0] = pk & 255; pos[1] = (pk >> 8) & 255; pos[2] = (pk >> 16) & 255; pos[3] = pk >> 24;
       } else {
 #pragma unroll
-        for (int b = 0; b < P; ++b) pos[b] = n2e_pos[(int64_t)P * jj + b];
+        for (int b = 0; b < P; ++b) pos[b] = n2e_pos[4 * (int64_t)jj + b];
       }
-      element_rows<P, Phys, RHO>(pr, X, nd, a, v);
+      if constexpr (ABL & 1) {  // ablation: no quadrature (keeps the index loads)
+#pragma unroll
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+          for (int k = 0; k < V; ++k) v[b][k] = (double)(nd[b] + k + a);
+      } else {
+        element_rows<P, Phys, RHO>(pr, X, nd, a, v);
+      }
     }
     // ordered accumulate: incident element r0+0, r0+1, ... (fixed order => reproducible sums)
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       if (w == wave && has) {
+        if constexpr (ABL & 2) {  // ablation: no LDS accumulate (one add keeps v alive)
+          double t = 0.0;
 #pragma unroll
-        for (int b = 0; b < P; ++b)
+          for (int b = 0; b < P; ++b)
 #pragma unroll
-          for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+            for (int k = 0; k < V; ++k) t += v[b][k];
+          acc[pos[0] * V * LDS_STRIDE + lane] += t;
+        } else {
+#pragma unroll
+          for (int b = 0; b < P; ++b)
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+        }
       }
       __syncthreads();
     }
   }
 
   // coalesced write-out: thread t takes coupling (block) t of the tile's contiguous range
-  for (int32_t tb = threadIdx.x; tb < total; tb += 64 * NW) {
-    const int o = owner[tb];
-    const int c = tb - prefix[o];
-    const int64_t g = (int64_t)wavebase + tb;
-    if constexpr (V == 4) {
-      double2 lo, hi;
-      lo.x = acc[(c * 4 + 0) * LDS_STRIDE + o];
-      lo.y = acc[(c * 4 + 1) * LDS_STRIDE + o];
-      hi.x = acc[(c * 4 + 2) * LDS_STRIDE + o];
-      hi.y = acc[(c * 4 + 3) * LDS_STRIDE + o];
-      double2* dst = reinterpret_cast<double2*>(out0 + 4 * g);
-      dst[0] = lo;
-      dst[1] = hi;
-    } else {
+  if constexpr (V == 4) {
+    // thread t stores the t-th 16-byte half block: a wave store covers 1 KiB contiguous
+    const int32_t total2 = (ABL & 4) ? min(total, 1) : 2 * total;  // ABL&4: no write-out
+    double2* dst = reinterpret_cast<double2*>(out0 + 4 * (int64_t)wavebase);
+    for (int32_t q = threadIdx.x; q < total2; q += 64 * NW) {
+      const int32_t tb = q >> 1;
+      const int hb = (q & 1) * 2;
+      const int o = owner[tb];
+      const int c = tb - prefix[o];
+      double2 v2;
+      v2.x = acc[(c * 4 + hb) * LDS_STRIDE + o];
+      v2.y = acc[(c * 4 + hb + 1) * LDS_STRIDE + o];
+      dst[q] = v2;
+    }
+  } else {
+    for (int32_t tb = threadIdx.x; tb < ((ABL & 4) ? min(total, 1) : total); tb += 64 * NW) {
+      const int o = owner[tb];
+      const int c = tb - prefix[o];
+      const int64_t g = (int64_t)wavebase + tb;
       if (out0) out0[g] = acc[(c * 2 + 0) * LDS_STRIDE + o];
       if (out1) out1[g] = acc[(c * 2 + 1) * LDS_STRIDE + o];
     }
@@ -414,20 +683,75 @@ static size_t gather_lds_bytes(int maxrow, int V) {
   return (b + 15) & ~(size_t)15;
 }
 
-static constexpr int GATHER_NW = 4;  // waves per 64-node tile
+static constexpr int GATHER_NW = 2;  // waves per 64-node tile of the legacy kernel
+
+static size_t v2_lds_bytes(int maxrow, int maxval, int V, bool rho) {
+  size_t b = (size_t)maxrow * V * LDS_STRIDE * 8 + (size_t)maxrow * LDS_STRIDE * 16 +
+             (rho ? (size_t)maxrow * LDS_STRIDE * 8 : 0) + (size_t)maxval * 64 * 4 + 128 * 4 + (size_t)2 * 64 * maxrow;
+  return (b + 15) & ~(size_t)15;
+}
 
 template <int P, class Phys, bool RHO>
-static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
+static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   const size_t lds = gather_lds_bytes(ctx->max_row_blocks, Phys::V);
   if (lds > 160 * 1024)
     return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");
   auto kern = k_assemble_gather<P, Phys, RHO, GATHER_NW>;
+  int nw = GATHER_NW;
+  if constexpr (P == 4 && Phys::V == 4 && !RHO) {
+    const char* e = getenv("PF_GATHER_NW");
+    const char* ab = getenv("PF_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+    if (e) nw = atoi(e);
+    if (nw != 1 && nw != 4) nw = 2;
+#define PF_PICK(NWV)                                                          \
+    if (nw == NWV) {                                                          \
+      if (abl == 1) kern = k_assemble_gather<P, Phys, RHO, NWV, 1>;           \
+      else if (abl == 4) kern = k_assemble_gather<P, Phys, RHO, NWV, 4>;      \
+      else if (abl == 5) kern = k_assemble_gather<P, Phys, RHO, NWV, 5>;      \
+      else kern = k_assemble_gather<P, Phys, RHO, NWV, 0>;                    \
+    }
+    PF_PICK(1) PF_PICK(2) PF_PICK(4)
+#undef PF_PICK
+  }
   if (lds > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned grid = (unsigned)cdiv(ctx->nnodes, 64);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * GATHER_NW), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
                      ctx->max_valence, ctx->X, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, pr, out0,
                      out1);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// Timing experiments only:  PF_GATHER_IMPL=legacy selects the first-generation kernel
+// (PF_GATHER_NW=1|2|4 waves per tile);  PF_ABLATE=<bits> (1 no quadrature, 4 no write-out) produces
+// deliberately wrong results for phase-cost measurements (quad elasticity without density only).
+template <int P, class Phys, bool RHO>
+static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
+  const char* impl = getenv("PF_GATHER_IMPL");
+  if (impl && impl[0] == 'l') return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
+  const size_t lds = v2_lds_bytes(ctx->max_row_blocks, ctx->max_valence, Phys::V, RHO);
+  if (lds > 160 * 1024)
+    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");
+  auto kern = k_assemble_v2<P, Phys, RHO, 0>;
+  if constexpr (P == 4 && Phys::V == 4 && !RHO) {
+    const char* ab = getenv("PF_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+    if (abl == 1) kern = k_assemble_v2<P, Phys, RHO, 1>;
+    else if (abl == 4) kern = k_assemble_v2<P, Phys, RHO, 4>;
+    else if (abl == 5) kern = k_assemble_v2<P, Phys, RHO, 5>;
+  }
+  if (lds > 48 * 1024)
+    PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t ntiles = cdiv(ctx->nnodes, 64);
+  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
+  const char* g = getenv("PF_GATHER_WAVES_PER_CU");
+  if (g && atoi(g) > 0) per_cu = atoi(g);
+  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, (int64_t)256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
+                     ctx->max_valence, ctx->X, ctx->nptr, ctx->nidx, ctx->n2e_ptr,
+                     reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->diagpos, pr, out0, out1);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -31,7 +31,7 @@ struct pf_ctx {
   int32_t* nidx = nullptr;   // (nblocks)  neighbour node ids, ascending per row
   int32_t* n2e_ptr = nullptr;  // (nnodes+1) node -> incident (element, local index) list
   int32_t* n2e = nullptr;      // (nelems*P) entries e*P + a, ascending per node
-  uint8_t* n2e_pos = nullptr;  // (nelems*P*P) for incident pair j and element node b:
+  uint8_t* n2e_pos = nullptr;  // (nelems*P*4) 4 bytes per incident pair j; byte b (< P):
                                //   position of conn[e,b] in row n of the node graph
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)

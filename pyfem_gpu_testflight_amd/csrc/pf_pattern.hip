@@ -125,7 +125,7 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
       int32_t m = conn[(int64_t)e * P + b];
       int k = 0;
       while (nb[k] != m) ++k;
-      n2e_pos[(int64_t)j * P + b] = (uint8_t)k;
+      n2e_pos[(int64_t)j * 4 + b] = (uint8_t)k;
     }
   }
 }
@@ -310,7 +310,8 @@ static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
   PF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->nblocks = total;
   PF_HIP(hipMalloc(&ctx->nidx, sizeof(int32_t) * (size_t)total));
-  PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * P));
+  PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * 4));
+  PF_HIP(hipMemsetAsync(ctx->n2e_pos, 0, (size_t)ctx->nelems * P * 4, ctx->stream));
   PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
   k_row_fill<P><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
                                                               ctx->nidx, ctx->n2e_pos, ctx->diagpos);
