@@ -258,7 +258,7 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 //   * a single wave accumulates its incident elements in ascending order with plain LDS
 //     read-modify-writes: no barriers, no atomics, bitwise reproducible.
 // dynamic LDS (doubles first): acc[maxrow*V*65] | xs[maxrow*65] double2 | rs[maxrow*65] (RHO) |
-//                              pws[maxval*64] u32 | prefix[2][64] i32 | owner[2][64*maxrow] u8
+//                              pws[maxval*64] u32 | src[2][64*maxrow] u16
 // ------------------------------------------------------------------------------------------
 static constexpr int V2_CH = 12;   // neighbour ids prefetched in registers (rest: slow path)
 static constexpr int V2_JCH = 8;   // position words prefetched in registers (rest: slow path)
@@ -268,12 +268,11 @@ struct V2Ptrs {
 };
 
 struct V2Lds {
-  double* acc;
-  double2* xs;
-  double* rs;
-  uint32_t* pws;
-  int32_t* prefix;
-  uint8_t* owner;
+  double2* acc;    // [(slot*VH + h)*65 + lane]  values (2h, 2h+1) of the slot's V-vector
+  double2* xs;     // [slot*65 + lane]           neighbour coordinates
+  double* rs;      // [slot*65 + lane]           neighbour densities (RHO)
+  uint32_t* pws;   // [j*64 + lane]              position words of the incident elements
+  uint16_t* src;   // [2][64*maxrow]             write-out map: lane | slot<<8 for the tile's t-th block
   int maxrow;
 };
 
@@ -296,7 +295,7 @@ __device__ __forceinline__ V2Ptrs v2_load_ptrs(int64_t tile, int lane, int64_t n
   _Pragma("unroll") for (int c = 0; c < V2_CH; ++c) nid[c] = (c < (q).cnt) ? nidx[(q).rowbase + c] : 0; \
   _Pragma("unroll") for (int j = 0; j < V2_JCH; ++j) pw[j] = (j < (q).nj) ? n2e_pos4[(q).jb + j] : 0u;
 
-// stage the tile described by q in LDS: X (rho) of the row neighbours, position words, write-out maps
+// stage the tile described by q in LDS: X (rho) of the row neighbours, position words, write-out map
 template <bool RHO>
 __device__ __forceinline__ void v2_stage(const V2Ptrs& q, const int32_t (&nid)[V2_CH], const uint32_t (&pw)[V2_JCH],
                                          int pb, int lane, const V2Lds& L, const double* __restrict__ X,
@@ -325,9 +324,8 @@ __device__ __forceinline__ void v2_stage(const V2Ptrs& q, const int32_t (&nid)[V
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
   maxnj = mx;
-  L.prefix[pb * 64 + lane] = pre;
-  uint8_t* own = L.owner + (size_t)pb * 64 * L.maxrow;
-  for (int c = 0; c < q.cnt; ++c) own[pre + c] = (uint8_t)lane;
+  uint16_t* sm = L.src + (size_t)pb * 64 * L.maxrow;
+  for (int c = 0; c < q.cnt; ++c) sm[pre + c] = (uint16_t)(lane | (c << 8));
 #pragma unroll
   for (int j = 0; j < V2_JCH; ++j)
     if (j < q.nj) L.pws[j * 64 + lane] = pw[j];
@@ -346,6 +344,19 @@ __device__ __forceinline__ void v2_stage(const V2Ptrs& q, const int32_t (&nid)[V
   }
 }
 
+// coordinates / densities of one incident element from the staged neighbours
+template <int P, bool RHO>
+__device__ __forceinline__ void v2_load_elem(uint32_t pk, int lane, const V2Lds& L, Elem<P>& el, double (&rho_e)[P]) {
+#pragma unroll
+  for (int b = 0; b < P; ++b) {
+    const int pos = (pk >> (8 * b)) & 255;
+    const double2 xy = L.xs[pos * LDS_STRIDE + lane];
+    el.x[b] = xy.x;
+    el.y[b] = xy.y;
+    if constexpr (RHO) rho_e[b] = L.rs[pos * LDS_STRIDE + lane]; else rho_e[b] = 1.0;
+  }
+}
+
 template <int P, class Phys, bool RHO, int ABL = 0>
 __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxrow, int32_t maxval,
                                                     const double* __restrict__ X,
@@ -357,50 +368,53 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1) {
   constexpr int V = Phys::V;
+  constexpr int VH = V / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V2Lds L;
   L.maxrow = maxrow;
-  L.acc = reinterpret_cast<double*>(smem);
-  L.xs = reinterpret_cast<double2*>(L.acc + (size_t)maxrow * V * LDS_STRIDE);
+  L.acc = reinterpret_cast<double2*>(smem);
+  L.xs = L.acc + (size_t)maxrow * VH * LDS_STRIDE;
   L.rs = reinterpret_cast<double*>(L.xs + (size_t)maxrow * LDS_STRIDE);
   L.pws = reinterpret_cast<uint32_t*>(L.rs + (RHO ? (size_t)maxrow * LDS_STRIDE : 0));
-  L.prefix = reinterpret_cast<int32_t*>(L.pws + (size_t)maxval * 64);
-  L.owner = reinterpret_cast<uint8_t*>(L.prefix + 128);
-  double* const acc = L.acc;
-  double2* const xs = L.xs;
-  double* const rs = L.rs;
-  uint32_t* const pws = L.pws;
-  int32_t* const prefix = L.prefix;
-  uint8_t* const owner = L.owner;
+  L.src = reinterpret_cast<uint16_t*>(L.pws + (size_t)maxval * 64);
+  double2* const acc = L.acc;
 
   const int lane = threadIdx.x;
   const int64_t ntiles = (nnodes + 63) / 64;
   const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
-  typedef V2Ptrs Ptrs;
 
   // ---- prologue: first tile, nothing to overlap with -------------------------------------------
-  Ptrs cur = v2_load_ptrs(t0, lane, nnodes, nptr, n2e_ptr, diagpos);
+  V2Ptrs cur = v2_load_ptrs(t0, lane, nnodes, nptr, n2e_ptr, diagpos);
   int32_t nid[V2_CH];
   uint32_t pw[V2_JCH];
   V2_LOAD_LISTS(cur)
   int pb = 0;
   int32_t total, wavebase, maxnj;
   v2_stage<RHO>(cur, nid, pw, pb, lane, L, X, pr.rho, nidx, n2e_pos4, total, wavebase, maxnj);
-  for (int s = 0; s < cur.cnt * V; ++s) acc[s * LDS_STRIDE + lane] = 0.0;
+  for (int s = 0; s < cur.cnt * VH; ++s) acc[s * LDS_STRIDE + lane] = make_double2(0.0, 0.0);
 
   for (int64_t tile = t0; tile < t1; ++tile) {
     const bool more = tile + 1 < t1;
-    Ptrs nxt = cur;
+    V2Ptrs nxt = cur;
     if (more) nxt = v2_load_ptrs(tile + 1, lane, nnodes, nptr, n2e_ptr, diagpos);  // in flight during element 0
 
-    // ---- incident elements of this tile, ascending ------------------------------------------
+    // ---- incident elements of this tile, ascending; inputs of element j+1 and the position
+    //      word of element j+2 are fetched from LDS while element j is integrated ------------------
+    uint32_t pk0 = (0 < cur.nj) ? L.pws[lane] : 0u;
+    uint32_t pk1 = (1 < cur.nj) ? L.pws[64 + lane] : 0u;
+    Elem<P> el0;
+    double rho0[P];
+    if (0 < cur.nj) v2_load_elem<P, RHO>(pk0, lane, L, el0, rho0);
     for (int32_t j = 0; j < maxnj; ++j) {
+      Elem<P> el1;
+      double rho1[P];
+      if (j + 1 < cur.nj) v2_load_elem<P, RHO>(pk1, lane, L, el1, rho1);
+      const uint32_t pk2 = (j + 2 < cur.nj) ? L.pws[(j + 2) * 64 + lane] : 0u;
       if (j < cur.nj) {
-        const uint32_t pk = pws[j * 64 + lane];
         int pos[P];
 #pragma unroll
-        for (int b = 0; b < P; ++b) pos[b] = (pk >> (8 * b)) & 255;
+        for (int b = 0; b < P; ++b) pos[b] = (pk0 >> (8 * b)) & 255;
         int a = 0;
 #pragma unroll
         for (int b = 1; b < P; ++b) a = (pos[b] == cur.dpos) ? b : a;
@@ -409,25 +423,25 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
 #pragma unroll
           for (int b = 0; b < P; ++b)
 #pragma unroll
-            for (int k = 0; k < V; ++k) v[b][k] = (double)(pos[b] + k + a);
+            for (int k = 0; k < V; ++k) v[b][k] = el0.x[b] + (double)(k + a);
         } else {
-          Elem<P> el;
-          double rho_e[P];
-#pragma unroll
-          for (int b = 0; b < P; ++b) {
-            const double2 xy = xs[pos[b] * LDS_STRIDE + lane];
-            el.x[b] = xy.x;
-            el.y[b] = xy.y;
-            if constexpr (RHO) rho_e[b] = rs[pos[b] * LDS_STRIDE + lane];
-          }
-          element_rows_core<P, Phys, RHO>(pr, el, rho_e, a, v);
+          element_rows_core<P, Phys, RHO>(pr, el0, rho0, a, v);
         }
+        // single wave, program order: ascending-element summation without read-back
 #pragma unroll
         for (int b = 0; b < P; ++b)
 #pragma unroll
-          for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
+          for (int k = 0; k < V; ++k) {
+            double* slot = reinterpret_cast<double*>(&acc[(pos[b] * VH + (k >> 1)) * LDS_STRIDE + lane]) + (k & 1);
+            __hip_atomic_fetch_add(slot, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
       }
       if (j == 0 && more) { V2_LOAD_LISTS(nxt) }  // row pointers of tile+1 have landed by now
+      pk0 = pk1;
+      pk1 = pk2;
+      el0 = el1;
+#pragma unroll
+      for (int b = 0; b < P; ++b) rho0[b] = rho1[b];
     }
     if (maxnj == 0 && more) { V2_LOAD_LISTS(nxt) }
 
@@ -435,30 +449,45 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
     int32_t total_n = 0, wavebase_n = 0, maxnj_n = 0;
     if (more) v2_stage<RHO>(nxt, nid, pw, pb ^ 1, lane, L, X, pr.rho, nidx, n2e_pos4, total_n, wavebase_n, maxnj_n);
 
-    // ---- write-out of this tile: lane q stores the q-th 16-byte piece of the tile's range ------
+    // ---- write-out of this tile: lane q stores the q-th 16-byte piece of the tile's range,
+    //      four pieces per lane in flight (one LDS lookup + one b128 read each) --------------------
     {
-      const int32_t* pf = prefix + pb * 64;
-      const uint8_t* own = owner + (size_t)pb * 64 * maxrow;
+      const uint16_t* sm = L.src + (size_t)pb * 64 * maxrow;
+      constexpr int U = 4;
       if constexpr (V == 4) {
         const int32_t total2 = (ABL & 4) ? min(total, 1) : 2 * total;
         double2* dst = reinterpret_cast<double2*>(out0 + 4 * (int64_t)wavebase);
-        for (int32_t q = lane; q < total2; q += 64) {
-          const int32_t tb = q >> 1;
-          const int hb = (q & 1) * 2;
-          const int o = own[tb];
-          const int c = tb - pf[o];
-          double2 v2;
-          v2.x = acc[(c * 4 + hb) * LDS_STRIDE + o];
-          v2.y = acc[(c * 4 + hb + 1) * LDS_STRIDE + o];
-          dst[q] = v2;
+        for (int32_t q0 = lane; q0 < total2; q0 += 64 * U) {
+          int sv[U];
+          double2 val[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) sv[u] = sm[min(q0 + 64 * u, total2 - 1) >> 1];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int o = sv[u] & 255, c = sv[u] >> 8, h = (q0 + 64 * u) & 1;
+            val[u] = acc[(c * 2 + h) * LDS_STRIDE + o];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (q0 + 64 * u < total2) dst[q0 + 64 * u] = val[u];
         }
       } else {
-        for (int32_t tb = lane; tb < ((ABL & 4) ? min(total, 1) : total); tb += 64) {
-          const int o = own[tb];
-          const int c = tb - pf[o];
-          const int64_t g = (int64_t)wavebase + tb;
-          if (out0) out0[g] = acc[(c * 2 + 0) * LDS_STRIDE + o];
-          if (out1) out1[g] = acc[(c * 2 + 1) * LDS_STRIDE + o];
+        const int32_t tot = (ABL & 4) ? min(total, 1) : total;
+        for (int32_t q0 = lane; q0 < tot; q0 += 64 * U) {
+          int sv[U];
+          double2 val[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) sv[u] = sm[min(q0 + 64 * u, tot - 1)];
+#pragma unroll
+          for (int u = 0; u < U; ++u) val[u] = acc[(sv[u] >> 8) * LDS_STRIDE + (sv[u] & 255)];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (q0 + 64 * u < tot) {
+              const int64_t g = (int64_t)wavebase + q0 + 64 * u;
+              if (out0) out0[g] = val[u].x;
+              if (out1) out1[g] = val[u].y;
+            }
+          }
         }
       }
     }
@@ -469,7 +498,7 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
       total = total_n;
       wavebase = wavebase_n;
       maxnj = maxnj_n;
-      for (int s = 0; s < cur.cnt * V; ++s) acc[s * LDS_STRIDE + lane] = 0.0;
+      for (int s = 0; s < cur.cnt * VH; ++s) acc[s * LDS_STRIDE + lane] = make_double2(0.0, 0.0);
     }
   }
 }
@@ -687,7 +716,7 @@ static constexpr int GATHER_NW = 2;  // waves per 64-node tile of the legacy ker
 
 static size_t v2_lds_bytes(int maxrow, int maxval, int V, bool rho) {
   size_t b = (size_t)maxrow * V * LDS_STRIDE * 8 + (size_t)maxrow * LDS_STRIDE * 16 +
-             (rho ? (size_t)maxrow * LDS_STRIDE * 8 : 0) + (size_t)maxval * 64 * 4 + 128 * 4 + (size_t)2 * 64 * maxrow;
+             (rho ? (size_t)maxrow * LDS_STRIDE * 8 : 0) + (size_t)maxval * 64 * 4 + (size_t)2 * 64 * maxrow * 2;
   return (b + 15) & ~(size_t)15;
 }
 
