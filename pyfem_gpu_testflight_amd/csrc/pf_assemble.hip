@@ -32,76 +32,37 @@ static constexpr int LDS_STRIDE = 65;             // doubles between consecutive
 
 // ------------------------------------------------------------------------------------------
 // element geometry at one quadrature point: det J, grad N (global), N
+//
+// Instruction diet (r02 counters: the assembly kernel is VALU-bound, ~520 VALU instructions per
+// incident element, fp64 issuing at a quarter of the fp32 rate):
+//   * J from the four edge differences of the quad (2 ops per entry instead of 4),
+//   * 1/det and the RAMP quotient by v_rcp_f64 + two Newton steps (5 ops) instead of the IEEE
+//     division expansion (~14 ops); det J is O(h^2), far from the ranges that expansion guards,
+//   * the constitutive matrix is applied once per element, not per quadrature point: the point
+//     loop only accumulates the four sums  S = sum_q s_q grad N_a (x) grad N_b  per coupled node b.
+// Results differ from the reference's einsum order by rounding only (parity bar 1e-10 max|K|).
 // ------------------------------------------------------------------------------------------
 template <int P>
 struct Elem {
   double x[P], y[P];
 };
 
-// quad: 2x2 Gauss, points ordered (-,-),(+,-),(+,+),(-,+)   (pyfem.py:83-94, 262-284)
-// `own` carries what identifies the lane's own local node a without a dynamic register index
-// (hipcc turns a ?: chain over Nx[a] back into a scratch round trip):
-//   quad: (sx, sy) = sign of the node's corner, N_a = (1+sx xi)(1+sy eta)/4
-//   tri : (c0, c1) with gradN_a = c0*row0(invJ) + c1*row1(invJ), and N_a
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// `own` identifies the lane's own local node a without a dynamic register index (hipcc turns a
+// ?: chain over Nx[a] into a scratch round trip):
+//   quad: (s0, s1) = signs of the node's corner:  N_a = (1 + s0 xi)(1 + s1 eta)/4
+//   tri : grad N_a = s0*row0(invJ) + s1*row1(invJ), N_a constant
 struct Own {
   double s0, s1, Na;
   double Nxa, Nya;  // filled per quadrature point
 };
-
-template <int Q>
-__device__ __forceinline__ void quad_point(const Elem<4>& el, Own& own, double& det, double Nx[4], double Ny[4],
-                                           double N[4]) {
-  constexpr double xi = (Q == 0 || Q == 3) ? -GP : GP;
-  constexpr double et = (Q == 0 || Q == 1) ? -GP : GP;
-  constexpr double dxi[4] = {-0.25 * (1.0 - et), 0.25 * (1.0 - et), 0.25 * (1.0 + et), -0.25 * (1.0 + et)};
-  constexpr double det_[4] = {-0.25 * (1.0 - xi), -0.25 * (1.0 + xi), 0.25 * (1.0 + xi), 0.25 * (1.0 - xi)};
-  N[0] = 0.25 * (1.0 - xi) * (1.0 - et);
-  N[1] = 0.25 * (1.0 + xi) * (1.0 - et);
-  N[2] = 0.25 * (1.0 + xi) * (1.0 + et);
-  N[3] = 0.25 * (1.0 - xi) * (1.0 + et);
-  // J[j][k] = sum_l dN[l][k] * X[l][j]      (utils.py:172-185)
-  double J00 = 0, J01 = 0, J10 = 0, J11 = 0;
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {
-    J00 += dxi[l] * el.x[l];
-    J01 += det_[l] * el.x[l];
-    J10 += dxi[l] * el.y[l];
-    J11 += det_[l] * el.y[l];
-  }
-  det = J00 * J11 - J01 * J10;  // utils.py:189-200 (closed form instead of LAPACK LU)
-  const double r = 1.0 / det;
-  const double i00 = J11 * r, i01 = -J01 * r, i10 = -J10 * r, i11 = J00 * r;  // utils.py:244-247
-#pragma unroll
-  for (int l = 0; l < 4; ++l) {  // Ngrad[k][l] = sum_m dN[k][m] invJ[m][l]   (utils.py:263)
-    Nx[l] = dxi[l] * i00 + det_[l] * i10;
-    Ny[l] = dxi[l] * i01 + det_[l] * i11;
-  }
-  const double da = 0.25 * own.s0 * (1.0 + own.s1 * et), db = 0.25 * own.s1 * (1.0 + own.s0 * xi);
-  own.Nxa = da * i00 + db * i10;
-  own.Nya = da * i01 + db * i11;
-  own.Na = 0.25 * (1.0 + own.s0 * xi) * (1.0 + own.s1 * et);
-}
-
-// tri: one point (1/3,1/3); dN = [[1,0],[0,1],[-1,-1]]   (pyfem.py:68-80, 365-377)
-__device__ __forceinline__ void tri_point(const Elem<3>& el, Own& own, double& det, double Nx[3], double Ny[3],
-                                          double N[3]) {
-  N[0] = 1.0 / 3;
-  N[1] = 1.0 / 3;
-  N[2] = 1 - 1.0 / 3 - 1.0 / 3;
-  const double J00 = el.x[0] - el.x[2], J01 = el.x[1] - el.x[2];
-  const double J10 = el.y[0] - el.y[2], J11 = el.y[1] - el.y[2];
-  det = J00 * J11 - J01 * J10;  // NOT |det|: the reference keeps the sign (pyfem.py:78 TODO)
-  const double r = 1.0 / det;
-  const double i00 = J11 * r, i01 = -J01 * r, i10 = -J10 * r, i11 = J00 * r;
-  Nx[0] = i00;
-  Ny[0] = i01;
-  Nx[1] = i10;
-  Ny[1] = i11;
-  Nx[2] = -i00 - i10;
-  Ny[2] = -i01 - i11;
-  own.Nxa = own.s0 * i00 + own.s1 * i10;
-  own.Nya = own.s0 * i01 + own.s1 * i11;
-}
 
 template <int P>
 __device__ __forceinline__ Own make_own(int a) {
@@ -117,6 +78,68 @@ __device__ __forceinline__ Own make_own(int a) {
   }
   o.Nxa = o.Nya = 0.0;
   return o;
+}
+
+// quad: 2x2 Gauss, points ordered (-,-),(+,-),(+,+),(-,+)   (pyfem.py:83-94, 262-284)
+struct QuadEdges {
+  double x10, x23, x30, x21, y10, y23, y30, y21;
+};
+
+__device__ __forceinline__ QuadEdges quad_edges(const Elem<4>& el) {
+  QuadEdges e;
+  e.x10 = el.x[1] - el.x[0]; e.x23 = el.x[2] - el.x[3]; e.x30 = el.x[3] - el.x[0]; e.x21 = el.x[2] - el.x[1];
+  e.y10 = el.y[1] - el.y[0]; e.y23 = el.y[2] - el.y[3]; e.y30 = el.y[3] - el.y[0]; e.y21 = el.y[2] - el.y[1];
+  return e;
+}
+
+template <int Q>
+__device__ __forceinline__ void quad_point(const QuadEdges& ed, Own& own, double& det, double Nx[4], double Ny[4],
+                                           double N[4]) {
+  constexpr double xi = (Q == 0 || Q == 3) ? -GP : GP;
+  constexpr double et = (Q == 0 || Q == 1) ? -GP : GP;
+  // dN/dxi = [-a, a, b, -b], dN/deta = [-c, -d, d, c]                       (pyfem.py:272-283)
+  constexpr double a = 0.25 * (1.0 - et), b = 0.25 * (1.0 + et), c = 0.25 * (1.0 - xi), d = 0.25 * (1.0 + xi);
+  N[0] = 0.25 * (1.0 - xi) * (1.0 - et);
+  N[1] = 0.25 * (1.0 + xi) * (1.0 - et);
+  N[2] = 0.25 * (1.0 + xi) * (1.0 + et);
+  N[3] = 0.25 * (1.0 - xi) * (1.0 + et);
+  // J[j][k] = sum_l dN[l][k] X[l][j]  (utils.py:172-185), regrouped by element edges
+  const double J00 = fma(a, ed.x10, b * ed.x23), J01 = fma(c, ed.x30, d * ed.x21);
+  const double J10 = fma(a, ed.y10, b * ed.y23), J11 = fma(c, ed.y30, d * ed.y21);
+  det = fma(J00, J11, -(J01 * J10));  // utils.py:189-200 (closed form instead of LAPACK LU)
+  const double r = fast_rcp(det);
+  const double i00 = J11 * r, i01 = -(J01 * r), i10 = -(J10 * r), i11 = J00 * r;  // utils.py:244-247
+  // Ngrad[l] = dN[l][0] invJ[0][:] + dN[l][1] invJ[1][:]                    (utils.py:263)
+  const double ax = a * i00, bx = b * i00, cx = c * i10, dx = d * i10;
+  Nx[0] = -ax - cx; Nx[1] = ax - dx; Nx[2] = bx + dx; Nx[3] = cx - bx;
+  const double ay = a * i01, by = b * i01, cy = c * i11, dy = d * i11;
+  Ny[0] = -ay - cy; Ny[1] = ay - dy; Ny[2] = by + dy; Ny[3] = cy - by;
+  const double tx = fma(own.s0, xi, 1.0), ty = fma(own.s1, et, 1.0);
+  const double da = (0.25 * own.s0) * ty, db = (0.25 * own.s1) * tx;
+  own.Nxa = fma(da, i00, db * i10);
+  own.Nya = fma(da, i01, db * i11);
+  own.Na = (0.25 * tx) * ty;
+}
+
+// tri: one point (1/3,1/3); dN = [[1,0],[0,1],[-1,-1]]   (pyfem.py:68-80, 365-377)
+__device__ __forceinline__ void tri_point(const Elem<3>& el, Own& own, double& det, double Nx[3], double Ny[3],
+                                          double N[3]) {
+  N[0] = 1.0 / 3;
+  N[1] = 1.0 / 3;
+  N[2] = 1 - 1.0 / 3 - 1.0 / 3;
+  const double J00 = el.x[0] - el.x[2], J01 = el.x[1] - el.x[2];
+  const double J10 = el.y[0] - el.y[2], J11 = el.y[1] - el.y[2];
+  det = fma(J00, J11, -(J01 * J10));  // NOT |det|: the reference keeps the sign (pyfem.py:78 TODO)
+  const double r = fast_rcp(det);
+  const double i00 = J11 * r, i01 = -(J01 * r), i10 = -(J10 * r), i11 = J00 * r;
+  Nx[0] = i00;
+  Ny[0] = i01;
+  Nx[1] = i10;
+  Ny[1] = i11;
+  Nx[2] = -i00 - i10;
+  Ny[2] = -i01 - i11;
+  own.Nxa = fma(own.s0, i00, own.s1 * i10);
+  own.Nya = fma(own.s0, i01, own.s1 * i11);
 }
 
 template <int P>
@@ -141,8 +164,9 @@ __device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int6
 }
 
 // ------------------------------------------------------------------------------------------
-// physics: rows of Ke that belong to local node `a`
-//   V values per coupled node b
+// physics: rows of Ke that belong to local node `a`;  V values per coupled node b.
+//   point():  accumulate the quadrature sums S (NS per coupled node)
+//   finish(): apply the constant material matrix once
 // ------------------------------------------------------------------------------------------
 struct ElasticityParams {
   double c11, c12, c33, p;     // C0 = E/(1-nu^2) [[1,nu,0],[nu,1,0],[0,0,(1-nu)/2]]  (pyfem.py:1746-1750)
@@ -151,28 +175,37 @@ struct ElasticityParams {
 
 template <int P, bool RHO>
 struct Elasticity {
-  static constexpr int V = 4;  // 2x2 block, row-major
+  static constexpr int V = 4;   // 2x2 block, row-major
+  static constexpr int NS = 4;  // S = [Sxx, Sxy, Syx, Syy],  S_uv = sum_q s dN_a/du dN_b/dv
   using Params = ElasticityParams;
 
   __device__ __forceinline__ static void point(const Params& pr, double det, double w, const double N[P],
                                                const double Nx[P], const double Ny[P], const double rho_e[P],
-                                               const Own& own, double v[P][4]) {
+                                               const Own& own, double S[P][NS]) {
     double s = det * w;
     if constexpr (RHO) {
-      double rq = 0;
+      double rq = N[0] * rho_e[0];
 #pragma unroll
-      for (int l = 0; l < P; ++l) rq += N[l] * rho_e[l];  // utils.py:204-221
-      s *= rq / (1.0 + pr.p * (1.0 - rq));                 // RAMP, pyfem.py:1944
+      for (int l = 1; l < P; ++l) rq = fma(N[l], rho_e[l], rq);  // utils.py:204-221
+      s *= rq * fast_rcp(fma(pr.p, 1.0 - rq, 1.0));              // RAMP, pyfem.py:1944
     }
-    const double ax = s * own.Nxa, ay = s * own.Nya;
-    const double c11x = pr.c11 * ax, c12x = pr.c12 * ax, c33x = pr.c33 * ax;
-    const double c11y = pr.c11 * ay, c12y = pr.c12 * ay, c33y = pr.c33 * ay;
+    const double gx = s * own.Nxa, gy = s * own.Nya;
 #pragma unroll
-    for (int b = 0; b < P; ++b) {  // B_a^T C0 B_b with B = [[Nx,0],[0,Ny],[Ny,Nx]]  (pyfem.py:1992-1997)
-      v[b][0] += c11x * Nx[b] + c33y * Ny[b];
-      v[b][1] += c12x * Ny[b] + c33y * Nx[b];
-      v[b][2] += c12y * Nx[b] + c33x * Ny[b];
-      v[b][3] += c11y * Ny[b] + c33x * Nx[b];
+    for (int b = 0; b < P; ++b) {
+      S[b][0] = fma(gx, Nx[b], S[b][0]);
+      S[b][1] = fma(gx, Ny[b], S[b][1]);
+      S[b][2] = fma(gy, Nx[b], S[b][2]);
+      S[b][3] = fma(gy, Ny[b], S[b][3]);
+    }
+  }
+  // B_a^T C0 B_b with B = [[Nx,0],[0,Ny],[Ny,Nx]]  (pyfem.py:1992-1997, 2016-2027)
+  __device__ __forceinline__ static void finish(const Params& pr, const double S[P][NS], double v[P][V]) {
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      v[b][0] = fma(pr.c11, S[b][0], pr.c33 * S[b][3]);
+      v[b][1] = fma(pr.c12, S[b][1], pr.c33 * S[b][2]);
+      v[b][2] = fma(pr.c12, S[b][2], pr.c33 * S[b][1]);
+      v[b][3] = fma(pr.c11, S[b][3], pr.c33 * S[b][0]);
     }
   }
 };
@@ -184,19 +217,25 @@ struct HelmholtzParams {
 
 template <int P>
 struct Helmholtz {
-  static constexpr int V = 2;  // [K, R]
+  static constexpr int V = 2;   // [K, R]
+  static constexpr int NS = 2;  // [stiffness sum, mass sum]
   using Params = HelmholtzParams;
-  __device__ __forceinline__ static void point(const Params& pr, double det, double w, const double N[P],
+  __device__ __forceinline__ static void point(const Params&, double det, double w, const double N[P],
                                                const double Nx[P], const double Ny[P], const double*, const Own& own,
-                                               double v[P][2]) {
+                                               double S[P][NS]) {
     const double s = det * w;
-    const double na = s * own.Na;
-    const double gx = s * pr.r2 * own.Nxa, gy = s * pr.r2 * own.Nya;
+    const double na = s * own.Na, gx = s * own.Nxa, gy = s * own.Nya;
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      const double m = na * N[b];  // Re, pyfem.py:2134-2136
-      v[b][1] += m;
-      v[b][0] += gx * Nx[b] + gy * Ny[b] + m;  // Ke = r0^2 gradN.gradN + Re, pyfem.py:2127-2131, 2176
+      S[b][0] = fma(gx, Nx[b], fma(gy, Ny[b], S[b][0]));  // pyfem.py:2127-2131
+      S[b][1] = fma(na, N[b], S[b][1]);                   // Re, pyfem.py:2134-2136
+    }
+  }
+  __device__ __forceinline__ static void finish(const Params& pr, const double S[P][NS], double v[P][V]) {
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      v[b][1] = S[b][1];
+      v[b][0] = fma(pr.r2, S[b][0], S[b][1]);  // Ke = r0^2 gradN.gradN + Re, pyfem.py:2176
     }
   }
 };
@@ -205,21 +244,24 @@ struct Helmholtz {
 template <int P, class Phys, bool RHO>
 __device__ __forceinline__ void element_rows_core(const typename Phys::Params& pr, const Elem<P>& el,
                                                   const double rho_e[P], int a, double v[P][Phys::V]) {
+  double S[P][Phys::NS];
 #pragma unroll
   for (int b = 0; b < P; ++b)
 #pragma unroll
-    for (int k = 0; k < Phys::V; ++k) v[b][k] = 0.0;
+    for (int k = 0; k < Phys::NS; ++k) S[b][k] = 0.0;
   double det, Nx[P], Ny[P], N[P];
   Own own = make_own<P>(a);
   if constexpr (P == 4) {
-    quad_point<0>(el, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, v);
-    quad_point<1>(el, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, v);
-    quad_point<2>(el, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, v);
-    quad_point<3>(el, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, v);
+    const QuadEdges ed = quad_edges(el);
+    quad_point<0>(ed, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, S);
+    quad_point<1>(ed, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, S);
+    quad_point<2>(ed, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, S);
+    quad_point<3>(ed, own, det, Nx, Ny, N); Phys::point(pr, det, 1.0, N, Nx, Ny, rho_e, own, S);
   } else {
     tri_point(el, own, det, Nx, Ny, N);
-    Phys::point(pr, det, 0.5, N, Nx, Ny, rho_e, own, v);
+    Phys::point(pr, det, 0.5, N, Nx, Ny, rho_e, own, S);
   }
+  Phys::finish(pr, S, v);
 }
 
 template <int P, class Phys, bool RHO>
