@@ -546,6 +546,184 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
 }
 
 // ------------------------------------------------------------------------------------------
+// GATHER assembly v3 (default): lane = incident (node, element) pair, tile = npt consecutive nodes.
+//
+// The measurements that led here (profiles/r01_*): with lane = node the accumulator tile is
+// 18.7 KB per 64 nodes, which caps a CU at 8 tiles; every tile then pays its dependent load chain,
+// its quadrature and its store drain back to back (phases measured additive: 172 + 132 + 184 us) and
+// boundary/irregular nodes leave lanes idle.  Here
+//   * each lane integrates ONE incident element for one node (perfect load balance for any
+//     valence); a tile is the npt nodes (16 for quads) whose <= 64 incident pairs fill the wave;
+//   * the tile's rows are ONE contiguous segment of the value array, and the LDS accumulator is an
+//     exact image of that segment (4.6 KB for quads): contributions go in with LDS fp64 atomic adds
+//     at (row offset + position byte), the write-out is a straight 16-byte-per-lane copy -- no maps,
+//     no barriers, 4x less LDS per wave than v1/v2;
+//   * waves are persistent and software-pipelined: row pointers two tiles ahead, the visit records
+//     one tile ahead, the coordinate gathers of the next tile in flight during the quadrature of the
+//     current one.  Every wait targets loads that were issued BEFORE the latest stores (vmcnt retires
+//     in issue order, stores included), so the store drain of tile t overlaps the work of tile t+1.
+// Summation order inside a tile is fixed by the instruction stream (same lanes, same addresses every
+// run), so results are bitwise reproducible although the adds are LDS atomics.
+// dynamic LDS: double2 img[npt*maxrow*V/2]
+// ------------------------------------------------------------------------------------------
+template <int P, bool RHO>
+struct V3Visit {   // everything a lane needs to integrate its incident pair
+  Elem<P> el;
+  double rho_e[P];
+  uint32_t pk;     // position bytes
+  int32_t roff;    // first block of the lane's node inside the tile segment
+  int a;           // local index of the lane's node in the element
+  bool active;
+};
+
+template <int P, class Phys, bool RHO, int ABL = 0>
+__global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt, int32_t maxrow,
+                                                    const double* __restrict__ X,
+                                                    const int32_t* __restrict__ nptr,
+                                                    const int32_t* __restrict__ n2e_ptr,
+                                                    const int4* __restrict__ vis_nd,
+                                                    const uint32_t* __restrict__ vis_pos,
+                                                    const uint8_t* __restrict__ vis_ln,
+                                                    typename Phys::Params pr, double* __restrict__ out0,
+                                                    double* __restrict__ out1) {
+  constexpr int V = Phys::V;
+  constexpr int VH = V / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* const img = reinterpret_cast<double2*>(smem);
+
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (nnodes + npt - 1) / npt;
+  const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+  if (t0 >= t1) return;
+
+  // ---- stage A: row pointers of a tile (lanes 0..npt hold entry n0+lane) ------------------------
+  struct PtrsA {
+    int32_t rp, vp;
+  };
+  auto load_A = [&](int64_t t) __attribute__((always_inline)) {
+    PtrsA A;
+    A.rp = 0;
+    A.vp = 0;
+    if (t < t1) {
+      const int64_t n = min(t * npt + lane, nnodes);
+      if (lane <= npt) {
+        A.rp = nptr[n];
+        A.vp = n2e_ptr[n];
+      }
+    }
+    return A;
+  };
+  // ---- stage B: the lane's visit record ------------------------------------------------------------
+  struct RecB {
+    int4 nd;
+    uint32_t pk;
+    uint32_t lnb;
+    bool active;
+  };
+  auto load_B = [&](int64_t t, const PtrsA& A) __attribute__((always_inline)) {
+    RecB B;
+    B.nd = make_int4(0, 0, 0, 0);
+    B.pk = 0;
+    B.lnb = 0;
+    B.active = false;
+    if (t < t1) {
+      const int nn = (int)min((int64_t)npt, nnodes - t * npt);
+      const int32_t vb = __shfl(A.vp, 0), ve = __shfl(A.vp, nn);
+      const int32_t jj = vb + lane;
+      B.active = jj < ve;
+      if (B.active) {
+        B.nd = vis_nd[jj];
+        B.pk = vis_pos[jj];
+        B.lnb = vis_ln[jj];
+      }
+    }
+    return B;
+  };
+  // ---- stage C: coordinate (density) gathers + row offset -------------------------------------------
+  auto load_C = [&](const RecB& B, const PtrsA& A) __attribute__((always_inline)) {
+    V3Visit<P, RHO> C;
+    C.pk = B.pk;
+    C.a = (int)(B.lnb >> 4);
+    C.active = B.active;
+    C.roff = __shfl(A.rp, (int)(B.lnb & 15)) - __shfl(A.rp, 0);
+    const int32_t nd[4] = {B.nd.x, B.nd.y, B.nd.z, B.nd.w};  // zeros when inactive: in-range loads
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      const double2 xy = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[b]);
+      C.el.x[b] = xy.x;
+      C.el.y[b] = xy.y;
+      if constexpr (RHO) C.rho_e[b] = pr.rho[nd[b]]; else C.rho_e[b] = 1.0;
+    }
+    return C;
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------
+  PtrsA A0 = load_A(t0);        // tile t
+  PtrsA A1 = load_A(t0 + 1);    // tile t+1
+  PtrsA A2 = load_A(t0 + 2);    // tile t+2
+  RecB B0 = load_B(t0, A0);
+  RecB B1 = load_B(t0 + 1, A1);
+  V3Visit<P, RHO> C0 = load_C(B0, A0);
+
+  for (int64_t t = t0; t < t1; ++t) {
+    // tile scalars of the current tile
+    const int nn = (int)min((int64_t)npt, nnodes - t * npt);
+    const int32_t base = __shfl(A0.rp, 0);
+    const int32_t npieces = (__shfl(A0.rp, nn) - base) * VH;
+
+    // 1. coordinates of tile t+1 (its record arrived during the previous iteration)
+    V3Visit<P, RHO> C1 = load_C(B1, A1);
+    // 2. record of tile t+2, row pointers of tile t+3
+    RecB B2 = load_B(t + 2, A2);
+    PtrsA A3 = load_A(t + 3);
+
+    // 3. zero the image of this tile's segment (the previous tile's copy-out reads are complete:
+    //    one wave, LDS executes in order)
+    for (int32_t q = lane; q < npieces; q += 64) img[q] = make_double2(0.0, 0.0);
+
+    // 4. quadrature of the lane's incident element, rows of its node only
+    if (C0.active) {
+      double v[P][V];
+      if constexpr (ABL & 1) {
+#pragma unroll
+        for (int b = 0; b < P; ++b)
+#pragma unroll
+          for (int k = 0; k < V; ++k) v[b][k] = C0.el.x[b] + (double)(k + C0.a);
+      } else {
+        element_rows_core<P, Phys, RHO>(pr, C0.el, C0.rho_e, C0.a, v);
+      }
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        const int blk = C0.roff + (int)((C0.pk >> (8 * b)) & 255);
+        double* slot = reinterpret_cast<double*>(img + (size_t)blk * VH);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          __hip_atomic_fetch_add(slot + k, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+
+    // 5. copy the finished segment out: 16 bytes per lane, 1 KiB contiguous per wave store
+    {
+      const int32_t np = (ABL & 4) ? min(npieces, 1) : npieces;
+      if constexpr (V == 4) {
+        double2* dst = reinterpret_cast<double2*>(out0) + 2 * (int64_t)base;
+        for (int32_t q = lane; q < np; q += 64) dst[q] = img[q];
+      } else {
+        for (int32_t q = lane; q < np; q += 64) {
+          const double2 kr = img[q];
+          if (out0) out0[(int64_t)base + q] = kr.x;
+          if (out1) out1[(int64_t)base + q] = kr.y;
+        }
+      }
+    }
+    // 6. rotate the pipeline
+    A0 = A1; A1 = A2; A2 = A3;
+    B1 = B2;
+    C0 = C1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // GATHER assembly: one workgroup of NW waves per 64 consecutive nodes.
 //   lane  = node (owns the node's d rows of K)
 //   wave w handles incident elements w, w+NW, ... of every node of the tile, so the dependent
@@ -801,7 +979,30 @@ static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* o
 template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   const char* impl = getenv("PF_GATHER_IMPL");
-  if (impl && impl[0] == 'l') return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
+  if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
+  if (!(impl && impl[0] == 'v' && impl[1] == '2')) {  // default: v3
+    const size_t lds3 = (((size_t)ctx->npt * ctx->max_row_blocks * Phys::V * 8) + 15) & ~(size_t)15;
+    auto k3 = k_assemble_v3<P, Phys, RHO, 0>;
+    if constexpr (P == 4 && Phys::V == 4 && !RHO) {
+      const char* ab = getenv("PF_ABLATE");
+      const int abl = ab ? atoi(ab) : 0;
+      if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 1>;
+      else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 4>;
+      else if (abl == 5) k3 = k_assemble_v3<P, Phys, RHO, 5>;
+    }
+    if (lds3 > 48 * 1024)
+      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    const int64_t nt = cdiv(ctx->nnodes, ctx->npt);
+    int wpc = 12;
+    const char* g3 = getenv("PF_GATHER_WAVES_PER_CU");
+    if (g3 && atoi(g3) > 0) wpc = atoi(g3);
+    const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
+    hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->npt, ctx->max_row_blocks, ctx->X,
+                       ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_nd),
+                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_ln, pr, out0, out1);
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
   const size_t lds = v2_lds_bytes(ctx->max_row_blocks, ctx->max_valence, Phys::V, RHO);
   if (lds > 160 * 1024)
     return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");

@@ -130,6 +130,28 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
   }
 }
 
+// visit-ordered element records for the assembly kernel: for the j-th incident pair of node n
+// (global index jj) the element's node ids and  (n mod npt) | a<<4
+template <int P>
+__global__ void k_build_visits(int64_t nnodes, int npt, const int32_t* __restrict__ conn,
+                               const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                               int4* __restrict__ vis_nd, uint8_t* __restrict__ vis_ln) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int32_t ea = n2e[jj];
+    const int32_t e = ea / P;
+    const int a = ea - e * P;
+    int4 nd;
+    nd.x = conn[(int64_t)e * P + 0];
+    nd.y = conn[(int64_t)e * P + 1];
+    nd.z = conn[(int64_t)e * P + 2];
+    nd.w = (P == 4) ? conn[(int64_t)e * P + (P - 1)] : 0;
+    vis_nd[jj] = nd;
+    vis_ln[jj] = (uint8_t)((n & (npt - 1)) | (a << 4));
+  }
+}
+
 // position of conn[e,b] in the row of conn[e,a]  (atomic-scatter mode only)
 template <int P>
 __global__ void k_e2pos(int64_t nelems, const int32_t* __restrict__ conn, const int32_t* __restrict__ nptr,
@@ -207,6 +229,9 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->n2e_pos);
   pf_free(ctx->diagpos);
   pf_free(ctx->e2pos);
+  pf_free(ctx->vis_nd);
+  pf_free(ctx->vis_ln);
+  ctx->npt = 0;
   ctx->d = 0;
   ctx->nblocks = 0;
   return PF_OK;
@@ -360,6 +385,18 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     return rc;
   }
   PF_REQUIRE((int64_t)d * d * ctx->nblocks < ((int64_t)1 << 31), "pf_pattern_build: nnz exceeds int32 (scipy CSR index type)");
+  // nodes per assembly tile: a tile's incident pairs must fit one wave (64 lanes)
+  ctx->npt = ctx->max_valence <= 4 ? 16 : ctx->max_valence <= 8 ? 8 : ctx->max_valence <= 16 ? 4
+           : ctx->max_valence <= 32 ? 2 : ctx->max_valence <= 64 ? 1 : 0;
+  if (ctx->npt) {
+    PF_HIP(hipMalloc(&ctx->vis_nd, sizeof(int4) * (size_t)total));
+    PF_HIP(hipMalloc(&ctx->vis_ln, (size_t)total));
+    if (ctx->P == 4)
+      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_ln);
+    else
+      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_ln);
+    PF_LAUNCH_CHECK();
+  }
   ctx->d = d;
   return PF_OK;
 }
