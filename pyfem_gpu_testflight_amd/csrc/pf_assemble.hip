@@ -566,161 +566,201 @@ __global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxr
 // run), so results are bitwise reproducible although the adds are LDS atomics.
 // dynamic LDS: double2 img[npt*maxrow*V/2]
 // ------------------------------------------------------------------------------------------
-template <int P, bool RHO>
-struct V3Visit {   // everything a lane needs to integrate its incident pair
-  Elem<P> el;
-  double rho_e[P];
-  uint32_t pk;     // position bytes
-  int32_t roff;    // first block of the lane's node inside the tile segment
-  int a;           // local index of the lane's node in the element
+struct V3Rec {        // stage B: the lane's visit record (one tile ahead)
+  int4 nd;            // node ids of the incident element
+  uint32_t pk;        // position bytes of those nodes in the lane's row
+  uint32_t meta;      // row offset inside the tile | a << 16
   bool active;
 };
 
-template <int P, class Phys, bool RHO, int ABL = 0>
+template <int P, bool RHO>
+struct V3Visit {      // stage C: what the quadrature needs (gathers in flight during the previous tile)
+  Elem<P> el;
+  double rho_e[P];
+  uint32_t pk, meta;
+  bool active;
+};
+
+struct V3Tile {       // wave-uniform tile scalars (scalar loads, two tiles ahead)
+  int32_t vb, ve, base, nblk;
+};
+
+// NOTE: the pipeline stages are free __forceinline__ functions, not lambdas: hipcc keeps local arrays of
+// a lambda that is inlined at two call sites in scratch memory (seen twice in this file's history).
+
+// All prefetch loads are UNCONDITIONAL with clamped indices: a load under `if (active)` that is merged
+// with a default at the join makes hipcc wait for it on the spot (s_waitcnt vmcnt right behind the
+// issue), which exposes a full memory latency per tile.
+__device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, int32_t npt, int64_t nnodes,
+                                               const int32_t* __restrict__ nptr,
+                                               const int32_t* __restrict__ n2e_ptr) {  // uniform -> s_load
+  V3Tile T;
+  const int64_t tc = min(t, t1 - 1);
+  const int64_t na = tc * npt, nb = min(na + npt, nnodes);
+  T.vb = n2e_ptr[na];
+  T.ve = (t < t1) ? n2e_ptr[nb] : T.vb;
+  T.base = nptr[na];
+  T.nblk = nptr[nb] - T.base;
+  return T;
+}
+
+__device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t nvis,
+                                             const int4* __restrict__ vis_nd, const uint32_t* __restrict__ vis_pos,
+                                             const uint32_t* __restrict__ vis_meta) {
+  V3Rec B;
+  const int32_t jj = T.vb + lane;
+  B.active = jj < T.ve;
+  const int32_t jc = min(jj, nvis - 1);
+  B.nd = vis_nd[jc];
+  B.pk = vis_pos[jc];
+  B.meta = vis_meta[jc];
+  return B;
+}
+
+template <int P, bool RHO>
+__device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __restrict__ X,
+                                              const double* __restrict__ rho, V3Visit<P, RHO>& C) {
+  C.pk = B.pk;
+  C.meta = B.meta;
+  C.active = B.active;
+  const double2 p0 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.x);
+  const double2 p1 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.y);
+  const double2 p2 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.z);
+  C.el.x[0] = p0.x; C.el.y[0] = p0.y;
+  C.el.x[1] = p1.x; C.el.y[1] = p1.y;
+  C.el.x[2] = p2.x; C.el.y[2] = p2.y;
+  if constexpr (P == 4) {
+    const double2 p3 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.w);
+    C.el.x[3] = p3.x; C.el.y[3] = p3.y;
+  }
+  if constexpr (RHO) {
+    C.rho_e[0] = rho[B.nd.x];
+    C.rho_e[1] = rho[B.nd.y];
+    C.rho_e[2] = rho[B.nd.z];
+    if constexpr (P == 4) C.rho_e[3] = rho[B.nd.w];
+  } else {
+#pragma unroll
+    for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
+  }
+}
+
+// integrate tile Tcur from Cuse into the LDS image and copy the finished segment out
+template <int P, class Phys, bool RHO, int NOUT, int ABL>
+__device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V3Tile& Tcur,
+                                        const V3Visit<P, RHO>& Cuse, double2* img, int lane,
+                                        double* __restrict__ out0, double* __restrict__ out1,
+                                        double* __restrict__ trash) {
+  constexpr int V = Phys::V;
+  constexpr int VH = V / 2;
+  const int32_t npieces = Tcur.nblk * VH;
+  // zero the image of this tile's segment (the previous tile's copy-out reads are complete: one wave,
+  // LDS executes in order)
+  for (int32_t q = lane; q < npieces; q += 64) img[q] = make_double2(0.0, 0.0);
+
+  if (Cuse.active) {
+    const int a = (int)(Cuse.meta >> 16);
+    const int roff = (int)(Cuse.meta & 0xffff);
+    double v[P][V];
+    if constexpr (ABL & 1) {
+#pragma unroll
+      for (int b = 0; b < P; ++b)
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[b][k] = Cuse.el.x[b] + (double)(k + a);
+    } else {
+      element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, a, v);
+    }
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      const int blk = roff + (int)((Cuse.pk >> (8 * b)) & 255);
+      double* slot = reinterpret_cast<double*>(img + (size_t)blk * VH);
+#pragma unroll
+      for (int k = 0; k < V; ++k)
+        __hip_atomic_fetch_add(slot + k, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+
+  // copy-out: 16 bytes per lane, 1 KiB contiguous per wave store.  NOUT > 0: fixed, fully unrolled
+  // piece count -- a store LOOP of unknown trip count makes hipcc flush vmcnt to 0 in front of it
+  // (seen in the ISA), i.e. wait for the prefetches that were just issued.
+  const int32_t np = (ABL & 4) ? min(npieces, 1) : npieces;
+  const int64_t base = Tcur.base;
+  if constexpr (NOUT > 0) {
+    // STATIC store count: pieces past the end are clamped to the last piece (the same 16 bytes are
+    // rewritten with the same value).  With a data-dependent number of stores hipcc cannot count what is
+    // in flight behind a prefetch and falls back to s_waitcnt vmcnt(0) -- i.e. to draining the stores.
+    // (a tile of isolated nodes has no blocks: its stores go to a trash line instead of a branch)
+    const bool any = np > 0;
+    double2* d4 = any ? reinterpret_cast<double2*>(out0) + 2 * base : reinterpret_cast<double2*>(trash);
+    double* d0 = any ? out0 + base : trash;
+    double* d1 = any ? out1 + base : trash + 1;
+#pragma unroll
+    for (int u = 0; u < NOUT; ++u) {
+      const int32_t q = any ? min(lane + 64 * u, np - 1) : 0;
+      const double2 val = img[q];
+      if constexpr (V == 4) {
+        d4[q] = val;
+      } else {
+        d0[q] = val.x;
+        d1[q] = val.y;
+      }
+    }
+  } else {
+    for (int32_t q = lane; q < np; q += 64) {
+      const double2 val = img[q];
+      if constexpr (V == 4) {
+        (reinterpret_cast<double2*>(out0) + 2 * base)[q] = val;
+      } else {
+        if (out0) out0[base + q] = val.x;
+        if (out1) out1[base + q] = val.y;
+      }
+    }
+  }
+}
+
+template <int P, class Phys, bool RHO, int NOUT, int ABL = 0>
 __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int32_t* __restrict__ n2e_ptr,
                                                     const int4* __restrict__ vis_nd,
                                                     const uint32_t* __restrict__ vis_pos,
-                                                    const uint8_t* __restrict__ vis_ln,
+                                                    const uint32_t* __restrict__ vis_meta, int32_t nvis,
                                                     typename Phys::Params pr, double* __restrict__ out0,
-                                                    double* __restrict__ out1) {
-  constexpr int V = Phys::V;
-  constexpr int VH = V / 2;
+                                                    double* __restrict__ out1, double* __restrict__ trash) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* const img = reinterpret_cast<double2*>(smem);
-
   const int lane = threadIdx.x;
   const int64_t ntiles = (nnodes + npt - 1) / npt;
   const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
 
-  // ---- stage A: row pointers of a tile (lanes 0..npt hold entry n0+lane) ------------------------
-  struct PtrsA {
-    int32_t rp, vp;
-  };
-  auto load_A = [&](int64_t t) __attribute__((always_inline)) {
-    PtrsA A;
-    A.rp = 0;
-    A.vp = 0;
-    if (t < t1) {
-      const int64_t n = min(t * npt + lane, nnodes);
-      if (lane <= npt) {
-        A.rp = nptr[n];
-        A.vp = n2e_ptr[n];
-      }
-    }
-    return A;
-  };
-  // ---- stage B: the lane's visit record ------------------------------------------------------------
-  struct RecB {
-    int4 nd;
-    uint32_t pk;
-    uint32_t lnb;
-    bool active;
-  };
-  auto load_B = [&](int64_t t, const PtrsA& A) __attribute__((always_inline)) {
-    RecB B;
-    B.nd = make_int4(0, 0, 0, 0);
-    B.pk = 0;
-    B.lnb = 0;
-    B.active = false;
-    if (t < t1) {
-      const int nn = (int)min((int64_t)npt, nnodes - t * npt);
-      const int32_t vb = __shfl(A.vp, 0), ve = __shfl(A.vp, nn);
-      const int32_t jj = vb + lane;
-      B.active = jj < ve;
-      if (B.active) {
-        B.nd = vis_nd[jj];
-        B.pk = vis_pos[jj];
-        B.lnb = vis_ln[jj];
-      }
-    }
-    return B;
-  };
-  // ---- stage C: coordinate (density) gathers + row offset -------------------------------------------
-  auto load_C = [&](const RecB& B, const PtrsA& A) __attribute__((always_inline)) {
-    V3Visit<P, RHO> C;
-    C.pk = B.pk;
-    C.a = (int)(B.lnb >> 4);
-    C.active = B.active;
-    C.roff = __shfl(A.rp, (int)(B.lnb & 15)) - __shfl(A.rp, 0);
-    const int32_t nd[4] = {B.nd.x, B.nd.y, B.nd.z, B.nd.w};  // zeros when inactive: in-range loads
-#pragma unroll
-    for (int b = 0; b < P; ++b) {
-      const double2 xy = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[b]);
-      C.el.x[b] = xy.x;
-      C.el.y[b] = xy.y;
-      if constexpr (RHO) C.rho_e[b] = pr.rho[nd[b]]; else C.rho_e[b] = 1.0;
-    }
-    return C;
-  };
+  // Pipeline state.  Two register sets (a/b) are used on alternate tiles, so nothing a load is about to
+  // write is ever copied: a rotation by copy would have to wait for the loads just issued.
+  V3Tile T0 = v3_load_tile(t0, t1, npt, nnodes, nptr, n2e_ptr);
+  V3Tile T1 = v3_load_tile(t0 + 1, t1, npt, nnodes, nptr, n2e_ptr);
+  V3Tile T2 = v3_load_tile(t0 + 2, t1, npt, nnodes, nptr, n2e_ptr);
+  V3Rec Ba = v3_load_rec(T0, lane, nvis, vis_nd, vis_pos, vis_meta);
+  V3Rec Bb = v3_load_rec(T1, lane, nvis, vis_nd, vis_pos, vis_meta);
+  V3Visit<P, RHO> Ca, Cb;
+  v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
 
-  // ---- prologue ----------------------------------------------------------------------------------------
-  PtrsA A0 = load_A(t0);        // tile t
-  PtrsA A1 = load_A(t0 + 1);    // tile t+1
-  PtrsA A2 = load_A(t0 + 2);    // tile t+2
-  RecB B0 = load_B(t0, A0);
-  RecB B1 = load_B(t0 + 1, A1);
-  V3Visit<P, RHO> C0 = load_C(B0, A0);
-
-  for (int64_t t = t0; t < t1; ++t) {
-    // tile scalars of the current tile
-    const int nn = (int)min((int64_t)npt, nnodes - t * npt);
-    const int32_t base = __shfl(A0.rp, 0);
-    const int32_t npieces = (__shfl(A0.rp, nn) - base) * VH;
-
-    // 1. coordinates of tile t+1 (its record arrived during the previous iteration)
-    V3Visit<P, RHO> C1 = load_C(B1, A1);
-    // 2. record of tile t+2, row pointers of tile t+3
-    RecB B2 = load_B(t + 2, A2);
-    PtrsA A3 = load_A(t + 3);
-
-    // 3. zero the image of this tile's segment (the previous tile's copy-out reads are complete:
-    //    one wave, LDS executes in order)
-    for (int32_t q = lane; q < npieces; q += 64) img[q] = make_double2(0.0, 0.0);
-
-    // 4. quadrature of the lane's incident element, rows of its node only
-    if (C0.active) {
-      double v[P][V];
-      if constexpr (ABL & 1) {
-#pragma unroll
-        for (int b = 0; b < P; ++b)
-#pragma unroll
-          for (int k = 0; k < V; ++k) v[b][k] = C0.el.x[b] + (double)(k + C0.a);
-      } else {
-        element_rows_core<P, Phys, RHO>(pr, C0.el, C0.rho_e, C0.a, v);
-      }
-#pragma unroll
-      for (int b = 0; b < P; ++b) {
-        const int blk = C0.roff + (int)((C0.pk >> (8 * b)) & 255);
-        double* slot = reinterpret_cast<double*>(img + (size_t)blk * VH);
-#pragma unroll
-        for (int k = 0; k < V; ++k)
-          __hip_atomic_fetch_add(slot + k, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-    }
-
-    // 5. copy the finished segment out: 16 bytes per lane, 1 KiB contiguous per wave store
-    {
-      const int32_t np = (ABL & 4) ? min(npieces, 1) : npieces;
-      if constexpr (V == 4) {
-        double2* dst = reinterpret_cast<double2*>(out0) + 2 * (int64_t)base;
-        for (int32_t q = lane; q < np; q += 64) dst[q] = img[q];
-      } else {
-        for (int32_t q = lane; q < np; q += 64) {
-          const double2 kr = img[q];
-          if (out0) out0[(int64_t)base + q] = kr.x;
-          if (out1) out1[(int64_t)base + q] = kr.y;
-        }
-      }
-    }
-    // 6. rotate the pipeline
-    A0 = A1; A1 = A2; A2 = A3;
-    B1 = B2;
-    C0 = C1;
+  // steady state: two tiles per trip, both always executed (a conditional second half gives the
+  // back edge two different in-flight counts and hipcc falls back to vmcnt(0) at the loop top)
+  int64_t t = t0;
+  for (; t + 1 < t1; t += 2) {
+    // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
+    const V3Tile T3 = v3_load_tile(t + 3, t1, npt, nnodes, nptr, n2e_ptr);
+    v3_load_visit<P, RHO>(Bb, X, pr.rho, Cb);
+    Ba = v3_load_rec(T2, lane, nvis, vis_nd, vis_pos, vis_meta);
+    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, lane, out0, out1, trash);
+    // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
+    const V3Tile T4 = v3_load_tile(t + 4, t1, npt, nnodes, nptr, n2e_ptr);
+    v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
+    Bb = v3_load_rec(T3, lane, nvis, vis_nd, vis_pos, vis_meta);
+    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, lane, out0, out1, trash);
+    T0 = T2; T1 = T3; T2 = T4;
   }
+  if (t < t1) v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, lane, out0, out1, trash);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -982,13 +1022,20 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
   if (!(impl && impl[0] == 'v' && impl[1] == '2')) {  // default: v3
     const size_t lds3 = (((size_t)ctx->npt * ctx->max_row_blocks * Phys::V * 8) + 15) & ~(size_t)15;
-    auto k3 = k_assemble_v3<P, Phys, RHO, 0>;
-    if constexpr (P == 4 && Phys::V == 4 && !RHO) {
-      const char* ab = getenv("PF_ABLATE");
-      const int abl = ab ? atoi(ab) : 0;
-      if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 1>;
-      else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 4>;
-      else if (abl == 5) k3 = k_assemble_v3<P, Phys, RHO, 5>;
+    const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V / 2), 64);
+    const char* ab = getenv("PF_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+    auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;
+    const bool both = (Phys::V == 4) || (out0 && out1);
+    if (per_lane <= 5 && both) {
+      k3 = k_assemble_v3<P, Phys, RHO, 5, 0>;
+      if constexpr (P == 4 && Phys::V == 4 && !RHO) {
+        if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 5, 1>;
+        else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 5, 4>;
+        else if (abl == 5) k3 = k_assemble_v3<P, Phys, RHO, 5, 5>;
+      }
+    } else if (per_lane <= 10 && both) {
+      k3 = k_assemble_v3<P, Phys, RHO, 10, 0>;
     }
     if (lds3 > 48 * 1024)
       PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
@@ -999,7 +1046,8 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
     hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->npt, ctx->max_row_blocks, ctx->X,
                        ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_nd),
-                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_ln, pr, out0, out1);
+                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_meta, (int32_t)(ctx->nelems * ctx->P), pr, out0, out1,
+                       ctx->scal + (size_t)PF_NPART * (PF_NPART_ARRAYS - 1) + PF_NPART - 8);
     PF_LAUNCH_CHECK();
     return PF_OK;
   }

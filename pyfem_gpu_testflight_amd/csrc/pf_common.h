@@ -35,7 +35,7 @@ struct pf_ctx {
                                //   position of conn[e,b] in row n of the node graph
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   void* vis_nd = nullptr;      // (nelems*P) int4: node ids of the element of incident pair jj (visit order)
-  uint8_t* vis_ln = nullptr;   // (nelems*P) (node mod npt) | local index a << 4
+  uint32_t* vis_meta = nullptr;  // (nelems*P) row offset of the pair's node inside its tile | local index a << 16
   int npt = 0;                 // nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 

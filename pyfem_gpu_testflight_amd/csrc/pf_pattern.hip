@@ -131,24 +131,27 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
 }
 
 // visit-ordered element records for the assembly kernel: for the j-th incident pair of node n
-// (global index jj) the element's node ids and  (n mod npt) | a<<4
+// (global index jj) the element's node ids and  meta = roff | a<<16, where roff is the first block
+// of node n's row relative to the first row of its npt-node tile and a the local index of n
 template <int P>
 __global__ void k_build_visits(int64_t nnodes, int npt, const int32_t* __restrict__ conn,
-                               const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
-                               int4* __restrict__ vis_nd, uint8_t* __restrict__ vis_ln) {
+                               const int32_t* __restrict__ nptr, const int32_t* __restrict__ n2e_ptr,
+                               const int32_t* __restrict__ n2e, int4* __restrict__ vis_nd,
+                               uint32_t* __restrict__ vis_meta) {
   int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (n >= nnodes) return;
+  const uint32_t roff = (uint32_t)(nptr[n] - nptr[(n / npt) * npt]);
   for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
     const int32_t ea = n2e[jj];
     const int32_t e = ea / P;
-    const int a = ea - e * P;
+    const uint32_t a = (uint32_t)(ea - e * P);
     int4 nd;
     nd.x = conn[(int64_t)e * P + 0];
     nd.y = conn[(int64_t)e * P + 1];
     nd.z = conn[(int64_t)e * P + 2];
     nd.w = (P == 4) ? conn[(int64_t)e * P + (P - 1)] : 0;
     vis_nd[jj] = nd;
-    vis_ln[jj] = (uint8_t)((n & (npt - 1)) | (a << 4));
+    vis_meta[jj] = roff | (a << 16);
   }
 }
 
@@ -230,7 +233,7 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->diagpos);
   pf_free(ctx->e2pos);
   pf_free(ctx->vis_nd);
-  pf_free(ctx->vis_ln);
+  pf_free(ctx->vis_meta);
   ctx->npt = 0;
   ctx->d = 0;
   ctx->nblocks = 0;
@@ -390,11 +393,11 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
            : ctx->max_valence <= 32 ? 2 : ctx->max_valence <= 64 ? 1 : 0;
   if (ctx->npt) {
     PF_HIP(hipMalloc(&ctx->vis_nd, sizeof(int4) * (size_t)total));
-    PF_HIP(hipMalloc(&ctx->vis_ln, (size_t)total));
+    PF_HIP(hipMalloc(&ctx->vis_meta, sizeof(uint32_t) * (size_t)total));
     if (ctx->P == 4)
-      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_ln);
+      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_meta);
     else
-      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_ln);
+      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_meta);
     PF_LAUNCH_CHECK();
   }
   ctx->d = d;

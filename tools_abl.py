@@ -19,7 +19,7 @@ rho = torch.rand(h.nnodes, dtype=torch.float64, device="cuda") * 0.5 + 0.5
 def t(label, in0=None, p=0.0):
     ms = h.time_kernel(_lib.PF_K_ASSEMBLE_ELASTICITY, 20, in0=in0, out0=K.vals, E=10.0, nu=0.3, p=p)
     print(f"  {label}: {ms*1e3:8.1f} us", flush=True)
-for wpc in ["8", "12", "16", "24", "32"]:
+for wpc in ["8", "12", "16", "24"]:
     os.environ["PF_GATHER_WAVES_PER_CU"] = wpc
     for abl in [0, 1, 4, 5]:
         os.environ["PF_ABLATE"] = str(abl)
