@@ -644,18 +644,23 @@ __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __re
   }
 }
 
-// integrate tile Tcur from Cuse into the LDS image and copy the finished segment out
+// integrate tile Tcur from Cuse into the LDS image and copy the finished segment out.
+// Image layout: V planes of `plane` doubles, value k of the tile's block B at img[k*plane + B].  With the
+// blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
+// 8 of the 32 banks (r03 counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
+// touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
 template <int P, class Phys, bool RHO, int NOUT, int ABL>
 __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V3Tile& Tcur,
-                                        const V3Visit<P, RHO>& Cuse, double2* img, int lane,
+                                        const V3Visit<P, RHO>& Cuse, double* img, int plane, int lane,
                                         double* __restrict__ out0, double* __restrict__ out1,
                                         double* __restrict__ trash) {
   constexpr int V = Phys::V;
   constexpr int VH = V / 2;
-  const int32_t npieces = Tcur.nblk * VH;
-  // zero the image of this tile's segment (the previous tile's copy-out reads are complete: one wave,
-  // LDS executes in order)
-  for (int32_t q = lane; q < npieces; q += 64) img[q] = make_double2(0.0, 0.0);
+  const int32_t nblk = Tcur.nblk;
+  // zero the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
+#pragma unroll
+  for (int k = 0; k < V; ++k)
+    for (int32_t q = lane; q < nblk; q += 64) img[k * plane + q] = 0.0;
 
   if (Cuse.active) {
     const int a = (int)(Cuse.meta >> 16);
@@ -672,46 +677,43 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       const int blk = roff + (int)((Cuse.pk >> (8 * b)) & 255);
-      double* slot = reinterpret_cast<double*>(img + (size_t)blk * VH);
 #pragma unroll
       for (int k = 0; k < V; ++k)
-        __hip_atomic_fetch_add(slot + k, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
 
-  // copy-out: 16 bytes per lane, 1 KiB contiguous per wave store.  NOUT > 0: fixed, fully unrolled
-  // piece count -- a store LOOP of unknown trip count makes hipcc flush vmcnt to 0 in front of it
-  // (seen in the ISA), i.e. wait for the prefetches that were just issued.
-  const int32_t np = (ABL & 4) ? min(npieces, 1) : npieces;
+  // copy-out: 16 bytes per lane, 1 KiB contiguous per wave store.  STATIC store count (NOUT > 0): pieces
+  // past the end are clamped to the last piece (the same 16 bytes rewritten with the same value); with a
+  // data-dependent number of stores hipcc cannot count what is in flight behind a prefetch and falls back
+  // to s_waitcnt vmcnt(0), i.e. to draining the stores.  A tile of isolated nodes has no blocks: its
+  // stores go to a trash line instead of a branch.
+  const int32_t np = ((ABL & 4) ? min(nblk, 1) : nblk) * VH;
   const int64_t base = Tcur.base;
+  const bool any = np > 0;
+  double2* d4 = any ? reinterpret_cast<double2*>(out0) + 2 * base : reinterpret_cast<double2*>(trash);
+  double* d0 = any ? out0 + base : trash;
+  double* d1 = any ? out1 + base : trash + 1;
   if constexpr (NOUT > 0) {
-    // STATIC store count: pieces past the end are clamped to the last piece (the same 16 bytes are
-    // rewritten with the same value).  With a data-dependent number of stores hipcc cannot count what is
-    // in flight behind a prefetch and falls back to s_waitcnt vmcnt(0) -- i.e. to draining the stores.
-    // (a tile of isolated nodes has no blocks: its stores go to a trash line instead of a branch)
-    const bool any = np > 0;
-    double2* d4 = any ? reinterpret_cast<double2*>(out0) + 2 * base : reinterpret_cast<double2*>(trash);
-    double* d0 = any ? out0 + base : trash;
-    double* d1 = any ? out1 + base : trash + 1;
 #pragma unroll
     for (int u = 0; u < NOUT; ++u) {
       const int32_t q = any ? min(lane + 64 * u, np - 1) : 0;
-      const double2 val = img[q];
       if constexpr (V == 4) {
-        d4[q] = val;
+        const int32_t tb = q >> 1, h2 = (q & 1) * 2;
+        d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
       } else {
-        d0[q] = val.x;
-        d1[q] = val.y;
+        d0[q] = img[q];
+        d1[q] = img[plane + q];
       }
     }
   } else {
     for (int32_t q = lane; q < np; q += 64) {
-      const double2 val = img[q];
       if constexpr (V == 4) {
-        (reinterpret_cast<double2*>(out0) + 2 * base)[q] = val;
+        const int32_t tb = q >> 1, h2 = (q & 1) * 2;
+        d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
       } else {
-        if (out0) out0[base + q] = val.x;
-        if (out1) out1[base + q] = val.y;
+        if (out0) out0[base + q] = img[q];
+        if (out1) out1[base + q] = img[plane + q];
       }
     }
   }
@@ -728,7 +730,8 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1, double* __restrict__ trash) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double2* const img = reinterpret_cast<double2*>(smem);
+  double* const img = reinterpret_cast<double*>(smem);
+  const int plane = npt * maxrow + 1;  // odd plane stride: the V planes start on different banks
   const int lane = threadIdx.x;
   const int64_t ntiles = (nnodes + npt - 1) / npt;
   const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
@@ -752,15 +755,15 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
     const V3Tile T3 = v3_load_tile(t + 3, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Bb, X, pr.rho, Cb);
     Ba = v3_load_rec(T2, lane, nvis, vis_nd, vis_pos, vis_meta);
-    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, lane, out0, out1, trash);
+    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V3Tile T4 = v3_load_tile(t + 4, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
     Bb = v3_load_rec(T3, lane, nvis, vis_nd, vis_pos, vis_meta);
-    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, lane, out0, out1, trash);
+    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (t < t1) v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, lane, out0, out1, trash);  // odd tail
+  if (t < t1) v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1021,7 +1024,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   const char* impl = getenv("PF_GATHER_IMPL");
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
   if (!(impl && impl[0] == 'v' && impl[1] == '2')) {  // default: v3
-    const size_t lds3 = (((size_t)ctx->npt * ctx->max_row_blocks * Phys::V * 8) + 15) & ~(size_t)15;
+    const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
     const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V / 2), 64);
     const char* ab = getenv("PF_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
