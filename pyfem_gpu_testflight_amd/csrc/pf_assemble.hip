@@ -746,6 +746,13 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   V3Rec Bb = v3_load_rec(T1, lane, nvis, vis_nd, vis_pos, vis_meta);
   V3Visit<P, RHO> Ca, Cb;
   v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
+  // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
+  // load" (prologue: needs vmcnt(0)) with "five stores are younger than it" (back edge: vmcnt(5) is
+  // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
+  asm volatile("" ::"v"(Bb.nd.x), "v"(Bb.nd.y), "v"(Bb.nd.z), "v"(Bb.nd.w), "v"(Bb.pk), "v"(Bb.meta));
+  asm volatile("" ::"v"(Ca.el.x[0]), "v"(Ca.el.x[1]), "v"(Ca.el.x[2]), "v"(Ca.el.y[0]), "v"(Ca.el.y[1]), "v"(Ca.el.y[2]));
+  if constexpr (P == 4) asm volatile("" ::"v"(Ca.el.x[3]), "v"(Ca.el.y[3]));
+  if constexpr (RHO) asm volatile("" ::"v"(Ca.rho_e[0]), "v"(Ca.rho_e[1]), "v"(Ca.rho_e[2]), "v"(Ca.rho_e[P - 1]));
 
   // steady state: two tiles per trip, both always executed (a conditional second half gives the
   // back edge two different in-flight counts and hipcc falls back to vmcnt(0) at the loop top)
