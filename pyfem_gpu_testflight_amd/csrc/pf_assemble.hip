@@ -278,274 +278,6 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 }
 
 // ------------------------------------------------------------------------------------------
-// GATHER assembly v2 (default): persistent single-wave workgroups, software-pipelined over tiles.
-//
-// What the r01/r02 measurements said about the first version (one short-lived workgroup per
-// 64-node tile): skeleton loads ~155 us + quadrature ~280 us + write-out ~270 us ADD UP (714 us) --
-// every tile pays a 4-deep dependent load chain (row pointers -> incidence -> conn -> X), then
-// computes, then holds its LDS and wave slots while its stores drain, and VGPR/LDS occupancy is
-// too low for other tiles to cover that.  This version removes the serialisation instead of
-// relying on occupancy:
-//   * lane = node.  The coordinates (and densities) of the node's ROW NEIGHBOURS are staged once
-//     per tile in LDS ([neighbour slot][lane]); an incident element's corner nodes are neighbour
-//     slots (the 1-byte positions the symbolic phase stored), so the quadrature reads its inputs
-//     from LDS: the kernel touches neither conn nor the incidence list, and X is gathered 9 times
-//     per node instead of 16.
-//   * one wave walks a contiguous run of tiles.  Row pointers for tile t+1 are requested at the top
-//     of tile t, neighbour ids / position words after the first incident element, the X gathers
-//     after the last; they are waited for and parked in LDS BEFORE tile t's stores are issued.
-//     vmcnt retires in issue order on gfx950 (stores included), so a load waited for after a store
-//     would expose the full store drain; here no wait ever sits behind a fresh store, and the drain
-//     of tile t overlaps the quadrature of tile t+1.
-//   * a single wave accumulates its incident elements in ascending order with plain LDS
-//     read-modify-writes: no barriers, no atomics, bitwise reproducible.
-// dynamic LDS (doubles first): acc[maxrow*V*65] | xs[maxrow*65] double2 | rs[maxrow*65] (RHO) |
-//                              pws[maxval*64] u32 | src[2][64*maxrow] u16
-// ------------------------------------------------------------------------------------------
-static constexpr int V2_CH = 12;   // neighbour ids prefetched in registers (rest: slow path)
-static constexpr int V2_JCH = 8;   // position words prefetched in registers (rest: slow path)
-
-struct V2Ptrs {
-  int32_t rowbase, cnt, jb, nj, dpos;
-};
-
-struct V2Lds {
-  double2* acc;    // [(slot*VH + h)*65 + lane]  values (2h, 2h+1) of the slot's V-vector
-  double2* xs;     // [slot*65 + lane]           neighbour coordinates
-  double* rs;      // [slot*65 + lane]           neighbour densities (RHO)
-  uint32_t* pws;   // [j*64 + lane]              position words of the incident elements
-  uint16_t* src;   // [2][64*maxrow]             write-out map: lane | slot<<8 for the tile's t-th block
-  int maxrow;
-};
-
-__device__ __forceinline__ V2Ptrs v2_load_ptrs(int64_t tile, int lane, int64_t nnodes, const int32_t* __restrict__ nptr,
-                                               const int32_t* __restrict__ n2e_ptr,
-                                               const uint8_t* __restrict__ diagpos) {
-  V2Ptrs q;
-  const int64_t n = tile * 64 + lane;
-  if (n < nnodes) {
-    const int32_t a0 = nptr[n], a1 = nptr[n + 1], b0 = n2e_ptr[n], b1 = n2e_ptr[n + 1];
-    q.rowbase = a0; q.cnt = a1 - a0; q.jb = b0; q.nj = b1 - b0; q.dpos = diagpos[n];
-  } else {
-    q.rowbase = 0; q.cnt = 0; q.jb = 0; q.nj = 0; q.dpos = 0;
-  }
-  return q;
-}
-
-// neighbour ids and position words of the lane's node, fixed-size register sets (0 beyond the row)
-#define V2_LOAD_LISTS(q)                                                                  \
-  _Pragma("unroll") for (int c = 0; c < V2_CH; ++c) nid[c] = (c < (q).cnt) ? nidx[(q).rowbase + c] : 0; \
-  _Pragma("unroll") for (int j = 0; j < V2_JCH; ++j) pw[j] = (j < (q).nj) ? n2e_pos4[(q).jb + j] : 0u;
-
-// stage the tile described by q in LDS: X (rho) of the row neighbours, position words, write-out map
-template <bool RHO>
-__device__ __forceinline__ void v2_stage(const V2Ptrs& q, const int32_t (&nid)[V2_CH], const uint32_t (&pw)[V2_JCH],
-                                         int pb, int lane, const V2Lds& L, const double* __restrict__ X,
-                                         const double* __restrict__ rho, const int32_t* __restrict__ nidx,
-                                         const uint32_t* __restrict__ n2e_pos4, int32_t& total, int32_t& wavebase,
-                                         int32_t& maxnj) {
-  // X (and rho) gathers of the row neighbours: issue all, then park in LDS
-  double2 xv[V2_CH];
-  double rv[V2_CH];
-#pragma unroll
-  for (int c = 0; c < V2_CH; ++c) {  // nid[c] == 0 beyond the row: a harmless in-range load
-    xv[c] = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nid[c]);
-    if constexpr (RHO) rv[c] = rho[nid[c]]; else rv[c] = 0.0;
-  }
-  // exclusive wave scan of cnt, tile totals (independent work while the gathers fly)
-  int32_t incl = q.cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int32_t t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  const int32_t pre = incl - q.cnt;
-  total = __shfl(incl, 63);
-  wavebase = __shfl(q.rowbase, 0);
-  int32_t mx = q.nj;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-  maxnj = mx;
-  uint16_t* sm = L.src + (size_t)pb * 64 * L.maxrow;
-  for (int c = 0; c < q.cnt; ++c) sm[pre + c] = (uint16_t)(lane | (c << 8));
-#pragma unroll
-  for (int j = 0; j < V2_JCH; ++j)
-    if (j < q.nj) L.pws[j * 64 + lane] = pw[j];
-  for (int j = V2_JCH; j < q.nj; ++j) L.pws[j * 64 + lane] = n2e_pos4[q.jb + j];  // slow path
-#pragma unroll
-  for (int c = 0; c < V2_CH; ++c) {
-    if (c < q.cnt) {
-      L.xs[c * LDS_STRIDE + lane] = xv[c];
-      if constexpr (RHO) L.rs[c * LDS_STRIDE + lane] = rv[c];
-    }
-  }
-  for (int c = V2_CH; c < q.cnt; ++c) {  // slow path: very high valence
-    const int32_t m = nidx[q.rowbase + c];
-    L.xs[c * LDS_STRIDE + lane] = *reinterpret_cast<const double2*>(X + 2 * (int64_t)m);
-    if constexpr (RHO) L.rs[c * LDS_STRIDE + lane] = rho[m];
-  }
-}
-
-// coordinates / densities of one incident element from the staged neighbours
-template <int P, bool RHO>
-__device__ __forceinline__ void v2_load_elem(uint32_t pk, int lane, const V2Lds& L, Elem<P>& el, double (&rho_e)[P]) {
-#pragma unroll
-  for (int b = 0; b < P; ++b) {
-    const int pos = (pk >> (8 * b)) & 255;
-    const double2 xy = L.xs[pos * LDS_STRIDE + lane];
-    el.x[b] = xy.x;
-    el.y[b] = xy.y;
-    if constexpr (RHO) rho_e[b] = L.rs[pos * LDS_STRIDE + lane]; else rho_e[b] = 1.0;
-  }
-}
-
-template <int P, class Phys, bool RHO, int ABL = 0>
-__global__ __launch_bounds__(64) void k_assemble_v2(int64_t nnodes, int32_t maxrow, int32_t maxval,
-                                                    const double* __restrict__ X,
-                                                    const int32_t* __restrict__ nptr,
-                                                    const int32_t* __restrict__ nidx,
-                                                    const int32_t* __restrict__ n2e_ptr,
-                                                    const uint32_t* __restrict__ n2e_pos4,
-                                                    const uint8_t* __restrict__ diagpos,
-                                                    typename Phys::Params pr, double* __restrict__ out0,
-                                                    double* __restrict__ out1) {
-  constexpr int V = Phys::V;
-  constexpr int VH = V / 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  V2Lds L;
-  L.maxrow = maxrow;
-  L.acc = reinterpret_cast<double2*>(smem);
-  L.xs = L.acc + (size_t)maxrow * VH * LDS_STRIDE;
-  L.rs = reinterpret_cast<double*>(L.xs + (size_t)maxrow * LDS_STRIDE);
-  L.pws = reinterpret_cast<uint32_t*>(L.rs + (RHO ? (size_t)maxrow * LDS_STRIDE : 0));
-  L.src = reinterpret_cast<uint16_t*>(L.pws + (size_t)maxval * 64);
-  double2* const acc = L.acc;
-
-  const int lane = threadIdx.x;
-  const int64_t ntiles = (nnodes + 63) / 64;
-  const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
-  if (t0 >= t1) return;
-
-  // ---- prologue: first tile, nothing to overlap with -------------------------------------------
-  V2Ptrs cur = v2_load_ptrs(t0, lane, nnodes, nptr, n2e_ptr, diagpos);
-  int32_t nid[V2_CH];
-  uint32_t pw[V2_JCH];
-  V2_LOAD_LISTS(cur)
-  int pb = 0;
-  int32_t total, wavebase, maxnj;
-  v2_stage<RHO>(cur, nid, pw, pb, lane, L, X, pr.rho, nidx, n2e_pos4, total, wavebase, maxnj);
-  for (int s = 0; s < cur.cnt * VH; ++s) acc[s * LDS_STRIDE + lane] = make_double2(0.0, 0.0);
-
-  for (int64_t tile = t0; tile < t1; ++tile) {
-    const bool more = tile + 1 < t1;
-    V2Ptrs nxt = cur;
-    if (more) nxt = v2_load_ptrs(tile + 1, lane, nnodes, nptr, n2e_ptr, diagpos);  // in flight during element 0
-
-    // ---- incident elements of this tile, ascending; inputs of element j+1 and the position
-    //      word of element j+2 are fetched from LDS while element j is integrated ------------------
-    uint32_t pk0 = (0 < cur.nj) ? L.pws[lane] : 0u;
-    uint32_t pk1 = (1 < cur.nj) ? L.pws[64 + lane] : 0u;
-    Elem<P> el0;
-    double rho0[P];
-    if (0 < cur.nj) v2_load_elem<P, RHO>(pk0, lane, L, el0, rho0);
-    for (int32_t j = 0; j < maxnj; ++j) {
-      Elem<P> el1;
-      double rho1[P];
-      if (j + 1 < cur.nj) v2_load_elem<P, RHO>(pk1, lane, L, el1, rho1);
-      const uint32_t pk2 = (j + 2 < cur.nj) ? L.pws[(j + 2) * 64 + lane] : 0u;
-      if (j < cur.nj) {
-        int pos[P];
-#pragma unroll
-        for (int b = 0; b < P; ++b) pos[b] = (pk0 >> (8 * b)) & 255;
-        int a = 0;
-#pragma unroll
-        for (int b = 1; b < P; ++b) a = (pos[b] == cur.dpos) ? b : a;
-        double v[P][V];
-        if constexpr (ABL & 1) {
-#pragma unroll
-          for (int b = 0; b < P; ++b)
-#pragma unroll
-            for (int k = 0; k < V; ++k) v[b][k] = el0.x[b] + (double)(k + a);
-        } else {
-          element_rows_core<P, Phys, RHO>(pr, el0, rho0, a, v);
-        }
-        // single wave, program order: ascending-element summation without read-back
-#pragma unroll
-        for (int b = 0; b < P; ++b)
-#pragma unroll
-          for (int k = 0; k < V; ++k) {
-            double* slot = reinterpret_cast<double*>(&acc[(pos[b] * VH + (k >> 1)) * LDS_STRIDE + lane]) + (k & 1);
-            __hip_atomic_fetch_add(slot, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-      }
-      if (j == 0 && more) { V2_LOAD_LISTS(nxt) }  // row pointers of tile+1 have landed by now
-      pk0 = pk1;
-      pk1 = pk2;
-      el0 = el1;
-#pragma unroll
-      for (int b = 0; b < P; ++b) rho0[b] = rho1[b];
-    }
-    if (maxnj == 0 && more) { V2_LOAD_LISTS(nxt) }
-
-    // ---- stage tile+1 (its loads complete BEFORE this tile's stores are issued) ---------------
-    int32_t total_n = 0, wavebase_n = 0, maxnj_n = 0;
-    if (more) v2_stage<RHO>(nxt, nid, pw, pb ^ 1, lane, L, X, pr.rho, nidx, n2e_pos4, total_n, wavebase_n, maxnj_n);
-
-    // ---- write-out of this tile: lane q stores the q-th 16-byte piece of the tile's range,
-    //      four pieces per lane in flight (one LDS lookup + one b128 read each) --------------------
-    {
-      const uint16_t* sm = L.src + (size_t)pb * 64 * maxrow;
-      constexpr int U = 4;
-      if constexpr (V == 4) {
-        const int32_t total2 = (ABL & 4) ? min(total, 1) : 2 * total;
-        double2* dst = reinterpret_cast<double2*>(out0 + 4 * (int64_t)wavebase);
-        for (int32_t q0 = lane; q0 < total2; q0 += 64 * U) {
-          int sv[U];
-          double2 val[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) sv[u] = sm[min(q0 + 64 * u, total2 - 1) >> 1];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int o = sv[u] & 255, c = sv[u] >> 8, h = (q0 + 64 * u) & 1;
-            val[u] = acc[(c * 2 + h) * LDS_STRIDE + o];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (q0 + 64 * u < total2) dst[q0 + 64 * u] = val[u];
-        }
-      } else {
-        const int32_t tot = (ABL & 4) ? min(total, 1) : total;
-        for (int32_t q0 = lane; q0 < tot; q0 += 64 * U) {
-          int sv[U];
-          double2 val[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) sv[u] = sm[min(q0 + 64 * u, tot - 1)];
-#pragma unroll
-          for (int u = 0; u < U; ++u) val[u] = acc[(sv[u] >> 8) * LDS_STRIDE + (sv[u] & 255)];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (q0 + 64 * u < tot) {
-              const int64_t g = (int64_t)wavebase + q0 + 64 * u;
-              if (out0) out0[g] = val[u].x;
-              if (out1) out1[g] = val[u].y;
-            }
-          }
-        }
-      }
-    }
-    // ---- next tile becomes current -----------------------------------------------------------------
-    if (more) {
-      cur = nxt;
-      pb ^= 1;
-      total = total_n;
-      wavebase = wavebase_n;
-      maxnj = maxnj_n;
-      for (int s = 0; s < cur.cnt * VH; ++s) acc[s * LDS_STRIDE + lane] = make_double2(0.0, 0.0);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // GATHER assembly v3 (default): lane = incident (node, element) pair, tile = npt consecutive nodes.
 //
 // The measurements that led here (profiles/r01_*): with lane = node the accumulator tile is
@@ -726,7 +458,7 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
                                                     const int32_t* __restrict__ n2e_ptr,
                                                     const int4* __restrict__ vis_nd,
                                                     const uint32_t* __restrict__ vis_pos,
-                                                    const uint32_t* __restrict__ vis_meta, int32_t nvis,
+                                                    const uint32_t* __restrict__ vis_meta, int32_t nvis, int32_t strided,
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1, double* __restrict__ trash) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -734,14 +466,17 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   const int plane = npt * maxrow + 1;  // odd plane stride: the V planes start on different banks
   const int lane = threadIdx.x;
   const int64_t ntiles = (nnodes + npt - 1) / npt;
-  const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+  // tile walk: contiguous run per wave (tstride == 1) or round-robin over the grid (tstride == gridDim)
+  const int64_t tstride = strided ? gridDim.x : 1;
+  const int64_t t0 = strided ? blockIdx.x : ntiles * blockIdx.x / gridDim.x;
+  const int64_t t1 = strided ? ntiles : ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
 
   // Pipeline state.  Two register sets (a/b) are used on alternate tiles, so nothing a load is about to
   // write is ever copied: a rotation by copy would have to wait for the loads just issued.
   V3Tile T0 = v3_load_tile(t0, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Tile T1 = v3_load_tile(t0 + 1, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Tile T2 = v3_load_tile(t0 + 2, t1, npt, nnodes, nptr, n2e_ptr);
+  V3Tile T1 = v3_load_tile(t0 + tstride, t1, npt, nnodes, nptr, n2e_ptr);
+  V3Tile T2 = v3_load_tile(t0 + 2 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
   V3Rec Ba = v3_load_rec(T0, lane, nvis, vis_nd, vis_pos, vis_meta);
   V3Rec Bb = v3_load_rec(T1, lane, nvis, vis_nd, vis_pos, vis_meta);
   V3Visit<P, RHO> Ca, Cb;
@@ -757,14 +492,14 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   // steady state: two tiles per trip, both always executed (a conditional second half gives the
   // back edge two different in-flight counts and hipcc falls back to vmcnt(0) at the loop top)
   int64_t t = t0;
-  for (; t + 1 < t1; t += 2) {
+  for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
-    const V3Tile T3 = v3_load_tile(t + 3, t1, npt, nnodes, nptr, n2e_ptr);
+    const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Bb, X, pr.rho, Cb);
     Ba = v3_load_rec(T2, lane, nvis, vis_nd, vis_pos, vis_meta);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
-    const V3Tile T4 = v3_load_tile(t + 4, t1, npt, nnodes, nptr, n2e_ptr);
+    const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
     Bb = v3_load_rec(T3, lane, nvis, vis_nd, vis_pos, vis_meta);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
@@ -984,12 +719,6 @@ static size_t gather_lds_bytes(int maxrow, int V) {
 
 static constexpr int GATHER_NW = 2;  // waves per 64-node tile of the legacy kernel
 
-static size_t v2_lds_bytes(int maxrow, int maxval, int V, bool rho) {
-  size_t b = (size_t)maxrow * V * LDS_STRIDE * 8 + (size_t)maxrow * LDS_STRIDE * 16 +
-             (rho ? (size_t)maxrow * LDS_STRIDE * 8 : 0) + (size_t)maxval * 64 * 4 + (size_t)2 * 64 * maxrow * 2;
-  return (b + 15) & ~(size_t)15;
-}
-
 template <int P, class Phys, bool RHO>
 static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   const size_t lds = gather_lds_bytes(ctx->max_row_blocks, Phys::V);
@@ -1030,7 +759,7 @@ template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   const char* impl = getenv("PF_GATHER_IMPL");
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
-  if (!(impl && impl[0] == 'v' && impl[1] == '2')) {  // default: v3
+  {  // default: v3
     const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
     const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V / 2), 64);
     const char* ab = getenv("PF_ABLATE");
@@ -1050,40 +779,18 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     if (lds3 > 48 * 1024)
       PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     const int64_t nt = cdiv(ctx->nnodes, ctx->npt);
-    int wpc = 12;
+    int wpc = 24;  // persistent waves per CU (r03 sweep: 24-32 best)
     const char* g3 = getenv("PF_GATHER_WAVES_PER_CU");
     if (g3 && atoi(g3) > 0) wpc = atoi(g3);
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
     hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->npt, ctx->max_row_blocks, ctx->X,
                        ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_nd),
-                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_meta, (int32_t)(ctx->nelems * ctx->P), pr, out0, out1,
-                       ctx->scal + (size_t)PF_NPART * (PF_NPART_ARRAYS - 1) + PF_NPART - 8);
+                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_meta, (int32_t)(ctx->nelems * ctx->P), (int32_t)!(getenv("PF_TILE_ORDER") && getenv("PF_TILE_ORDER")[0] == 'c'), pr, out0, out1,
+                       ctx->scal + (size_t)PF_NPART * PF_NPART_ARRAYS /* 16 spare doubles: trash line */);
     PF_LAUNCH_CHECK();
     return PF_OK;
   }
-  const size_t lds = v2_lds_bytes(ctx->max_row_blocks, ctx->max_valence, Phys::V, RHO);
-  if (lds > 160 * 1024)
-    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");
-  auto kern = k_assemble_v2<P, Phys, RHO, 0>;
-  if constexpr (P == 4 && Phys::V == 4 && !RHO) {
-    const char* ab = getenv("PF_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
-    if (abl == 1) kern = k_assemble_v2<P, Phys, RHO, 1>;
-    else if (abl == 4) kern = k_assemble_v2<P, Phys, RHO, 4>;
-    else if (abl == 5) kern = k_assemble_v2<P, Phys, RHO, 5>;
-  }
-  if (lds > 48 * 1024)
-    PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int64_t ntiles = cdiv(ctx->nnodes, 64);
-  int per_cu = (int)std::min<size_t>(8, (160 * 1024) / lds);
-  const char* g = getenv("PF_GATHER_WAVES_PER_CU");
-  if (g && atoi(g) > 0) per_cu = atoi(g);
-  const unsigned grid = (unsigned)std::min<int64_t>(ntiles, (int64_t)256 * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
-                     ctx->max_valence, ctx->X, ctx->nptr, ctx->nidx, ctx->n2e_ptr,
-                     reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->diagpos, pr, out0, out1);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
+  return pf_fail(ctx, PF_E_INVALID, "unknown PF_GATHER_IMPL");
 }
 
 int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, const double* rho, int mode,

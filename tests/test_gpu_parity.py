@@ -323,3 +323,32 @@ def test_cg_is_bitwise_reproducible(pf):
         sols.append((x.clone(), it))
     assert sols[0][1] == sols[1][1]
     assert bool((sols[0][0] == sols[1][0]).all())
+
+
+def test_isolated_nodes_and_kernel_variants(pf, orc):
+    """Nodes that no element references (the reference allows them: pyfem.py:683-684) give empty rows;
+    32 consecutive ones make whole assembly tiles empty.  Also cross-checks the first-generation
+    kernel (PF_GATHER_IMPL=legacy) against the default one, bit for bit."""
+    import os
+
+    conn, X = orc.structured_mesh(9, 7, "quad")
+    gap = 32
+    shift = np.where(np.arange(X.shape[0]) >= 20, gap, 0)
+    conn2 = conn + shift[conn]
+    X2 = np.zeros((X.shape[0] + gap, 2))
+    X2[np.arange(X.shape[0]) + shift] = X
+    q, b = _qb(pf, "quad")
+    rho = 0.2 + 0.8 * np.random.RandomState(9).rand(X2.shape[0])
+    model = pf.LinearElasticity(X2, conn2, [0, 1], None, {int(conn2.max()): [0.0, -1.0]}, q, b, p=2.0)
+    Ks = model.compute_jacobian(rho).to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X2, conn2, "quad", rho=rho, p=2.0), orc.create_conn_dof(conn2, 2))
+    assert Ks.shape == Ko.shape
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    a = model.compute_jacobian(rho).vals.clone()
+    os.environ["PF_GATHER_IMPL"] = "legacy"
+    try:
+        bvals = model.compute_jacobian(rho).vals.clone()
+    finally:
+        del os.environ["PF_GATHER_IMPL"]
+    assert float((a - bvals).abs().max()) <= 1e-14 * float(a.abs().max())

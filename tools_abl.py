@@ -11,18 +11,19 @@ h = m.hctx
 os.environ["PF_GATHER_IMPL"] = "legacy"
 ref = m.compute_jacobian().vals.clone()
 os.environ["PF_GATHER_IMPL"] = "v3"
-K = m.compute_jacobian()
-print("v3 vs legacy max abs diff:", float((K.vals - ref).abs().max()), "max:", float(ref.abs().max()))
-K2 = m.compute_jacobian()
-print("v3 run-to-run bitwise:", bool((K.vals == K2.vals).all()))
 rho = torch.rand(h.nnodes, dtype=torch.float64, device="cuda") * 0.5 + 0.5
+K = m.compute_jacobian()
 def t(label, in0=None, p=0.0):
     ms = h.time_kernel(_lib.PF_K_ASSEMBLE_ELASTICITY, 20, in0=in0, out0=K.vals, E=10.0, nu=0.3, p=p)
     print(f"  {label}: {ms*1e3:8.1f} us", flush=True)
-for wpc in ["8", "12", "16", "24"]:
-    os.environ["PF_GATHER_WAVES_PER_CU"] = wpc
-    for abl in [0, 1, 4, 5]:
-        os.environ["PF_ABLATE"] = str(abl)
-        t(f"v3 waves/CU={wpc} ABL={abl}")
-    os.environ["PF_ABLATE"] = "0"
-    t(f"v3 waves/CU={wpc} with rho", in0=rho, p=3.0)
+for order in ["contig", "strided"]:
+    os.environ["PF_TILE_ORDER"] = order
+    K2 = m.compute_jacobian()
+    print(order, "max abs diff vs legacy:", float((K2.vals - ref).abs().max()))
+    for wpc in ["12", "16", "24", "32"]:
+        os.environ["PF_GATHER_WAVES_PER_CU"] = wpc
+        for abl in [0, 1, 4]:
+            os.environ["PF_ABLATE"] = str(abl)
+            t(f"{order} waves/CU={wpc} ABL={abl}")
+        os.environ["PF_ABLATE"] = "0"
+        t(f"{order} waves/CU={wpc} with rho", in0=rho, p=3.0)
