@@ -193,6 +193,22 @@ def main():
         iters = args.cg_iters
     cg_rate = iters / t_cg
 
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/r01_pmc_summary.json: WRITE_SIZE + FETCH_SIZE in KB, separate passes; FETCH_SIZE of the
+    # 16-B/lane SpMV stream doubled as MI355X_MICROARCH.md prescribes, the assembly's mixed-width reads
+    # left raw = a lower bound).  null when the summary is missing or the mesh is not the profiled one.
+    traffic_asm = traffic_spmv = None
+    try:
+        if nx == 2048 and world == 1:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            for k, v in pm.items():
+                if "k_assemble_v3" in k:
+                    traffic_asm = 1024.0 * (v["WRITE_SIZE"] + v["FETCH_SIZE"])
+                if "k_spmv" in k:
+                    traffic_spmv = 1024.0 * (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"])
+    except Exception:
+        pass
+
     out = {
         "metric": "element-assemblies/sec (4M-quad plane-stress); CG-iter/sec alongside",
         "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,11 +218,11 @@ def main():
                                f"{nelems_total} elements, ndof={2 * (nx + 1) ** 2}, element-block partition over "
                                f"{world} GPU(s)", "nelems": nelems_total, "cg_iters_timed": int(iters)},
         "cg_iter_per_sec": cg_rate,
-        "roofline": {"bound": "hbm", "kernel": "k_assemble_gather<4,Elasticity>", "achieved": asm_gbs,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "kernel": "k_assemble_v3<4,Elasticity<4,false>>", "achieved": asm_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
                      "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms},
         "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": None,
+                          "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
                           "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms},
         "setup_s": t_setup,
     }
