@@ -96,11 +96,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): PF_BENCH_BACKEND=gloo with
+    # PF_BENCH_DEVICE=0 runs the N>1 code path with every rank on the same GPU
+    if "PF_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["PF_BENCH_DEVICE"])
+    backend = os.environ.get("PF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from pyfem_gpu_testflight_amd import _lib, pyfem
 
