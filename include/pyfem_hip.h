@@ -133,20 +133,20 @@ int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rt
  *   pf_spmv_dot:        y = A x ; partials of x . y
  *   pf_cgcg_update_xrz: alpha = state[0]; x += alpha p; r -= alpha s; z = dinv*r (dinv NULL: z = r);
  *                       partials of sum w r z and sum w r r
- *   pf_cgcg_reduce:     red_out[0..2] = [gamma, delta, rr] from the partials of the two calls above
- *   pf_cgcg_scalars:    state = [alpha, beta, gamma]; beta = first ? 0 : gamma_new/gamma;
- *                       alpha = gamma_new/(delta - beta*gamma_new/alpha); red = reduced [gamma_new, delta, rr]
- *   pf_cgcg_update_ps:  beta = state[1]; p = z + beta p ; s = w + beta s                        */
+ *   pf_cgcg_reduce:     zero[0..nzero) = 0 (the interface part of the all-reduce buffer), then
+ *                       red_out[0..2] = [gamma, delta, rr] from the partials of the two calls above
+ *   pf_cgcg_update_ps:  state = [alpha, beta, gamma]; from state_in and the REDUCED red = [gamma_new, delta, rr]:
+ *                       beta = first ? 0 : gamma_new/gamma; alpha = gamma_new/(delta - beta*gamma_new/alpha);
+ *                       p = z + beta p ; s = w + beta s ; the new state goes to state_out (!= state_in)      */
 int pf_dot(pf_ctx* ctx, int64_t n, const double* a, const double* b, const double* w, double* out);
 int pf_copy_indexed(pf_ctx* ctx, int64_t n, const int32_t* src_idx, const int32_t* dst_idx,
                     const double* src, double* dst);
 int pf_spmv_dot(pf_ctx* ctx, const double* vals, const double* x, double* y);
 int pf_cgcg_update_xrz(pf_ctx* ctx, const double* state, const double* p, const double* s,
                        const double* dinv, const double* w, double* x, double* r, double* z);
-int pf_cgcg_reduce(pf_ctx* ctx, double* red_out);
-int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, int first);
-int pf_cgcg_update_ps(pf_ctx* ctx, const double* state, const double* z, const double* w,
-                      double* p, double* s);
+int pf_cgcg_reduce(pf_ctx* ctx, double* red_out, double* zero, int64_t nzero);
+int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, const double* red,
+                      int first, const double* z, const double* w, double* p, double* s);
 
 /* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
  *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */

@@ -45,9 +45,8 @@ SIGNATURES = {
     "pf_copy_indexed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pf_cgcg_update_xrz": (C.c_int, [_vp] * 9),
-    "pf_cgcg_reduce": (C.c_int, [_vp, _vp]),
-    "pf_cgcg_scalars": (C.c_int, [_vp, _vp, _vp, C.c_int]),
-    "pf_cgcg_update_ps": (C.c_int, [_vp] * 6),
+    "pf_cgcg_reduce": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "pf_cgcg_update_ps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
 }
 

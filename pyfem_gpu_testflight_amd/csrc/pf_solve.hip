@@ -241,8 +241,10 @@ __global__ __launch_bounds__(256) void k_dot(int64_t n, const double* __restrict
 // out[k] = sum of partial array k, k < narr; one 256-thread block
 __global__ __launch_bounds__(256) void k_finalize(int narr, const double* __restrict__ p0, int n0,
                                                   const double* __restrict__ p1, int n1,
-                                                  const double* __restrict__ p2, int n2, double* __restrict__ out) {
+                                                  const double* __restrict__ p2, int n2, double* __restrict__ out,
+                                                  double* __restrict__ zero, int64_t nzero) {
   __shared__ double sh[4];
+  for (int64_t i = threadIdx.x; i < nzero; i += blockDim.x) zero[i] = 0.0;
   double t = block_sum_partials(p0, n0, sh);
   if (threadIdx.x == 0) out[0] = t;
   if (narr > 1) {
@@ -350,7 +352,21 @@ __global__ __launch_bounds__(256) void k_cgcg_update_xrz(int64_t n, const double
   __shared__ double sh[4];
   const double alpha = state[0];
   double s1 = 0.0, s2 = 0.0;
-  PF_VEC_LOOP(i, n) {
+  const int64_t n2 = n >> 1;
+  PF_VEC_LOOP(i, n2) {
+    const double2 pv = ld2(p, i), sv = ld2(s, i);
+    double2 xv = ld2(x, i), rv = ld2(r, i), zv;
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+    if (dinv) { const double2 dv = ld2(dinv, i); zv.x = dv.x * rv.x; zv.y = dv.y * rv.y; } else zv = rv;
+    st2(x, i, xv); st2(r, i, rv); st2(z, i, zv);
+    double2 wv = make_double2(1.0, 1.0);
+    if (w) wv = ld2(w, i);
+    s1 += wv.x * rv.x * zv.x + wv.y * rv.y * zv.y;
+    s2 += wv.x * rv.x * rv.x + wv.y * rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * s[i];
     r[i] = ri;
@@ -364,29 +380,40 @@ __global__ __launch_bounds__(256) void k_cgcg_update_xrz(int64_t n, const double
   block_store_partial(s2, rr_part, sh);
 }
 
-__global__ void k_cgcg_scalars(double* __restrict__ state, const double* __restrict__ red, int first) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// scalar recurrences of the single-reduction CG, evaluated redundantly by every block:
+//   beta = first ? 0 : gamma_new/gamma ; alpha = gamma_new/(delta - beta*gamma_new/alpha)
+// state_in = [alpha, beta, gamma] of the previous iteration, red = reduced [gamma_new, delta, rr];
+// block 0 publishes the new state to state_out (ping-pong: nobody reads what it overwrites).
+__global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double* __restrict__ state_in,
+                                                        double* __restrict__ state_out,
+                                                        const double* __restrict__ red, int first,
+                                                        const double* __restrict__ z, const double* __restrict__ w,
+                                                        double* __restrict__ p, double* __restrict__ s) {
   const double gamma_new = red[0], delta = red[1];
   double alpha, beta;
   if (first) {
     beta = 0.0;
     alpha = gamma_new / delta;
   } else {
-    beta = gamma_new / state[2];
-    alpha = gamma_new / (delta - beta * gamma_new / state[0]);
+    beta = gamma_new / state_in[2];
+    alpha = gamma_new / (delta - beta * gamma_new / state_in[0]);
   }
-  state[0] = alpha;
-  state[1] = beta;
-  state[2] = gamma_new;
-}
-
-__global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double* __restrict__ state,
-                                                        const double* __restrict__ z, const double* __restrict__ w,
-                                                        double* __restrict__ p, double* __restrict__ s) {
-  const double beta = state[1];
-  PF_VEC_LOOP(i, n) {
-    p[i] = z[i] + beta * p[i];
-    s[i] = w[i] + beta * s[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state_out[0] = alpha;
+    state_out[1] = beta;
+    state_out[2] = gamma_new;
+  }
+  const int64_t n2 = n >> 1;
+  PF_VEC_LOOP(i, n2) {
+    const double2 zv = ld2(z, i), wv = ld2(w, i);
+    double2 pv = ld2(p, i), sv = ld2(s, i);
+    pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
+    sv.x = wv.x + beta * sv.x; sv.y = wv.y + beta * sv.y;
+    st2(p, i, pv); st2(s, i, sv);
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    p[n - 1] = z[n - 1] + beta * p[n - 1];
+    s[n - 1] = w[n - 1] + beta * s[n - 1];
   }
 }
 
@@ -444,7 +471,7 @@ extern "C" int pf_dot(pf_ctx* ctx, int64_t n, const double* a, const double* b, 
   PF_REQUIRE(a && b && out && n >= 0, "pf_dot: NULL argument");
   const unsigned g = vec_grid(n);
   k_dot<<<g, 256, 0, ctx->stream>>>(n, a, b, w, part(ctx, PA_BB));
-  k_finalize<<<1, 256, 0, ctx->stream>>>(1, part(ctx, PA_BB), (int)g, nullptr, 0, nullptr, 0, out);
+  k_finalize<<<1, 256, 0, ctx->stream>>>(1, part(ctx, PA_BB), (int)g, nullptr, 0, nullptr, 0, out, nullptr, 0);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -478,31 +505,24 @@ extern "C" int pf_cgcg_update_xrz(pf_ctx* ctx, const double* state, const double
   return PF_OK;
 }
 
-extern "C" int pf_cgcg_reduce(pf_ctx* ctx, double* red_out) {
+extern "C" int pf_cgcg_reduce(pf_ctx* ctx, double* red_out, double* zero, int64_t nzero) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(ctx->d && red_out, "pf_cgcg_reduce: no pattern / NULL argument");
+  PF_REQUIRE(ctx->d && red_out && (zero || nzero == 0), "pf_cgcg_reduce: no pattern / NULL argument");
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   const int nv = (int)vec_grid(n), ns = (int)spmv_grid(ctx->nnodes);
   k_finalize<<<1, 256, 0, ctx->stream>>>(3, part(ctx, PA_GAMMA), nv, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), nv,
-                                         red_out);
+                                         red_out, zero, nzero);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
 
-extern "C" int pf_cgcg_scalars(pf_ctx* ctx, double* state, const double* red, int first) {
+extern "C" int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, const double* red,
+                                 int first, const double* z, const double* w, double* p, double* s) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(state && red, "pf_cgcg_scalars: NULL argument");
-  k_cgcg_scalars<<<1, 64, 0, ctx->stream>>>(state, red, first);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-extern "C" int pf_cgcg_update_ps(pf_ctx* ctx, const double* state, const double* z, const double* w, double* p,
-                                 double* s) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(ctx->d && state && z && w && p && s, "pf_cgcg_update_ps: no pattern / NULL argument");
+  PF_REQUIRE(ctx->d && state_in && state_out && state_in != state_out && red && z && w && p && s,
+             "pf_cgcg_update_ps: no pattern / NULL argument / state buffers alias");
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
-  k_cgcg_update_ps<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state, z, w, p, s);
+  k_cgcg_update_ps<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state_in, state_out, red, first, z, w, p, s);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

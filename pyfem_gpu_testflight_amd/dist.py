@@ -99,8 +99,12 @@ class HipLocalOps:
     def _p(self, t):
         return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
 
-    def _call(self, name, *a):
+    def begin(self):
+        """Bind the context to torch's current stream once per solve (the per-call rebinding of the
+        generic HipContext methods costs more host time than the kernels take at 8 GPUs)."""
         self.h._sync_stream()
+
+    def _call(self, name, *a):
         self._lib.check(self.h._ctx, getattr(self.lib, name)(self.h._ctx, *a), name)
 
     def zeros(self, n, dtype=None):
@@ -125,14 +129,12 @@ class HipLocalOps:
         self._call("pf_cgcg_update_xrz", self._p(state), self._p(p), self._p(s), self._p(dinv), self._p(w),
                    self._p(x), self._p(r), self._p(z))
 
-    def cgcg_reduce(self, red):
-        self._call("pf_cgcg_reduce", self._p(red))
+    def cgcg_reduce(self, red, zero, nzero):
+        self._call("pf_cgcg_reduce", self._p(red), self._p(zero), C.c_int64(nzero))
 
-    def cgcg_scalars(self, state, red, first):
-        self._call("pf_cgcg_scalars", self._p(state), self._p(red), int(first))
-
-    def cgcg_update_ps(self, state, z, w, p, s):
-        self._call("pf_cgcg_update_ps", self._p(state), self._p(z), self._p(w), self._p(p), self._p(s))
+    def cgcg_update_ps(self, state_in, state_out, red, first, z, w, p, s):
+        self._call("pf_cgcg_update_ps", self._p(state_in), self._p(state_out), self._p(red), int(first),
+                   self._p(z), self._p(w), self._p(p), self._p(s))
 
 
 # ------------------------------------------------------------------------------------------
@@ -159,6 +161,8 @@ class Interface:
 
     def sum(self, v):
         """v[interface dofs] <- sum over ranks (in place); other entries untouched."""
+        if hasattr(self.ops, "begin"):
+            self.ops.begin()
         self.buf.zero_()
         self.ops.copy_indexed(self.n, self.local, self.slots, v, self.buf)
         _all_reduce(self.buf, self.group)
@@ -175,8 +179,10 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
     G = iface.G
     buf = iface.buf
     red = buf[G:]  # gamma, delta, rr
+    if hasattr(ops, "begin"):
+        ops.begin()
     x, r, z, w, p, s = ops.zeros(n), b.clone(), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
-    state = ops.zeros(3)
+    state, state_next = ops.zeros(3), ops.zeros(3)  # [alpha, beta, gamma], ping-pong
     bb = ops.zeros(1)
     ops.dot(b, b, own_w, bb)
     _all_reduce(bb, iface.group)
@@ -186,10 +192,9 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
         maxiter = 10 * n
     it, rnorm = 0, float("inf")
     while it < maxiter:
-        buf.zero_()
         ops.cgcg_update_xrz(state, p, s, dinv, own_w, x, r, z)
         ops.spmv_dot(K, z, w)
-        ops.cgcg_reduce(red)  # local [gamma, delta, rr] into the tail of the all-reduce buffer
+        ops.cgcg_reduce(red, buf, G)  # clear the interface part; local [gamma, delta, rr] into the tail
         ops.copy_indexed(iface.n, iface.local, iface.slots, w, buf)
         _all_reduce(buf, iface.group)
         ops.copy_indexed(iface.n, iface.slots, iface.local, buf, w)
@@ -198,8 +203,8 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
             rnorm = float(red[2].item()) ** 0.5
             if not rnorm == rnorm or rnorm <= tol:
                 break
-        ops.cgcg_scalars(state, red, it == 0)
-        ops.cgcg_update_ps(state, z, w, p, s)
+        ops.cgcg_update_ps(state, state_next, red, it == 0, z, w, p, s)
+        state, state_next = state_next, state
         it += 1
     relres = rnorm / bnorm if bnorm > 0 else rnorm
     if not rnorm <= tol:

@@ -46,19 +46,17 @@ class NumpyLocalOps:
         self._gamma = float((ww * r * z).sum())
         self._rr = float((ww * r * r).sum())
 
-    def cgcg_reduce(self, red):
+    def cgcg_reduce(self, red, zero, nzero):
+        zero[:nzero] = 0.0
         red[0], red[1], red[2] = self._gamma, self._delta, self._rr
 
-    def cgcg_scalars(self, state, red, first):
+    def cgcg_update_ps(self, state_in, state_out, red, first, z, w, p, s):
         g, d = float(red[0]), float(red[1])
         if first:
             beta, alpha = 0.0, g / d
         else:
-            beta = g / float(state[2])
-            alpha = g / (d - beta * g / float(state[0]))
-        state[0], state[1], state[2] = alpha, beta, g
-
-    def cgcg_update_ps(self, state, z, w, p, s):
-        beta = state[1]
+            beta = g / float(state_in[2])
+            alpha = g / (d - beta * g / float(state_in[0]))
+        state_out[0], state_out[1], state_out[2] = alpha, beta, g
         p.mul_(beta).add_(z)
         s.mul_(beta).add_(w)
