@@ -19,10 +19,14 @@
 // the (<= 4096, L2-resident) partials in a fixed order.  That removes the serialisation, needs no
 // extra launch and no fence (the kernel boundary publishes the partials), and makes CG bitwise
 // reproducible run to run.
+#include <stdlib.h>
+
 #include "pf_common.h"
 
-static constexpr int SPMV_TILE = 64;     // nodes per wave tile
-static constexpr int SPMV_CHUNK = 640;   // blocks staged in LDS per pass (d=2: 10 KB -> 16 waves/CU)
+// SpMV shapes: <D, rows per lane, blocks per lane in flight, LDS strip entries> (10 KB strips -> 16 waves/CU)
+#define PF_SPMV1 1, 2, 6, 1280
+#define PF_SPMV2 2, 1, 3, 640
+static constexpr int SPMV_TILE1 = 128, SPMV_TILE2 = 64;  // nodes per wave tile (64 * rows per lane)
 static constexpr int SPMV_MAXGRID = 4096;
 static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
 static constexpr int NPART = PF_NPART;   // capacity of one partial array
@@ -80,31 +84,41 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 
 // ------------------------------------------------------------------------------------------
 // y = A x ; optionally dot_part[blockIdx.x] = sum over this wave's rows of x_i y_i
+//   R = node rows per lane (tile = 64*R nodes), U = blocks per lane in flight, CH = LDS strip entries.
+//   d=1 moves a third of the bytes of d=2 per node, so it takes R=2 / U=6 to amortise the per-tile
+//   overhead (r01: 50 % of peak at R=1/U=3).
 // ------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int R, int U, int CH>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ dot_part) {
   using V = typename Vec<D>::T;
-  __shared__ V prod[SPMV_CHUNK];
+  constexpr int TILE = 64 * R;
+  __shared__ V prod[CH];
   const int lane = threadIdx.x;
   double dacc = 0.0;
-  const int64_t ntiles = (nnodes + SPMV_TILE - 1) / SPMV_TILE;
+  const int64_t ntiles = (nnodes + TILE - 1) / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t n = tile * SPMV_TILE + lane;
-    const bool valid = n < nnodes;
-    const int32_t rb = valid ? nptr[n] : 0;
-    const int32_t re = valid ? nptr[n + 1] : 0;
-    const int32_t base = __shfl(rb, 0);
-    const int64_t nlast = min(nnodes, (tile + 1) * SPMV_TILE);
+    int32_t rb[R], re[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t n = tile * TILE + r * 64 + lane;
+      const bool valid = n < nnodes;
+      rb[r] = valid ? nptr[n] : 0;
+      re[r] = valid ? nptr[n + 1] : 0;
+    }
+    const int32_t base = __shfl(rb[0], 0);
+    const int64_t nlast = min(nnodes, (tile + 1) * TILE);
     const int32_t end = nptr[nlast];  // uniform
-    V acc;
-    if constexpr (D == 1) acc = 0.0; else acc = make_double2(0.0, 0.0);
-    for (int32_t c0 = base; c0 < end; c0 += SPMV_CHUNK) {
-      const int32_t c1 = min(end, c0 + SPMV_CHUNK);
-      // phase A: stream blocks [c0, c1), three per lane in flight
-      constexpr int U = 3;
+    V acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (D == 1) acc[r] = 0.0; else acc[r] = make_double2(0.0, 0.0);
+    }
+    for (int32_t c0 = base; c0 < end; c0 += CH) {
+      const int32_t c1 = min(end, c0 + CH);
+      // phase A: stream blocks [c0, c1), U per lane in flight
       for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
         int32_t g[U], m[U];
 #pragma unroll
@@ -139,22 +153,29 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
       }
       __syncthreads();
       // phase B: lane-per-node partial row sums over this chunk
-      const int32_t lo = max(rb, c0), hi = min(re, c1);
-      for (int32_t gq = lo; gq < hi; ++gq) {
-        const V pv = prod[gq - c0];
-        if constexpr (D == 1) acc += pv; else { acc.x += pv.x; acc.y += pv.y; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int32_t lo = max(rb[r], c0), hi = min(re[r], c1);
+        for (int32_t gq = lo; gq < hi; ++gq) {
+          const V pv = prod[gq - c0];
+          if constexpr (D == 1) acc[r] += pv; else { acc[r].x += pv.x; acc[r].y += pv.y; }
+        }
       }
       __syncthreads();
     }
-    if (valid) {
-      if constexpr (D == 1) {
-        y[n] = acc;
-        if (dot_part) dacc += x[n] * acc;
-      } else {
-        *reinterpret_cast<double2*>(y + 2 * n) = acc;
-        if (dot_part) {
-          const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
-          dacc += xv.x * acc.x + xv.y * acc.y;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t n = tile * TILE + r * 64 + lane;
+      if (n < nnodes) {
+        if constexpr (D == 1) {
+          y[n] = acc[r];
+          if (dot_part) dacc += x[n] * acc[r];
+        } else {
+          *reinterpret_cast<double2*>(y + 2 * n) = acc[r];
+          if (dot_part) {
+            const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
+            dacc += xv.x * acc[r].x + xv.y * acc[r].y;
+          }
         }
       }
     }
@@ -421,17 +442,31 @@ __global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double*
 static inline unsigned vec_grid(int64_t n) {
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 512), VEC_BLOCKS));
 }
-static inline unsigned spmv_grid(int64_t nnodes) {
-  return (unsigned)std::min<int64_t>(cdiv(nnodes, SPMV_TILE), SPMV_MAXGRID);
+static inline unsigned spmv_grid_d(int64_t nnodes, int d) {
+  return (unsigned)std::min<int64_t>(cdiv(nnodes, d == 1 ? SPMV_TILE1 : SPMV_TILE2), SPMV_MAXGRID);
 }
 static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
 
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part) {
-  const unsigned grid = spmv_grid(ctx->nnodes);
+  unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
+#ifdef PF_SPMV_SWEEP
+  const char* sh = getenv("PF_SPMV_SHAPE");
+  const int shape = sh ? atoi(sh) : 0;
+#define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
+  if (shape == ID && ctx->d == D_) {                                                                        \
+    grid = (unsigned)std::min<int64_t>(cdiv(ctx->nnodes, 64 * R_), SPMV_MAXGRID);                            \
+    k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part); \
+    PF_LAUNCH_CHECK();                                                                                      \
+    return PF_OK;                                                                                           \
+  }
+  PF_TRY(1, 1, 4, 6, 2560) PF_TRY(2, 1, 2, 9, 1280) PF_TRY(3, 1, 4, 9, 2560) PF_TRY(4, 1, 1, 6, 640) PF_TRY(5, 1, 2, 3, 1280)
+  PF_TRY(1, 2, 2, 3, 1280) PF_TRY(2, 2, 1, 5, 640) PF_TRY(3, 2, 2, 5, 1280) PF_TRY(4, 2, 1, 2, 640) PF_TRY(5, 2, 1, 3, 1024)
+#undef PF_TRY
+#endif
   if (ctx->d == 1)
-    k_spmv<1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
+    k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
   else
-    k_spmv<2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
+    k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -509,7 +544,7 @@ extern "C" int pf_cgcg_reduce(pf_ctx* ctx, double* red_out, double* zero, int64_
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d && red_out && (zero || nzero == 0), "pf_cgcg_reduce: no pattern / NULL argument");
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
-  const int nv = (int)vec_grid(n), ns = (int)spmv_grid(ctx->nnodes);
+  const int nv = (int)vec_grid(n), ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
   k_finalize<<<1, 256, 0, ctx->stream>>>(3, part(ctx, PA_GAMMA), nv, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), nv,
                                          red_out, zero, nzero);
   PF_LAUNCH_CHECK();
@@ -554,7 +589,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   double *r = ctx->cgw, *z = r + n, *p = z + n, *Ap = p + n, *dinv = Ap + n;
   hipStream_t st = ctx->stream;
   const unsigned vg = vec_grid(n);
-  const int ns = (int)spmv_grid(ctx->nnodes);
+  const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
 
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
