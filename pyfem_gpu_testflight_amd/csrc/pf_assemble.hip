@@ -298,10 +298,10 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 // run), so results are bitwise reproducible although the adds are LDS atomics.
 // dynamic LDS: double2 img[npt*maxrow*V/2]
 // ------------------------------------------------------------------------------------------
-struct V3Rec {        // stage B: the lane's visit record (one tile ahead)
-  int4 nd;            // node ids of the incident element
-  uint32_t pk;        // position bytes of those nodes in the lane's row
-  uint32_t meta;      // row offset inside the tile | a << 16
+struct V3Rec {        // stage B: the lane's visit record + the tile's row pointers (one tile ahead)
+  int4 rec;           // {o0, o1, o2, w}: other node ids of the element, w = packed pos/a/ln (pf_pattern.hip)
+  int32_t rp;         // lanes 0..npt: nptr[n0 + lane]
+  int32_t n0;         // first node of the tile
   bool active;
 };
 
@@ -309,12 +309,13 @@ template <int P, bool RHO>
 struct V3Visit {      // stage C: what the quadrature needs (gathers in flight during the previous tile)
   Elem<P> el;
   double rho_e[P];
-  uint32_t pk, meta;
+  uint32_t w;         // packed positions / local index
+  int32_t roff;       // first block of the lane's node inside the tile segment
   bool active;
 };
 
 struct V3Tile {       // wave-uniform tile scalars (scalar loads, two tiles ahead)
-  int32_t vb, ve, base, nblk;
+  int32_t vb, ve, base, nblk, n0;
 };
 
 // NOTE: the pipeline stages are free __forceinline__ functions, not lambdas: hipcc keeps local arrays of
@@ -329,6 +330,7 @@ __device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, int32_t np
   V3Tile T;
   const int64_t tc = min(t, t1 - 1);
   const int64_t na = tc * npt, nb = min(na + npt, nnodes);
+  T.n0 = (int32_t)na;
   T.vb = n2e_ptr[na];
   T.ve = (t < t1) ? n2e_ptr[nb] : T.vb;
   T.base = nptr[na];
@@ -336,40 +338,46 @@ __device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, int32_t np
   return T;
 }
 
-__device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t nvis,
-                                             const int4* __restrict__ vis_nd, const uint32_t* __restrict__ vis_pos,
-                                             const uint32_t* __restrict__ vis_meta) {
+__device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t nvis, int64_t nnodes,
+                                             const int4* __restrict__ vis_rec, const int32_t* __restrict__ nptr) {
   V3Rec B;
   const int32_t jj = T.vb + lane;
   B.active = jj < T.ve;
-  const int32_t jc = min(jj, nvis - 1);
-  B.nd = vis_nd[jc];
-  B.pk = vis_pos[jc];
-  B.meta = vis_meta[jc];
+  B.n0 = T.n0;
+  B.rec = vis_rec[min(jj, nvis - 1)];
+  B.rp = nptr[min((int64_t)T.n0 + lane, nnodes)];
   return B;
 }
 
 template <int P, bool RHO>
 __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __restrict__ X,
                                               const double* __restrict__ rho, V3Visit<P, RHO>& C) {
-  C.pk = B.pk;
-  C.meta = B.meta;
+  const uint32_t w = (uint32_t)B.rec.w;
+  const int a = (int)((w >> 24) & 3), ln = (int)((w >> 26) & 15);
+  C.w = w;
   C.active = B.active;
-  const double2 p0 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.x);
-  const double2 p1 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.y);
-  const double2 p2 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.z);
+  C.roff = __shfl(B.rp, ln) - __shfl(B.rp, 0);
+  const int32_t n = B.n0 + ln;  // the lane's own node
+  int32_t nd[4];
+  nd[0] = (a == 0) ? n : B.rec.x;
+  nd[1] = (a == 1) ? n : ((a < 1) ? B.rec.x : B.rec.y);
+  nd[2] = (a == 2) ? n : ((a < 2) ? B.rec.y : B.rec.z);
+  nd[3] = (a == 3) ? n : B.rec.z;
+  const double2 p0 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[0]);
+  const double2 p1 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[1]);
+  const double2 p2 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[2]);
   C.el.x[0] = p0.x; C.el.y[0] = p0.y;
   C.el.x[1] = p1.x; C.el.y[1] = p1.y;
   C.el.x[2] = p2.x; C.el.y[2] = p2.y;
   if constexpr (P == 4) {
-    const double2 p3 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)B.nd.w);
+    const double2 p3 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[3]);
     C.el.x[3] = p3.x; C.el.y[3] = p3.y;
   }
   if constexpr (RHO) {
-    C.rho_e[0] = rho[B.nd.x];
-    C.rho_e[1] = rho[B.nd.y];
-    C.rho_e[2] = rho[B.nd.z];
-    if constexpr (P == 4) C.rho_e[3] = rho[B.nd.w];
+    C.rho_e[0] = rho[nd[0]];
+    C.rho_e[1] = rho[nd[1]];
+    C.rho_e[2] = rho[nd[2]];
+    if constexpr (P == 4) C.rho_e[3] = rho[nd[3]];
   } else {
 #pragma unroll
     for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
@@ -395,8 +403,8 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
     for (int32_t q = lane; q < nblk; q += 64) img[k * plane + q] = 0.0;
 
   if (Cuse.active) {
-    const int a = (int)(Cuse.meta >> 16);
-    const int roff = (int)(Cuse.meta & 0xffff);
+    const int a = (int)((Cuse.w >> 24) & 3);
+    const int roff = Cuse.roff;
     double v[P][V];
     if constexpr (ABL & 1) {
 #pragma unroll
@@ -408,7 +416,7 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
     }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      const int blk = roff + (int)((Cuse.pk >> (8 * b)) & 255);
+      const int blk = roff + (int)((Cuse.w >> (6 * b)) & 63);
 #pragma unroll
       for (int k = 0; k < V; ++k)
         __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -456,9 +464,7 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int32_t* __restrict__ n2e_ptr,
-                                                    const int4* __restrict__ vis_nd,
-                                                    const uint32_t* __restrict__ vis_pos,
-                                                    const uint32_t* __restrict__ vis_meta, int32_t nvis, int32_t strided,
+                                                    const int4* __restrict__ vis_rec, int32_t nvis, int32_t strided,
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1, double* __restrict__ trash) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -477,14 +483,14 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   V3Tile T0 = v3_load_tile(t0, t1, npt, nnodes, nptr, n2e_ptr);
   V3Tile T1 = v3_load_tile(t0 + tstride, t1, npt, nnodes, nptr, n2e_ptr);
   V3Tile T2 = v3_load_tile(t0 + 2 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Rec Ba = v3_load_rec(T0, lane, nvis, vis_nd, vis_pos, vis_meta);
-  V3Rec Bb = v3_load_rec(T1, lane, nvis, vis_nd, vis_pos, vis_meta);
+  V3Rec Ba = v3_load_rec(T0, lane, nvis, nnodes, vis_rec, nptr);
+  V3Rec Bb = v3_load_rec(T1, lane, nvis, nnodes, vis_rec, nptr);
   V3Visit<P, RHO> Ca, Cb;
   v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "five stores are younger than it" (back edge: vmcnt(5) is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
-  asm volatile("" ::"v"(Bb.nd.x), "v"(Bb.nd.y), "v"(Bb.nd.z), "v"(Bb.nd.w), "v"(Bb.pk), "v"(Bb.meta));
+  asm volatile("" ::"v"(Bb.rec.x), "v"(Bb.rec.y), "v"(Bb.rec.z), "v"(Bb.rec.w), "v"(Bb.rp));
   asm volatile("" ::"v"(Ca.el.x[0]), "v"(Ca.el.x[1]), "v"(Ca.el.x[2]), "v"(Ca.el.y[0]), "v"(Ca.el.y[1]), "v"(Ca.el.y[2]));
   if constexpr (P == 4) asm volatile("" ::"v"(Ca.el.x[3]), "v"(Ca.el.y[3]));
   if constexpr (RHO) asm volatile("" ::"v"(Ca.rho_e[0]), "v"(Ca.rho_e[1]), "v"(Ca.rho_e[2]), "v"(Ca.rho_e[P - 1]));
@@ -496,12 +502,12 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
     const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Bb, X, pr.rho, Cb);
-    Ba = v3_load_rec(T2, lane, nvis, vis_nd, vis_pos, vis_meta);
+    Ba = v3_load_rec(T2, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
     v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
-    Bb = v3_load_rec(T3, lane, nvis, vis_nd, vis_pos, vis_meta);
+    Bb = v3_load_rec(T3, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
     T0 = T2; T1 = T3; T2 = T4;
   }
@@ -784,8 +790,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     if (g3 && atoi(g3) > 0) wpc = atoi(g3);
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
     hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->npt, ctx->max_row_blocks, ctx->X,
-                       ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_nd),
-                       reinterpret_cast<const uint32_t*>(ctx->n2e_pos), ctx->vis_meta, (int32_t)(ctx->nelems * ctx->P), (int32_t)!(getenv("PF_TILE_ORDER") && getenv("PF_TILE_ORDER")[0] == 'c'), pr, out0, out1,
+                       ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), (int32_t)(ctx->nelems * ctx->P), (int32_t)!(getenv("PF_TILE_ORDER") && getenv("PF_TILE_ORDER")[0] == 'c'), pr, out0, out1,
                        ctx->scal + (size_t)PF_NPART * PF_NPART_ARRAYS /* 16 spare doubles: trash line */);
     PF_LAUNCH_CHECK();
     return PF_OK;

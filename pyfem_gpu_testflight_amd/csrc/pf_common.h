@@ -34,8 +34,7 @@ struct pf_ctx {
   uint8_t* n2e_pos = nullptr;  // (nelems*P*4) 4 bytes per incident pair j; byte b (< P):
                                //   position of conn[e,b] in row n of the node graph
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
-  void* vis_nd = nullptr;      // (nelems*P) int4: node ids of the element of incident pair jj (visit order)
-  uint32_t* vis_meta = nullptr;  // (nelems*P) row offset of the pair's node inside its tile | local index a << 16
+  void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
   int npt = 0;                 // nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 

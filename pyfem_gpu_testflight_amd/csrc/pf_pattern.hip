@@ -130,28 +130,28 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
   }
 }
 
-// visit-ordered element records for the assembly kernel: for the j-th incident pair of node n
-// (global index jj) the element's node ids and  meta = roff | a<<16, where roff is the first block
-// of node n's row relative to the first row of its npt-node tile and a the local index of n
+// visit-ordered element records for the assembly kernel, ONE 16-byte load per incident pair jj of
+// node n:  {o0, o1, o2, w}  where o* are the element's node ids other than n (ascending local index) and
+//   w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | (n mod npt)<<26
+// (pos_b = position of element node b in n's row, a = local index of n in the element).
 template <int P>
 __global__ void k_build_visits(int64_t nnodes, int npt, const int32_t* __restrict__ conn,
-                               const int32_t* __restrict__ nptr, const int32_t* __restrict__ n2e_ptr,
-                               const int32_t* __restrict__ n2e, int4* __restrict__ vis_nd,
-                               uint32_t* __restrict__ vis_meta) {
+                               const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                               const uint8_t* __restrict__ n2e_pos, int4* __restrict__ vis_rec) {
   int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (n >= nnodes) return;
-  const uint32_t roff = (uint32_t)(nptr[n] - nptr[(n / npt) * npt]);
   for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
     const int32_t ea = n2e[jj];
     const int32_t e = ea / P;
-    const uint32_t a = (uint32_t)(ea - e * P);
-    int4 nd;
-    nd.x = conn[(int64_t)e * P + 0];
-    nd.y = conn[(int64_t)e * P + 1];
-    nd.z = conn[(int64_t)e * P + 2];
-    nd.w = (P == 4) ? conn[(int64_t)e * P + (P - 1)] : 0;
-    vis_nd[jj] = nd;
-    vis_meta[jj] = roff | (a << 16);
+    const int a = ea - e * P;
+    int32_t o[3] = {0, 0, 0};
+    int k = 0;
+    uint32_t w = ((uint32_t)a << 24) | ((uint32_t)(n & (npt - 1)) << 26);
+    for (int b = 0; b < P; ++b) {
+      if (b != a) o[k++] = conn[(int64_t)e * P + b];
+      w |= (uint32_t)n2e_pos[(int64_t)jj * 4 + b] << (6 * b);
+    }
+    vis_rec[jj] = make_int4(o[0], o[1], o[2], (int32_t)w);
   }
 }
 
@@ -232,8 +232,7 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->n2e_pos);
   pf_free(ctx->diagpos);
   pf_free(ctx->e2pos);
-  pf_free(ctx->vis_nd);
-  pf_free(ctx->vis_meta);
+  pf_free(ctx->vis_rec);
   ctx->npt = 0;
   ctx->d = 0;
   ctx->nblocks = 0;
@@ -392,12 +391,11 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   ctx->npt = ctx->max_valence <= 4 ? 16 : ctx->max_valence <= 8 ? 8 : ctx->max_valence <= 16 ? 4
            : ctx->max_valence <= 32 ? 2 : ctx->max_valence <= 64 ? 1 : 0;
   if (ctx->npt) {
-    PF_HIP(hipMalloc(&ctx->vis_nd, sizeof(int4) * (size_t)total));
-    PF_HIP(hipMalloc(&ctx->vis_meta, sizeof(uint32_t) * (size_t)total));
+    PF_HIP(hipMalloc(&ctx->vis_rec, sizeof(int4) * (size_t)total));
     if (ctx->P == 4)
-      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_meta);
+      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     else
-      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, (int4*)ctx->vis_nd, ctx->vis_meta);
+      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     PF_LAUNCH_CHECK();
   }
   ctx->d = d;
