@@ -90,6 +90,13 @@ int pf_assemble_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const d
  * Kvals = r0^2*stiffness + mass, Rvals = mass (either may be NULL).  d must be 1.        */
 int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
 
+/* Sensitivity of phi^T K(rho) psi w.r.t. the nodal density: LinearElasticity._compute_K_dv_sens
+ * (pyfem.py:1873-1920) with _update_material_property_deriv (:1948-1973), fused -- the (E,D,D,P)
+ * tensor Ke_deriv is never formed.  rho float64[nnodes] (required), phi/psi float64[2*nnodes],
+ * out float64[nnodes].  compliance_grad (pyfem.py:1837-1848) is -pf_sens(rho, u, u).           */
+int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
+                         const double* phi, const double* psi, double* out);
+
 /* Element matrices to memory, (nelems, D, D) row-major -- model.Ke_mat / model.Re readers
  * (tests; examples/SciTech2023/performance/performance_test.py:52).                       */
 int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,

@@ -188,6 +188,34 @@ def main():
         pr = np.random.rand(x.shape[0])
         print(f"{name}: nnz={model.K.nnz}  p.rho = {pr.dot(out['rho'])!r}")
 
+    # --- sensitivity pass (tests/test_elasticity.py:68-104: phi^T dK/drho psi, p = 5) --------------
+    for name, nx, ny, etype in [("sens24x17_quad", 24, 17, "quad"), ("sens21x16_tri", 21, 16, "tri")]:
+        c = pyfem.ProblemCreator(nnodes_x=nx, nnodes_y=ny, element_type=etype)
+        conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+        rng = np.random.RandomState(3)
+        X = X + (0.01 * (rng.rand(*X.shape) - 0.5) if etype == "quad" else 0.0)
+        q, b = _qb(pyfem, etype)
+        model = pyfem.LinearElasticity(X, conn, dof_fixed, None, nodal_force, q, b, p=5.0)
+        np.random.seed(0)
+        nnodes = X.shape[0]
+        phi = np.random.rand(2 * nnodes)
+        psi = np.random.rand(2 * nnodes)
+        rho = np.random.rand(nnodes)
+        sens = model._compute_K_dv_sens(rho, phi, psi).copy()
+        K = model.compute_jacobian(rho)
+        rhs = model.compute_rhs().copy()
+        Kbc, rhs_bc = model.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+        from scipy.sparse.linalg import spsolve
+        u = spsolve(Kbc.tocsc(), rhs_bc)
+        grad = model.compliance_grad(rho, u).copy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), X=X, conn=conn.astype(np.int32),
+                            dof_fixed=np.asarray(dof_fixed, dtype=np.int32),
+                            force_nodes=np.array(list(nodal_force.keys()), dtype=np.int32),
+                            force_vals=np.array(list(nodal_force.values()), dtype=float),
+                            rho=rho, phi=phi, psi=psi, sens=sens, u=u, compliance=np.float64(rhs_bc.dot(u)),
+                            compliance_grad=grad, p=np.float64(5.0))
+        print(f"{name}: |sens|={np.linalg.norm(sens):.13e} c={rhs_bc.dot(u):.13e}")
+
     # --- mesh generator pins (ProblemCreator, pyfem.py:2469-2520, 2728-2773) -------------
     out = {}
     for etype in ("quad", "tri"):

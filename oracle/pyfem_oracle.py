@@ -159,6 +159,32 @@ def elasticity_Ke(X, conn, etype, rho=None, E=10.0, nu=0.3, p=0.0):
     return np.einsum("iq,q,iqnj,iq,nm,iqmk->ijk", detJ, wq, Be, Cq, C0, Be, optimize=True)
 
 
+def elasticity_K_dv_sens(X, conn, etype, rho, phi, psi, E=10.0, nu=0.3, p=0.0):
+    """d(phi^T K(rho) psi)/d rho  (nodal), ref: pyfem.py:1873-1920 with the RAMP derivative
+    (1+p)/(1+p(1-rho_q))^2 N[q,o] of :1948-1973; einsum strings of :1900 and :1912."""
+    _, wq = quadrature(etype)
+    N, dN = shape_tables(etype)
+    detJ, Ngrad = geometry(X, conn, dN)
+    nE, P = conn.shape
+    Q = wq.size
+    rho = np.asarray(rho, dtype=float)
+    rho_q = np.einsum("jl,il->ij", N, rho[conn])
+    Cqderiv = np.einsum("ql,iq->iql", N, (1 + p) / (1 + p * (1 - rho_q)) ** 2)
+    Be = np.zeros((nE, Q, 3, 2 * P))
+    Be[:, :, 0, 0::2] = Ngrad[..., 0]
+    Be[:, :, 1, 1::2] = Ngrad[..., 1]
+    Be[:, :, 2, 0::2] = Ngrad[..., 1]
+    Be[:, :, 2, 1::2] = Ngrad[..., 0]
+    C0 = plane_stress_C0(E, nu)
+    Ke_deriv = np.einsum("iq,q,iqnj,iqo,nm,iqmk->ijko", detJ, wq, Be, Cqderiv, C0, Be, optimize=True)
+    conn_dof = create_conn_dof(conn, 2)
+    inner = np.einsum("ij,ik,ijko->io", phi[conn_dof], psi[conn_dof], Ke_deriv)
+    out = np.zeros(X.shape[0])
+    for i in range(P):
+        np.add.at(out, conn[:, i], inner[:, i])
+    return out
+
+
 def helmholtz_Ke_Re(X, conn, etype, r0):
     """Re = sum_q detJ w N N^T ;  Ke = r0^2 sum_q detJ w gradN.gradN^T + Re
     (ref: pyfem.py:2127-2177)."""

@@ -646,6 +646,75 @@ __global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes,
 }
 
 // ------------------------------------------------------------------------------------------
+// Sensitivity pass:  out[o] = d(phi^T K(rho) psi)/d rho_o        (pyfem.py:1873-1920, 1948-1973)
+// The reference materialises dKe/drho as an (E, D, D, P) tensor (2 KB per quad) and contracts it
+// with phi, psi.  Here: inner[e,o] = sum_q detJ w N_o(q) r'(rho_q) (B phi_e)^T C0 (B psi_e), with
+// r' = (1+p)/(1+p(1-rho_q))^2, evaluated by the owner of node o and summed over its incident
+// elements in ascending order in a register: one lane per node, no scatter, no atomics, no tensor.
+// ------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const double* __restrict__ X,
+                                                         const int32_t* __restrict__ n2e_ptr,
+                                                         const int4* __restrict__ vis_rec, ElasticityParams pr,
+                                                         const double* __restrict__ phi,
+                                                         const double* __restrict__ psi, double* __restrict__ out) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  double acc = 0.0;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int4 rec = vis_rec[jj];
+    const int a = (int)(((uint32_t)rec.w >> 24) & 3);
+    int32_t nd[4];
+    nd[0] = (a == 0) ? (int32_t)n : rec.x;
+    nd[1] = (a == 1) ? (int32_t)n : ((a < 1) ? rec.x : rec.y);
+    nd[2] = (a == 2) ? (int32_t)n : ((a < 2) ? rec.y : rec.z);
+    nd[3] = (a == 3) ? (int32_t)n : rec.z;
+    Elem<P> el;
+    double rho_e[P], fx[P], fy[P], gx[P], gy[P];
+#pragma unroll
+    for (int b = 0; b < P; ++b) {
+      const double2 xy = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[b]);
+      el.x[b] = xy.x;
+      el.y[b] = xy.y;
+      rho_e[b] = pr.rho[nd[b]];
+      const double2 f = *reinterpret_cast<const double2*>(phi + 2 * (int64_t)nd[b]);
+      const double2 g = *reinterpret_cast<const double2*>(psi + 2 * (int64_t)nd[b]);
+      fx[b] = f.x; fy[b] = f.y; gx[b] = g.x; gy[b] = g.y;
+    }
+    Own own = make_own<P>(a);
+    auto point = [&](double det, double w, const double* N, const double* Nx, const double* Ny) {
+      double rq = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        rq = fma(N[b], rho_e[b], rq);
+        e1 = fma(Nx[b], fx[b], e1);                       // strains of phi: B phi_e  (pyfem.py:1992-1997)
+        e2 = fma(Ny[b], fy[b], e2);
+        e3 = fma(Ny[b], fx[b], fma(Nx[b], fy[b], e3));
+        h1 = fma(Nx[b], gx[b], h1);                       // strains of psi
+        h2 = fma(Ny[b], gy[b], h2);
+        h3 = fma(Ny[b], gx[b], fma(Nx[b], gy[b], h3));
+      }
+      const double t = fma(pr.p, 1.0 - rq, 1.0);
+      const double dr = (1.0 + pr.p) / (t * t);           // RAMP derivative, pyfem.py:1968
+      const double eCe = pr.c11 * (e1 * h1 + e2 * h2) + pr.c12 * (e1 * h2 + e2 * h1) + pr.c33 * e3 * h3;
+      acc = fma(det * w * dr * own.Na, eCe, acc);
+    };
+    double det, Nx[P], Ny[P], N[P];
+    if constexpr (P == 4) {
+      const QuadEdges ed = quad_edges(el);
+      quad_point<0>(ed, own, det, Nx, Ny, N); point(det, 1.0, N, Nx, Ny);
+      quad_point<1>(ed, own, det, Nx, Ny, N); point(det, 1.0, N, Nx, Ny);
+      quad_point<2>(ed, own, det, Nx, Ny, N); point(det, 1.0, N, Nx, Ny);
+      quad_point<3>(ed, own, det, Nx, Ny, N); point(det, 1.0, N, Nx, Ny);
+    } else {
+      tri_point(el, own, det, Nx, Ny, N);
+      point(det, 0.5, N, Nx, Ny);
+    }
+  }
+  out[n] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // ATOMIC scatter (elasticity only): one lane per element
 // ------------------------------------------------------------------------------------------
 template <int P, bool RHO>
@@ -871,6 +940,22 @@ extern "C" int pf_element_matrices_helmholtz2d(pf_ctx* ctx, double r0, double* K
     k_element_matrices<4, Helmholtz<4>, false><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, Re_out);
   else
     k_element_matrices<3, Helmholtz<3>, false><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, Re_out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho, const double* phi,
+                                    const double* psi, double* out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d == 2, "pf_sens_elasticity2d: pattern must be built with ndof_per_node = 2");
+  PF_REQUIRE(rho && phi && psi && out, "pf_sens_elasticity2d: NULL argument");
+  PF_REQUIRE(ctx->vis_rec, "pf_sens_elasticity2d: node valence above 64 is not supported");
+  ElasticityParams pr = make_elasticity(E, nu, p, rho);
+  const unsigned grid = (unsigned)cdiv(ctx->nnodes, 128);
+  if (ctx->P == 4)
+    k_sens_elasticity<4><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
+  else
+    k_sens_elasticity<3><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -116,6 +116,12 @@ class HipContext:
         self._call("pf_assemble_helmholtz2d", r0, _ptr(K), _ptr(R))
         return K, R
 
+    def sens_elasticity(self, E, nu, p, rho, phi, psi):
+        out = self.empty(self.nnodes)
+        self._sync_stream()
+        self._call("pf_sens_elasticity2d", E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        return out
+
     def element_matrices_elasticity(self, E, nu, p, rho=None):
         D = self.P * 2
         out = self.empty(self.nelems * D * D)

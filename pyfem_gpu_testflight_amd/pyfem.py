@@ -16,8 +16,8 @@ the library or a GPU the constructors raise.
 
 Scope: 2-D 4-node quads and 3-node triangles; LinearElasticity (plane
 stress, RAMP density), Helmholtz filter, Assembler.solve.  3-D elements, LinearPoisson,
-NonlinearPoisson2D, A2DWrapper, the sensitivity pass and complex-step dtypes are outside the
-accelerated path and raise NotImplementedError here.
+NonlinearPoisson2D, A2DWrapper and complex-step dtypes are outside the accelerated path and raise
+NotImplementedError here.
 """
 import numpy as np
 
@@ -270,11 +270,26 @@ class LinearElasticity(ModelBase):
         """ref: pyfem.py:1862-1870."""
         return np.ones(self.nnodes) / self.nnodes
 
+    @time_this
     def compliance_grad(self, rho, u):
-        raise NotImplementedError("sensitivity pass (_compute_K_dv_sens, pyfem.py:1873-1920) is a 'next' row "
-                                  "(SURVEY.md 8f, f2) and not on the accelerated path yet")
+        """ref: pyfem.py:1837-1848."""
+        return -self._compute_K_dv_sens(rho, u, u)
 
-    _compute_K_dv_sens = compliance_grad
+    @time_this
+    def _compute_K_dv_sens(self, rho, phi, psi):
+        """d(phi^T K psi)/d rho, ref: pyfem.py:1873-1920 -- one fused kernel, Ke_deriv is never formed.
+        numpy in -> numpy out; device tensors in -> device tensor out."""
+        torch = self.hctx.torch
+        on_device = isinstance(rho, torch.Tensor)
+        if not on_device and not hasattr(rho, "__len__"):
+            rho = np.ones(self.nnodes) * rho
+        rho_d = self._rho_device(rho)
+        if rho_d is None:
+            rho_d = self.hctx.to_device(np.ones(self.nnodes), torch.float64)
+        phi_d = phi if isinstance(phi, torch.Tensor) else self.hctx.to_device(np.asarray(phi, dtype=float), torch.float64)
+        psi_d = psi if isinstance(psi, torch.Tensor) else self.hctx.to_device(np.asarray(psi, dtype=float), torch.float64)
+        out = self.hctx.sens_elasticity(self.E, self.nu, self.p, rho_d, phi_d, psi_d)
+        return out if on_device else out.cpu().numpy()
 
 
 class Helmholtz(ModelBase):

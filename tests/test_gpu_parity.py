@@ -352,3 +352,25 @@ def test_isolated_nodes_and_kernel_variants(pf, orc):
     finally:
         del os.environ["PF_GATHER_IMPL"]
     assert float((a - bvals).abs().max()) <= 1e-14 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri")])
+def test_sensitivity_pass(pf, orc, name, etype):
+    """_compute_K_dv_sens / compliance / compliance_grad against the reference's own numbers
+    (tests/test_elasticity.py:68-132 checks them by complex step, which the fp64-real kernels cannot run)."""
+    g = load(name)
+    q, b = _qb(pf, etype)
+    model = pf.LinearElasticity(g["X"], g["conn"], g["dof_fixed"], None, force_dict(g), q, b, p=float(g["p"]))
+    s = model._compute_K_dv_sens(g["rho"], g["phi"], g["psi"])
+    assert s.shape == g["sens"].shape and relmax(s, g["sens"]) < K_TOL
+    c, u = model.compliance(g["rho"], solver="cg")
+    assert abs(c / float(g["compliance"]) - 1) < 1e-8 and relmax(u, g["u"]) < U_TOL
+    grad = model.compliance_grad(g["rho"], u)
+    assert relmax(grad, g["compliance_grad"]) < 1e-7
+    # directional derivative of phi^T K psi by central differences on the HIP assembly itself
+    rng = np.random.RandomState(1)
+    dv = rng.rand(g["rho"].size)
+    h = 1e-6
+    f = lambda r: g["phi"].dot(model.compute_jacobian(r).dot(g["psi"]))
+    fd = (f(g["rho"] + h * dv) - f(g["rho"] - h * dv)) / (2 * h)
+    assert abs(fd / dv.dot(s) - 1) < 1e-6

@@ -106,3 +106,14 @@ def test_mesh_generator_matches_reference():
         assert list(force.keys()) == list(g[f"{etype}_force_nodes"]) and np.array_equal(
             np.array(list(force.values())), g[f"{etype}_force_vals"])
         assert np.array_equal(orc.helmholtz_input(6, 4), g[f"{etype}_helm_x"])
+
+
+@pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri")])
+def test_sensitivity_matches_reference(name, etype):
+    """_compute_K_dv_sens and compliance_grad as the reference itself computed them (p = 5)."""
+    g = load(name)
+    X, conn = g["X"], g["conn"].astype(np.int64)
+    s = orc.elasticity_K_dv_sens(X, conn, etype, g["rho"], g["phi"], g["psi"], p=float(g["p"]))
+    assert relmax(s, g["sens"]) < 1e-13
+    grad = -orc.elasticity_K_dv_sens(X, conn, etype, g["rho"], g["u"], g["u"], p=float(g["p"]))
+    assert relmax(grad, g["compliance_grad"]) < 1e-12
