@@ -97,6 +97,20 @@ int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals
 int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
                          const double* phi, const double* psi, double* out);
 
+/* LinearPoisson, 2-D (pyfem.py:934-1329):
+ *   pf_assemble_poisson2d      compute_jacobian (:1006-1030): Ke = sum_q kappa_q detJ w gradN gradN^T with
+ *                              kappa_q = RAMP(rho_q) (:1279-1301), fused with the scatter; d must be 1
+ *   pf_quad_points             Xq (nelems, Q, 2): the points compute_rhs evaluates the Python gfunc at (:1160)
+ *   pf_poisson_rhs             compute_rhs (:997-1004): gq = gfunc(Xq) (nelems, Q) -> rhs (nnodes), including
+ *                              the reference's column quirk for triangles (:873)
+ *   pf_sens_poisson2d          _compute_K_dv_sens (:1240-1276), fused like the elasticity one           */
+int pf_assemble_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Kvals);
+int pf_element_matrices_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Ke_out);
+int pf_quad_points(pf_ctx* ctx, double* Xq_out);
+int pf_poisson_rhs(pf_ctx* ctx, const double* gq, double* rhs_out);
+int pf_sens_poisson2d(pf_ctx* ctx, double p, const double* rho, const double* phi, const double* psi,
+                      double* out);
+
 /* Element matrices to memory, (nelems, D, D) row-major -- model.Ke_mat / model.Re readers
  * (tests; examples/SciTech2023/performance/performance_test.py:52).                       */
 int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,

@@ -216,6 +216,44 @@ def main():
                             compliance_grad=grad, p=np.float64(5.0))
         print(f"{name}: |sens|={np.linalg.norm(sens):.13e} c={rhs_bc.dot(u):.13e}")
 
+    # --- LinearPoisson (tests/test_linear_poisson.py:11-40 and :57-113) -----------------------------
+    def gfunc(x):
+        _x = x[..., 0]
+        _y = x[..., 1]
+        return _x * (_x - 5.0) * (_x - 10.0) * _y * (_y - 4.0)
+
+    from scipy.sparse.linalg import spsolve
+    for name, nx, ny, distort, p in [("poi32_quad", 32, 32, 0.0, 0.0), ("poi17x12_quad_ramp", 17, 12, 0.02, 5.0)]:
+        c = pyfem.ProblemCreator(nnodes_x=nx, nnodes_y=ny)
+        conn, X, dof_fixed = c.create_poisson_problem()
+        rng = np.random.RandomState(8)
+        X = X + distort * (rng.rand(*X.shape) - 0.5)
+        q, b = _qb(pyfem, "quad")
+        vals = None if p == 0.0 else 0.1 * rng.rand(len(dof_fixed))
+        model = pyfem.LinearPoisson(X, conn, dof_fixed, vals, q, b, gfunc, p=p)
+        rho = np.ones(X.shape[0]) if p == 0.0 else 0.1 + 0.9 * rng.rand(X.shape[0])
+        K = model.compute_jacobian(rho)
+        rhs = model.compute_rhs().copy()
+        out = dict(X=X, conn=conn.astype(np.int32), dof_fixed=np.asarray(dof_fixed, dtype=np.int32), rho=rho,
+                   p=np.float64(p), Ke0=model.Ke_mat[0].copy(), rhs=rhs.copy())
+        if vals is not None:
+            out["fixed_vals"] = vals
+        out.update(_csr(K, "K"))
+        Kbc, rhs_bc = model.apply_dirichlet_bcs(K.copy(), rhs.copy(), enforce_symmetric_K=True)
+        out["rhs_bc"] = rhs_bc.copy()
+        u = spsolve(Kbc.tocsc(), rhs_bc)
+        out["u"] = u
+        np.random.seed(0)
+        phi, psi = np.random.rand(X.shape[0]), np.random.rand(X.shape[0])
+        out["phi"], out["psi"] = phi, psi
+        out["sens"] = model._compute_K_dv_sens(rho, phi, psi).copy()
+        out["compliance"] = np.float64(rhs_bc.dot(u))
+        out["compliance_grad"] = model.compliance_grad(rho, u).copy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        np.random.seed(123)
+        pr = np.random.rand(u.shape[0])
+        print(f"{name}: nnz={K.nnz} p.u = {pr.dot(u)!r}" + (" (survey: -7082.301628403809)" if name == "poi32_quad" else ""))
+
     # --- mesh generator pins (ProblemCreator, pyfem.py:2469-2520, 2728-2773) -------------
     out = {}
     for etype in ("quad", "tri"):

@@ -185,6 +185,49 @@ def elasticity_K_dv_sens(X, conn, etype, rho, phi, psi, E=10.0, nu=0.3, p=0.0):
     return out
 
 
+def poisson_Ke(X, conn, etype, rho=None, p=0.0):
+    """Ke = sum_q kappa_q detJ w gradN gradN^T, kappa_q = RAMP(rho_q); `kappa0` of the reference is stored
+    but never applied (ref: pyfem.py:1176-1187, 1279-1301)."""
+    _, wq = quadrature(etype)
+    N, dN = shape_tables(etype)
+    detJ, Ngrad = geometry(X, conn, dN)
+    rho = np.ones(X.shape[0]) if rho is None else np.asarray(rho, dtype=float)
+    kappa_q = ramp(np.einsum("jl,il->ij", N, rho[conn]), p)
+    return np.einsum("iq,iq,q,iqjl,iqkl->ijk", kappa_q, detJ, wq, Ngrad, Ngrad, optimize=True)
+
+
+def poisson_rhs(X, conn, etype, gfunc):
+    """Element rhs and its scatter WITH the reference's quirks (ref: pyfem.py:1131-1136, 861-875):
+    the einsum indexes N[j,k] with j on the quadrature axis (right only because N is symmetric for the
+    2x2 rule on quads) and _assemble_rhs loops over range(nquads) columns, not range(P)."""
+    _, wq = quadrature(etype)
+    N, dN = shape_tables(etype)
+    detJ, _ = geometry(X, conn, dN)
+    Xq = np.einsum("jl,ilk->ijk", N, X[conn])  # utils.py:204-221
+    fun = gfunc(Xq)
+    rhs_e = np.zeros((conn.shape[0], conn.shape[1]))
+    rhs_e[...] = np.einsum("ik,k,jk,ik->ij", detJ, wq, N, fun, optimize=True)
+    rhs = np.zeros(X.shape[0])
+    for n in range(wq.size):
+        np.add.at(rhs, conn[:, n], rhs_e[:, n])
+    return rhs
+
+
+def poisson_K_dv_sens(X, conn, etype, rho, phi, psi, p=0.0):
+    """d(phi^T K psi)/d rho for LinearPoisson (ref: pyfem.py:1240-1276, 1303-1329)."""
+    _, wq = quadrature(etype)
+    N, dN = shape_tables(etype)
+    detJ, Ngrad = geometry(X, conn, dN)
+    rho_q = np.einsum("jl,il->ij", N, np.asarray(rho, dtype=float)[conn])
+    kd = np.einsum("ql,iq->iql", N, (1 + p) / (1 + p * (1 - rho_q)) ** 2)
+    Ke_deriv = np.einsum("iqo,iq,q,iqjl,iqkl->ijko", kd, detJ, wq, Ngrad, Ngrad, optimize=True)
+    inner = np.einsum("ij,ik,ijko->io", phi[conn], psi[conn], Ke_deriv)
+    out = np.zeros(X.shape[0])
+    for i in range(conn.shape[1]):
+        np.add.at(out, conn[:, i], inner[:, i])
+    return out
+
+
 def helmholtz_Ke_Re(X, conn, etype, r0):
     """Re = sum_q detJ w N N^T ;  Ke = r0^2 sum_q detJ w gradN.gradN^T + Re
     (ref: pyfem.py:2127-2177)."""

@@ -34,6 +34,11 @@ SIGNATURES = {
     "pf_assemble_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, C.c_int, _vp]),
     "pf_assemble_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_sens_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "pf_assemble_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_element_matrices_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_quad_points": (C.c_int, [_vp, _vp]),
+    "pf_poisson_rhs": (C.c_int, [_vp, _vp, _vp]),
+    "pf_sens_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp, _vp, _vp]),
     "pf_element_matrices_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp]),
     "pf_element_matrices_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_vals_to_csr": (C.c_int, [_vp, _vp, _vp]),

@@ -240,6 +240,38 @@ struct Helmholtz {
   }
 };
 
+struct PoissonParams {
+  double p;           // RAMP penalisation of the conductivity
+  const double* rho;  // nodal density or nullptr
+};
+
+// LinearPoisson: Ke = sum_q kappa_q detJ w gradN gradN^T, kappa_q = RAMP(rho_q)   (pyfem.py:1176-1187, 1279-1301;
+// the reference stores kappa0 but never applies it)
+template <int P, bool RHO>
+struct Poisson {
+  static constexpr int V = 1;
+  static constexpr int NS = 1;
+  using Params = PoissonParams;
+  __device__ __forceinline__ static void point(const Params& pr, double det, double w, const double N[P],
+                                               const double Nx[P], const double Ny[P], const double rho_e[P],
+                                               const Own& own, double S[P][NS]) {
+    double s = det * w;
+    if constexpr (RHO) {
+      double rq = N[0] * rho_e[0];
+#pragma unroll
+      for (int l = 1; l < P; ++l) rq = fma(N[l], rho_e[l], rq);
+      s *= rq * fast_rcp(fma(pr.p, 1.0 - rq, 1.0));
+    }
+    const double gx = s * own.Nxa, gy = s * own.Nya;
+#pragma unroll
+    for (int b = 0; b < P; ++b) S[b][0] = fma(gx, Nx[b], fma(gy, Ny[b], S[b][0]));
+  }
+  __device__ __forceinline__ static void finish(const Params&, const double S[P][NS], double v[P][V]) {
+#pragma unroll
+    for (int b = 0; b < P; ++b) v[b][0] = S[b][0];
+  }
+};
+
 // rows of Ke owned by local node a, from element coordinates (and nodal densities) in registers
 template <int P, class Phys, bool RHO>
 __device__ __forceinline__ void element_rows_core(const typename Phys::Params& pr, const Elem<P>& el,
@@ -395,7 +427,7 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
                                         double* __restrict__ out0, double* __restrict__ out1,
                                         double* __restrict__ trash) {
   constexpr int V = Phys::V;
-  constexpr int VH = V / 2;
+  constexpr int VH = (V == 4) ? 2 : 1;  // 16-byte pieces (d=2) or entries (d=1) per coupling
   const int32_t nblk = Tcur.nblk;
   // zero the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
 #pragma unroll
@@ -433,7 +465,7 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
   const bool any = np > 0;
   double2* d4 = any ? reinterpret_cast<double2*>(out0) + 2 * base : reinterpret_cast<double2*>(trash);
   double* d0 = any ? out0 + base : trash;
-  double* d1 = any ? out1 + base : trash + 1;
+  double* d1 = (any && V == 2) ? out1 + base : trash + 1;
   if constexpr (NOUT > 0) {
 #pragma unroll
     for (int u = 0; u < NOUT; ++u) {
@@ -443,7 +475,7 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
         d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
       } else {
         d0[q] = img[q];
-        d1[q] = img[plane + q];
+        if constexpr (V == 2) d1[q] = img[plane + q];
       }
     }
   } else {
@@ -453,7 +485,8 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
         d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
       } else {
         if (out0) out0[base + q] = img[q];
-        if (out1) out1[base + q] = img[plane + q];
+        if constexpr (V == 2)
+          if (out1) out1[base + q] = img[plane + q];
       }
     }
   }
@@ -652,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes,
 // r' = (1+p)/(1+p(1-rho_q))^2, evaluated by the owner of node o and summed over its incident
 // elements in ascending order in a register: one lane per node, no scatter, no atomics, no tensor.
 // ------------------------------------------------------------------------------------------
-template <int P>
+template <int P, bool SCALAR = false>
 __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const double* __restrict__ X,
                                                          const int32_t* __restrict__ n2e_ptr,
                                                          const int4* __restrict__ vis_rec, ElasticityParams pr,
@@ -677,9 +710,13 @@ __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const d
       el.x[b] = xy.x;
       el.y[b] = xy.y;
       rho_e[b] = pr.rho[nd[b]];
-      const double2 f = *reinterpret_cast<const double2*>(phi + 2 * (int64_t)nd[b]);
-      const double2 g = *reinterpret_cast<const double2*>(psi + 2 * (int64_t)nd[b]);
-      fx[b] = f.x; fy[b] = f.y; gx[b] = g.x; gy[b] = g.y;
+      if constexpr (SCALAR) {  // LinearPoisson: scalar fields (pyfem.py:1240-1276)
+        fx[b] = phi[nd[b]]; gx[b] = psi[nd[b]]; fy[b] = 0.0; gy[b] = 0.0;
+      } else {
+        const double2 f = *reinterpret_cast<const double2*>(phi + 2 * (int64_t)nd[b]);
+        const double2 g = *reinterpret_cast<const double2*>(psi + 2 * (int64_t)nd[b]);
+        fx[b] = f.x; fy[b] = f.y; gx[b] = g.x; gy[b] = g.y;
+      }
     }
     Own own = make_own<P>(a);
     auto point = [&](double det, double w, const double* N, const double* Nx, const double* Ny) {
@@ -696,7 +733,18 @@ __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const d
       }
       const double t = fma(pr.p, 1.0 - rq, 1.0);
       const double dr = (1.0 + pr.p) / (t * t);           // RAMP derivative, pyfem.py:1968
-      const double eCe = pr.c11 * (e1 * h1 + e2 * h2) + pr.c12 * (e1 * h2 + e2 * h1) + pr.c33 * e3 * h3;
+      double eCe;
+      if constexpr (SCALAR) {
+        double px = 0.0, py = 0.0, qx = 0.0, qy = 0.0;  // grad phi . grad psi
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+          px = fma(Nx[b], fx[b], px); py = fma(Ny[b], fx[b], py);
+          qx = fma(Nx[b], gx[b], qx); qy = fma(Ny[b], gx[b], qy);
+        }
+        eCe = px * qx + py * qy;
+      } else {
+        eCe = pr.c11 * (e1 * h1 + e2 * h2) + pr.c12 * (e1 * h2 + e2 * h1) + pr.c33 * e3 * h3;
+      }
       acc = fma(det * w * dr * own.Na, eCe, acc);
     };
     double det, Nx[P], Ny[P], N[P];
@@ -712,6 +760,78 @@ __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const d
     }
   }
   out[n] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// LinearPoisson right-hand side (pyfem.py:997-1004, 1131-1173, 861-875).
+//   k_quad_points:  Xq[e,q,:] = sum_l N[q,l] X[conn[e,l],:]   (the points the Python gfunc is evaluated at)
+//   k_poisson_rhs:  rhs[n] = sum over incident (e,a) of rhs_e[e,a] with
+//                   rhs_e[e,a] = sum_q detJ_q w_q N[q][a] g[e,q]       -- quads (N symmetric: pyfem.py:1132)
+//                   rhs_e[e,0] = detJ * 0.5 * g[e,0], other columns dropped -- triangles: the reference's
+//                   _assemble_rhs loops over range(nquads) columns (pyfem.py:873), reproduced.
+// ------------------------------------------------------------------------------------------
+template <int P>
+__global__ void k_quad_points(int64_t nelems, const double* __restrict__ X, const int32_t* __restrict__ conn,
+                              double* __restrict__ Xq) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= nelems) return;
+  int32_t nd[P];
+  load_conn<P>(conn, e, nd);
+  Elem<P> el;
+  load_elem<P>(X, nd, el);
+  constexpr int Q = (P == 4) ? 4 : 1;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    double N[P];
+    if constexpr (P == 4) {
+      const double xi = (q == 0 || q == 3) ? -GP : GP, et = (q == 0 || q == 1) ? -GP : GP;
+      N[0] = 0.25 * (1.0 - xi) * (1.0 - et); N[1] = 0.25 * (1.0 + xi) * (1.0 - et);
+      N[2] = 0.25 * (1.0 + xi) * (1.0 + et); N[3] = 0.25 * (1.0 - xi) * (1.0 + et);
+    } else {
+      N[0] = 1.0 / 3; N[1] = 1.0 / 3; N[2] = 1 - 1.0 / 3 - 1.0 / 3;
+    }
+    double xq = 0.0, yq = 0.0;
+#pragma unroll
+    for (int l = 0; l < P; ++l) {
+      xq += N[l] * el.x[l];
+      yq += N[l] * el.y[l];
+    }
+    Xq[(e * Q + q) * 2 + 0] = xq;
+    Xq[(e * Q + q) * 2 + 1] = yq;
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(128) void k_poisson_rhs(int64_t nnodes, const double* __restrict__ X,
+                                                     const int32_t* __restrict__ conn,
+                                                     const int32_t* __restrict__ n2e_ptr,
+                                                     const int32_t* __restrict__ n2e, const double* __restrict__ gq,
+                                                     double* __restrict__ rhs) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  double acc = 0.0;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int32_t ea = n2e[jj];
+    const int32_t e = ea / P;
+    const int a = ea - e * P;
+    int32_t nd[P];
+    load_conn<P>(conn, e, nd);
+    Elem<P> el;
+    load_elem<P>(X, nd, el);
+    Own own = make_own<P>(a);
+    double det, Nx[P], Ny[P], N[P];
+    if constexpr (P == 4) {
+      const QuadEdges ed = quad_edges(el);
+      quad_point<0>(ed, own, det, Nx, Ny, N); acc = fma(det * own.Na, gq[4 * (int64_t)e + 0], acc);
+      quad_point<1>(ed, own, det, Nx, Ny, N); acc = fma(det * own.Na, gq[4 * (int64_t)e + 1], acc);
+      quad_point<2>(ed, own, det, Nx, Ny, N); acc = fma(det * own.Na, gq[4 * (int64_t)e + 2], acc);
+      quad_point<3>(ed, own, det, Nx, Ny, N); acc = fma(det * own.Na, gq[4 * (int64_t)e + 3], acc);
+    } else {
+      tri_point(el, own, det, Nx, Ny, N);
+      if (a == 0) acc = fma(det * 0.5, gq[e], acc);
+    }
+  }
+  rhs[n] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,7 +889,8 @@ __global__ __launch_bounds__(256) void k_element_matrices(int64_t nelems, const 
 #pragma unroll
       for (int b = 0; b < P; ++b) {
         if (out0) out0[e * P * P + a * P + b] = v[b][0];
-        if (out1) out1[e * P * P + a * P + b] = v[b][1];
+        if constexpr (Phys::V == 2)
+          if (out1) out1[e * P * P + a * P + b] = v[b][1];
       }
     }
   }
@@ -836,11 +957,11 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
   {  // default: v3
     const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
-    const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V / 2), 64);
+    const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V == 4 ? 2 : 1), 64);
     const char* ab = getenv("PF_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
     auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;
-    const bool both = (Phys::V == 4) || (out0 && out1);
+    const bool both = (Phys::V == 4) || (out0 && (out1 || Phys::V == 1));
     if (per_lane <= 5 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 5, 0>;
       if constexpr (P == 4 && Phys::V == 4 && !RHO) {
@@ -956,6 +1077,71 @@ extern "C" int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, 
     k_sens_elasticity<4><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
   else
     k_sens_elasticity<3><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// ---- LinearPoisson (row f4, 2-D part) ---------------------------------------------------------------
+extern "C" int pf_assemble_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Kvals) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d == 1, "pf_assemble_poisson2d: pattern must be built with ndof_per_node = 1");
+  PF_REQUIRE(Kvals, "pf_assemble_poisson2d: Kvals is NULL");
+  PoissonParams pr{p, rho};
+  if (ctx->P == 4)
+    return rho ? launch_gather<4, Poisson<4, true>, true>(ctx, pr, Kvals, nullptr)
+               : launch_gather<4, Poisson<4, false>, false>(ctx, pr, Kvals, nullptr);
+  return rho ? launch_gather<3, Poisson<3, true>, true>(ctx, pr, Kvals, nullptr)
+             : launch_gather<3, Poisson<3, false>, false>(ctx, pr, Kvals, nullptr);
+}
+
+extern "C" int pf_element_matrices_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Ke_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->conn && Ke_out, "pf_element_matrices_poisson2d: no mesh / NULL output");
+  PoissonParams pr{p, rho};
+  const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
+  if (ctx->P == 4) {
+    if (rho) k_element_matrices<4, Poisson<4, true>, true><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+    else k_element_matrices<4, Poisson<4, false>, false><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+  } else {
+    if (rho) k_element_matrices<3, Poisson<3, true>, true><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+    else k_element_matrices<3, Poisson<3, false>, false><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+  }
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_quad_points(pf_ctx* ctx, double* Xq_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->conn && Xq_out, "pf_quad_points: no mesh / NULL output");
+  const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
+  if (ctx->P == 4) k_quad_points<4><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, Xq_out);
+  else k_quad_points<3><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, Xq_out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_poisson_rhs(pf_ctx* ctx, const double* gq, double* rhs_out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d == 1 && gq && rhs_out, "pf_poisson_rhs: needs a scalar pattern / NULL argument");
+  const unsigned grid = (unsigned)cdiv(ctx->nnodes, 128);
+  if (ctx->P == 4) k_poisson_rhs<4><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->conn, ctx->n2e_ptr, ctx->n2e, gq, rhs_out);
+  else k_poisson_rhs<3><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->conn, ctx->n2e_ptr, ctx->n2e, gq, rhs_out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_sens_poisson2d(pf_ctx* ctx, double p, const double* rho, const double* phi, const double* psi,
+                                 double* out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d == 1, "pf_sens_poisson2d: pattern must be built with ndof_per_node = 1");
+  PF_REQUIRE(rho && phi && psi && out, "pf_sens_poisson2d: NULL argument");
+  PF_REQUIRE(ctx->vis_rec, "pf_sens_poisson2d: node valence above 64 is not supported");
+  ElasticityParams pr{0.0, 0.0, 0.0, p, rho};
+  const unsigned grid = (unsigned)cdiv(ctx->nnodes, 128);
+  if (ctx->P == 4)
+    k_sens_elasticity<4, true><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
+  else
+    k_sens_elasticity<3, true><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -122,6 +122,37 @@ class HipContext:
         self._call("pf_sens_elasticity2d", E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
         return out
 
+    def assemble_poisson(self, p, rho=None, out=None):
+        vals = self.empty(self.nnz) if out is None else out
+        self._sync_stream()
+        self._call("pf_assemble_poisson2d", p, _ptr(rho), _ptr(vals))
+        return vals
+
+    def element_matrices_poisson(self, p, rho=None):
+        out = self.empty(self.nelems * self.P * self.P)
+        self._sync_stream()
+        self._call("pf_element_matrices_poisson2d", p, _ptr(rho), _ptr(out))
+        return out.view(self.nelems, self.P, self.P)
+
+    def quad_points(self):
+        Q = 4 if self.P == 4 else 1
+        out = self.empty(self.nelems * Q * 2)
+        self._sync_stream()
+        self._call("pf_quad_points", _ptr(out))
+        return out.view(self.nelems, Q, 2)
+
+    def poisson_rhs(self, gq):
+        out = self.empty(self.nnodes)
+        self._sync_stream()
+        self._call("pf_poisson_rhs", _ptr(gq), _ptr(out))
+        return out
+
+    def sens_poisson(self, p, rho, phi, psi):
+        out = self.empty(self.nnodes)
+        self._sync_stream()
+        self._call("pf_sens_poisson2d", p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        return out
+
     def element_matrices_elasticity(self, E, nu, p, rho=None):
         D = self.P * 2
         out = self.empty(self.nelems * D * D)

@@ -15,7 +15,7 @@ holds the host logic the reference has around those calls.  There is no numpy fa
 the library or a GPU the constructors raise.
 
 Scope: 2-D 4-node quads and 3-node triangles; LinearElasticity (plane
-stress, RAMP density), Helmholtz filter, Assembler.solve.  3-D elements, LinearPoisson,
+stress, RAMP density, sensitivities), LinearPoisson, Helmholtz filter, Assembler.solve.  3-D elements,
 NonlinearPoisson2D, A2DWrapper and complex-step dtypes are outside the accelerated path and raise
 NotImplementedError here.
 """
@@ -193,6 +193,107 @@ class ModelBase:
         return K, rhs
 
 
+class LinearPoisson(ModelBase):
+    """ref: pyfem.py:934-1329 (2-D).  -k lap(u) = g with RAMP-penalised conductivity; `kappa0` is stored
+    and, as in the reference (:977 vs :1300), never applied.  compute_rhs evaluates the Python `gfunc` on
+    the host at the quadrature points the device computes and integrates on the device."""
+
+    @time_this
+    def __init__(self, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, gfunc, kappa0=1.0, p=0.0, device=None):
+        X = np.asarray(X)
+        if X.shape[1] != 2:
+            raise NotImplementedError("accelerated path: 3-D Poisson is out of scope (SURVEY.md 8f, f4)")
+        super().__init__(1, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
+        self.gfunc = gfunc
+        self.fun_vals = None
+        self.kappa0 = kappa0
+        self.p = float(p)
+        self._last_rho = None
+
+    def _rho_device(self, rho):
+        torch = self.hctx.torch
+        if isinstance(rho, torch.Tensor):
+            if rho.is_complex():
+                raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
+            return rho.to(device=self.hctx.device, dtype=torch.float64).contiguous()
+        if not hasattr(rho, "__len__"):
+            if rho == 1.0:
+                return None
+            rho = np.ones(self.nnodes) * rho
+        rho = np.asarray(rho)
+        if np.iscomplexobj(rho):
+            raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
+        return self.hctx.to_device(rho.astype(float), torch.float64)
+
+    @time_this
+    def compute_rhs(self):
+        """ref: pyfem.py:997-1004, 1138-1173."""
+        torch = self.hctx.torch
+        Xq = self.hctx.quad_points().cpu().numpy()
+        self.fun_vals = np.asarray(self.gfunc(Xq), dtype=float)
+        gq = self.hctx.to_device(np.ascontiguousarray(self.fun_vals), torch.float64)
+        self.rhs[:] = self.hctx.poisson_rhs(gq).cpu().numpy()
+        return self.rhs
+
+    @time_this
+    def compute_jacobian(self, rho=1.0, out=None):
+        """ref: pyfem.py:1006-1030."""
+        rho_d = self._rho_device(rho)
+        self._last_rho = rho_d
+        vals = self.hctx.assemble_poisson(self.p, rho_d, out=None if out is None else out.vals)
+        if out is not None:
+            out.invalidate()
+            out._eliminate = False
+            return out
+        return DeviceCSR(self.hctx, vals)
+
+    @property
+    def Ke_mat(self):
+        return self.hctx.element_matrices_poisson(self.p, self._last_rho).cpu().numpy()
+
+    @time_this
+    def compliance(self, rho, solver="cg", weighted=True):
+        """ref: pyfem.py:1033-1073."""
+        assert solver == "direct" or solver == "cg" or solver == "gmres"
+        K = self.compute_jacobian(rho)
+        rhs = self.compute_rhs()
+        K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+        u = Assembler(self)._solve_linear_system(K, rhs, solver)
+        c = rhs.dot(u) if weighted else np.sum(u) / len(u)
+        return c, u
+
+    @time_this
+    def compliance_grad(self, rho, u, weighted=True):
+        """ref: pyfem.py:1076-1104."""
+        if weighted:
+            psi = u
+        else:
+            K = self.compute_jacobian(rho)
+            rhs = np.ones(len(u))
+            K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+            psi = Assembler(self)._solve_linear_system(K, rhs, "cg") / len(u)
+        return -self._compute_K_dv_sens(rho, psi, u)
+
+    def volume(self, rho):
+        return rho.sum() / self.nnodes
+
+    def volume_grad(self, rho):
+        return np.ones(self.nnodes) / self.nnodes
+
+    @time_this
+    def _compute_K_dv_sens(self, rho, phi, psi):
+        """ref: pyfem.py:1240-1276, fused (no Ke_deriv tensor)."""
+        torch = self.hctx.torch
+        if not hasattr(rho, "__len__"):
+            rho = np.ones(self.nnodes) * rho
+        rho_d = self._rho_device(rho)
+        if rho_d is None:
+            rho_d = self.hctx.to_device(np.ones(self.nnodes), torch.float64)
+        phi_d = self.hctx.to_device(np.asarray(phi, dtype=float), torch.float64)
+        psi_d = self.hctx.to_device(np.asarray(psi, dtype=float), torch.float64)
+        return self.hctx.sens_poisson(self.p, rho_d, phi_d, psi_d).cpu().numpy()
+
+
 class LinearElasticity(ModelBase):
     """ref: pyfem.py:1667-2068 (2-D plane stress branch)."""
 
@@ -357,7 +458,6 @@ def _not_on_path(name, where):
     return _Stub
 
 
-LinearPoisson = _not_on_path("LinearPoisson", "pyfem.py:934-1329")
 NonlinearPoisson2D = _not_on_path("NonlinearPoisson2D", "pyfem.py:1332-1664")
 A2DWrapper = _not_on_path("A2DWrapper", "pyfem.py:2180-2283")
 

@@ -374,3 +374,57 @@ def test_sensitivity_pass(pf, orc, name, etype):
     f = lambda r: g["phi"].dot(model.compute_jacobian(r).dot(g["psi"]))
     fd = (f(g["rho"] + h * dv) - f(g["rho"] - h * dv)) / (2 * h)
     assert abs(fd / dv.dot(s) - 1) < 1e-6
+
+
+def _gfunc(x):  # tests/test_linear_poisson.py:11-14 of the reference
+    _x = x[..., 0]
+    _y = x[..., 1]
+    return _x * (_x - 5.0) * (_x - 10.0) * _y * (_y - 4.0)
+
+
+@pytest.mark.parametrize("name", ["poi32_quad", "poi17x12_quad_ramp"])
+def test_linear_poisson(pf, orc, name):
+    """LinearPoisson (row f4): K, quadrature rhs, BCs, solve, compliance and sensitivities against the
+    reference's own output; poi32 is tests/test_linear_poisson.py:18-40."""
+    g = load(name)
+    q, b = _qb(pf, "quad")
+    p = float(g["p"])
+    model = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], g.get("fixed_vals"), q, b, _gfunc, p=p)
+    K = model.compute_jacobian(g["rho"])
+    Ks = K.to_scipy()
+    ref = csr_of(g, "K", g["X"].shape[0])
+    assert np.array_equal(Ks.indptr, ref.indptr) and np.array_equal(Ks.indices, ref.indices)
+    assert np.abs(Ks.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
+    assert np.abs(model.Ke_mat[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
+    rhs = model.compute_rhs()
+    assert relmax(rhs, g["rhs"]) < K_TOL
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+    assert relmax(rhs, g["rhs_bc"]) < 1e-12
+    asm = pf.Assembler(model)
+    for method in ("direct", "cg"):
+        u = asm._solve_linear_system(K, rhs, method)
+        assert relmax(u, g["u"]) < U_TOL
+    s = model._compute_K_dv_sens(g["rho"], g["phi"], g["psi"])
+    assert relmax(s, g["sens"]) < K_TOL
+    model2 = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], g.get("fixed_vals"), q, b, _gfunc, p=p)
+    c, u = model2.compliance(g["rho"], solver="cg")
+    assert abs(c / float(g["compliance"]) - 1) < 1e-8
+    assert relmax(model2.compliance_grad(g["rho"], u), g["compliance_grad"]) < 1e-7
+    if name == "poi32_quad":  # the reference's own assertion, through Assembler.solve
+        model3 = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], None, q, b, _gfunc)
+        u3 = pf.Assembler(model3).solve(method="direct")
+        np.random.seed(123)
+        pr = np.random.rand(u3.shape[0])
+        assert abs((pr.dot(u3) - pr.dot(g["u"])) / pr.dot(u3)) < 1e-10
+
+
+def test_linear_poisson_tri_quirk(pf, orc):
+    """Triangles: the reference lumps each element's load on its first node; reproduced."""
+    conn, X = orc.structured_mesh(9, 7, "tri")
+    q, b = _qb(pf, "tri")
+    rho = 0.3 + 0.7 * np.random.RandomState(2).rand(X.shape[0])
+    model = pf.LinearPoisson(X, conn, [0, 5], None, q, b, _gfunc, p=2.0)
+    Ks = model.compute_jacobian(rho).to_scipy()
+    Ko = orc.assemble_csr(orc.poisson_Ke(X, conn, "tri", rho, 2.0), conn)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    assert relmax(model.compute_rhs(), orc.poisson_rhs(X, conn, "tri", _gfunc)) < K_TOL

@@ -117,3 +117,36 @@ def test_sensitivity_matches_reference(name, etype):
     assert relmax(s, g["sens"]) < 1e-13
     grad = -orc.elasticity_K_dv_sens(X, conn, etype, g["rho"], g["u"], g["u"], p=float(g["p"]))
     assert relmax(grad, g["compliance_grad"]) < 1e-12
+
+
+def _gfunc(x):  # the source term of the reference's test (tests/test_linear_poisson.py:11-14)
+    _x = x[..., 0]
+    _y = x[..., 1]
+    return _x * (_x - 5.0) * (_x - 10.0) * _y * (_y - 4.0)
+
+
+@pytest.mark.parametrize("name", ["poi32_quad", "poi17x12_quad_ramp"])
+def test_poisson_matches_reference(name):
+    g = load(name)
+    X, conn = g["X"], g["conn"].astype(np.int64)
+    p = float(g["p"])
+    Ke = orc.poisson_Ke(X, conn, "quad", g["rho"], p)
+    assert relmax(Ke[0], g["Ke0"]) < K_TOL
+    K = orc.assemble_csr(Ke, conn)
+    ref = csr_of(g, "K", X.shape[0])
+    assert np.array_equal(K.indptr, ref.indptr) and np.array_equal(K.indices, ref.indices)
+    assert np.abs(K.data - ref.data).max() < K_TOL * np.abs(ref.data).max()
+    rhs = orc.poisson_rhs(X, conn, "quad", _gfunc)
+    assert relmax(rhs, g["rhs"]) < K_TOL
+    Kbc, rhs_bc = orc.apply_dirichlet_bcs(K, rhs, g["dof_fixed"], g.get("fixed_vals"), True)
+    assert relmax(rhs_bc, g["rhs_bc"]) < 1e-12
+    from scipy.sparse.linalg import spsolve
+
+    u = spsolve(Kbc.tocsc(), rhs_bc)
+    assert relmax(u, g["u"]) < U_TOL
+    assert relmax(orc.poisson_K_dv_sens(X, conn, "quad", g["rho"], g["phi"], g["psi"], p), g["sens"]) < 1e-13
+    if name == "poi32_quad":
+        np.random.seed(123)
+        pr = np.random.rand(u.shape[0])
+        assert abs(pr.dot(u) / -7082.301628403809 - 1) < 1e-10
+        assert np.allclose(Ke[0, 0], [2 / 3, -1 / 6, -1 / 3, -1 / 6], atol=1e-13)
