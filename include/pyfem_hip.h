@@ -48,7 +48,7 @@ enum {
 
 enum { PF_QUAD4 = 4, PF_TRI3 = 3 };          /* nodes per element selects the element */
 enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
-enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1 };
+enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2 };
 
 /* ---- context -------------------------------------------------------------------------- */
 int pf_ctx_create(int device, pf_ctx** out);
@@ -141,6 +141,13 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * that many iterations (<=0: default 50); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
+/* PF_PRECOND_AMG: aggregation-AMG V(1,1) cycle -- the device counterpart of the reference's
+ * pyamg.smoothed_aggregation_solver(K).aspreconditioner() (pyfem.py:2393-2400) and of
+ * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,
+ * the coarse operators per call.  If the matrix has a non-positive diagonal entry (not SPD) pf_cg
+ * silently uses Jacobi instead.  pf_amg_info reports the hierarchy of the last AMG solve (HOST outputs,
+ * arrays of length cap). */
+int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);
 
 /* Building blocks for the one-process-per-GPU driver (pyfem_gpu_testflight_amd/dist.py): the
  * single-reduction (Chronopoulos-Gear) Jacobi-PCG.  ONE all-reduce per iteration carries the

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpyfem_hip.so")
 
 PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
-PF_PRECOND_NONE, PF_PRECOND_JACOBI = 0, 1
+PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG = 0, 1, 2
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
@@ -47,6 +47,7 @@ SIGNATURES = {
     "pf_extract_diag": (C.c_int, [_vp, _vp, _vp]),
     "pf_cg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.c_int, C.POINTER(_i32),
                         C.POINTER(_f64)]),
+    "pf_amg_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_f64), C.c_int]),
     "pf_dot": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_copy_indexed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp]),

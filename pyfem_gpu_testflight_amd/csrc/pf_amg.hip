@@ -1,0 +1,625 @@
+// Aggregation AMG V-cycle preconditioner for the PCG of pf_solve.hip (gfx950).
+//
+// Counterpart of the reference's `pyamg.smoothed_aggregation_solver(K).aspreconditioner()`
+// (pyfem.py:2393-2400) and `pyamg.ruge_stuben_solver(K)` (pyfem.py:2098) -- SURVEY.md 8f row f1.
+// pyamg is a host library; this is a from-scratch device implementation on the same data layout as
+// the rest of the path (node graph + dense d x d blocks), not a port:
+//   * aggregates depend on the node GRAPH only, so they are built once per mesh on the host (greedy
+//     root/neighbourhood aggregation, O(nnz) serial C++) together with the coarse node graphs;
+//   * per matrix, on the device: Galerkin coarse operators A_c = P^T A P by an owner-computes gather
+//     (one lane per coarse row, no atomics), with the tentative prolongator built from the near-null
+//     space: the constant for scalar problems, the three rigid-body modes (two translations and the
+//     in-plane rotation about the aggregate centroid) for plane elasticity -> 3 x 3 coarse blocks;
+//     dofs whose row is decoupled (Dirichlet rows after apply_dirichlet_bcs) are kept out of P and are
+//     solved exactly by the smoother;
+//   * V(1,1) cycle with damped Jacobi (omega from a Gershgorin bound of D^-1 A, so the smoother is a
+//     contraction on every level), dense inverse on the coarsest level (<= 384 dofs).
+// The cycle is a fixed symmetric positive definite operator, so it is a valid CG preconditioner.
+// Plain (unsmoothed) aggregation is used in this round; smoothing the prolongator is the next step.
+#include <algorithm>
+#include <vector>
+
+#include "pf_common.h"
+
+static constexpr int AMG_MAX_LEVELS = 12;
+static constexpr int AMG_COARSEST_DOFS = 384;
+
+struct AmgLevel {
+  int64_t n = 0;             // nodes
+  int dr = 0;                // dofs per node on this level
+  int32_t* ptr = nullptr;    // node graph (device); level 0 aliases the ctx pattern
+  int32_t* idx = nullptr;
+  bool owns_graph = false;
+  int64_t nblk = 0;
+  double* vals = nullptr;    // block values (level 0: the caller's matrix, not owned)
+  double* dinv = nullptr;    // omega / diag per dof
+  uint8_t* iso = nullptr;    // 1 = decoupled dof (row has no off-diagonal entries)
+  double* xy = nullptr;      // node coordinates (n,2) (level 0 aliases ctx->X)
+  bool owns_xy = false;
+  // transfer to the next level
+  int64_t nc = 0;            // number of aggregates
+  int32_t* agg = nullptr;    // (n) aggregate of each node
+  int32_t* aptr = nullptr;   // (nc+1) aggregate -> members
+  int32_t* amem = nullptr;   // (n)
+  // work vectors
+  double *x = nullptr, *b = nullptr, *t = nullptr;
+  double omega = 0.6;
+};
+
+struct pf_amg {
+  int nlevels = 0;
+  AmgLevel L[AMG_MAX_LEVELS];
+  double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
+  int64_t dense_m = 0;
+  double* gersh = nullptr;      // scratch for the Gershgorin bound
+};
+
+// ------------------------------------------------------------------------------------------
+// host: greedy aggregation + coarse graph
+// ------------------------------------------------------------------------------------------
+static void aggregate_host(int64_t n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx,
+                           std::vector<int32_t>& agg, int64_t& nc) {
+  agg.assign(n, -1);
+  nc = 0;
+  // pass 1: a node whose whole neighbourhood is free becomes the root of a new aggregate
+  for (int64_t i = 0; i < n; ++i) {
+    if (agg[i] != -1 || ptr[i + 1] == ptr[i]) continue;
+    bool free_nb = true;
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g)
+      if (agg[idx[g]] != -1) { free_nb = false; break; }
+    if (!free_nb) continue;
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) agg[idx[g]] = (int32_t)nc;
+    ++nc;
+  }
+  // pass 2: leftovers join a neighbouring pass-1 aggregate
+  std::vector<int32_t> pass1(agg);
+  for (int64_t i = 0; i < n; ++i) {
+    if (agg[i] != -1) continue;
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g)
+      if (pass1[idx[g]] != -1) { agg[i] = pass1[idx[g]]; break; }
+  }
+  // pass 3: whatever is still free (and isolated nodes) forms new aggregates with its free neighbours
+  for (int64_t i = 0; i < n; ++i) {
+    if (agg[i] != -1) continue;
+    agg[i] = (int32_t)nc;
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g)
+      if (agg[idx[g]] == -1) agg[idx[g]] = (int32_t)nc;
+    ++nc;
+  }
+}
+
+static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx,
+                              const std::vector<int32_t>& agg, int64_t nc, std::vector<int32_t>& aptr,
+                              std::vector<int32_t>& amem, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx) {
+  aptr.assign(nc + 1, 0);
+  for (int64_t i = 0; i < n; ++i) aptr[agg[i] + 1]++;
+  for (int64_t a = 0; a < nc; ++a) aptr[a + 1] += aptr[a];
+  amem.resize(n);
+  std::vector<int32_t> cur(aptr.begin(), aptr.end() - 1);
+  for (int64_t i = 0; i < n; ++i) amem[cur[agg[i]]++] = (int32_t)i;
+  cptr.assign(nc + 1, 0);
+  cidx.clear();
+  std::vector<int32_t> row;
+  for (int64_t a = 0; a < nc; ++a) {
+    row.clear();
+    row.push_back((int32_t)a);
+    for (int32_t k = aptr[a]; k < aptr[a + 1]; ++k) {
+      const int32_t i = amem[k];
+      for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) row.push_back(agg[idx[g]]);
+    }
+    std::sort(row.begin(), row.end());
+    row.erase(std::unique(row.begin(), row.end()), row.end());
+    cidx.insert(cidx.end(), row.begin(), row.end());
+    cptr[a + 1] = (int32_t)cidx.size();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------
+// decoupled dofs + Gershgorin bound of D^-1 A per dof
+template <int D>
+__global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                           const double* __restrict__ vals, uint8_t* __restrict__ iso,
+                           double* __restrict__ diag, double* __restrict__ bound) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double off[D], dg[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { off[k] = 0.0; dg[k] = 0.0; }
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+    const int64_t m = idx[g];
+    const double* a = vals + (int64_t)g * D * D;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+#pragma unroll
+      for (int l = 0; l < D; ++l) {
+        if (m == i && k == l) dg[k] = a[k * D + l];
+        else off[k] += fabs(a[k * D + l]);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    iso[D * i + k] = (off[k] == 0.0) ? 1 : 0;
+    if (dg[k] == 0.0) dg[k] = 1.0;  // empty / decoupled coarse dof: identity
+    diag[D * i + k] = dg[k];
+    bound[D * i + k] = (fabs(dg[k]) + off[k]) / fabs(dg[k]);
+  }
+}
+
+__global__ void k_amg_scale_dinv(int64_t n, double omega, double* __restrict__ d, const uint8_t* __restrict__ iso) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) d[i] = (iso[i] ? 1.0 : omega) / d[i];  // decoupled dofs are solved exactly
+}
+
+// tentative prolongator row block P_n (DR x DC) for node n of an aggregate with centroid (cx, cy)
+template <int DR, int DC>
+__device__ __forceinline__ void amg_P(double dx, double dy, const uint8_t* iso_n, double Pn[DR][DC]) {
+  if constexpr (DR == 1) {
+    Pn[0][0] = iso_n[0] ? 0.0 : 1.0;
+  } else if constexpr (DR == 2) {  // [I2 | rotation about the centroid]
+    Pn[0][0] = 1.0; Pn[0][1] = 0.0; Pn[0][2] = -dy;
+    Pn[1][0] = 0.0; Pn[1][1] = 1.0; Pn[1][2] = dx;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (iso_n[k]) { Pn[k][0] = Pn[k][1] = Pn[k][2] = 0.0; }
+  } else {  // rigid-body modes of a 3-dof node (ux, uy, theta)
+    Pn[0][0] = 1.0; Pn[0][1] = 0.0; Pn[0][2] = -dy;
+    Pn[1][0] = 0.0; Pn[1][1] = 1.0; Pn[1][2] = dx;
+    Pn[2][0] = 0.0; Pn[2][1] = 0.0; Pn[2][2] = 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (iso_n[k]) { Pn[k][0] = Pn[k][1] = Pn[k][2] = 0.0; }
+  }
+}
+
+// coarse coordinates = centroid of the members
+__global__ void k_amg_centroids(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
+                                const double* __restrict__ xy, double* __restrict__ cxy) {
+  const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (a >= nc) return;
+  double sx = 0.0, sy = 0.0;
+  const int32_t b = aptr[a], e = aptr[a + 1];
+  for (int32_t k = b; k < e; ++k) {
+    sx += xy[2 * (int64_t)amem[k]];
+    sy += xy[2 * (int64_t)amem[k] + 1];
+  }
+  const double inv = 1.0 / (double)max(e - b, 1);
+  cxy[2 * a] = sx * inv;
+  cxy[2 * a + 1] = sy * inv;
+}
+
+// Galerkin product, one lane per coarse row I:  C[I,J] = sum_{n in I} sum_{m in J} P_n^T A[n,m] P_m
+template <int DR, int DC>
+__global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
+                               const int32_t* __restrict__ agg, const int32_t* __restrict__ ptr,
+                               const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                               const uint8_t* __restrict__ iso, const double* __restrict__ xy,
+                               const double* __restrict__ cxy, const int32_t* __restrict__ cptr,
+                               const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  const int32_t cb = cptr[I], ce = cptr[I + 1];
+  for (int64_t q = (int64_t)cb * DC * DC; q < (int64_t)ce * DC * DC; ++q) cvals[q] = 0.0;
+  const double cxI = cxy[2 * I], cyI = cxy[2 * I + 1];
+  for (int32_t k = aptr[I]; k < aptr[I + 1]; ++k) {
+    const int64_t n = amem[k];
+    double Pn[DR][DC];
+    amg_P<DR, DC>(xy[2 * n] - cxI, xy[2 * n + 1] - cyI, iso + DR * n, Pn);
+    for (int32_t g = ptr[n]; g < ptr[n + 1]; ++g) {
+      const int64_t m = idx[g];
+      const int32_t J = agg[m];
+      double Pm[DR][DC];
+      amg_P<DR, DC>(xy[2 * m] - cxy[2 * (int64_t)J], xy[2 * m + 1] - cxy[2 * (int64_t)J + 1], iso + DR * m, Pm);
+      const double* a = vals + (int64_t)g * DR * DR;
+      double AP[DR][DC];  // A[n,m] P_m
+#pragma unroll
+      for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < DR; ++t) s += a[r * DR + t] * Pm[t][c];
+          AP[r][c] = s;
+        }
+      int32_t pos = cb;
+      while (cidx[pos] != J) ++pos;
+      double* dst = cvals + (int64_t)pos * DC * DC;
+#pragma unroll
+      for (int r = 0; r < DC; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          double s = 0.0;
+#pragma unroll
+          for (int t = 0; t < DR; ++t) s += Pn[t][r] * AP[t][c];
+          dst[r * DC + c] += s;
+        }
+    }
+  }
+}
+
+// generic block SpMV for the coarse levels: 64-node tiles, blocks streamed lane-per-block through LDS
+template <int D>
+__global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
+                                                 const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y) {
+  constexpr int CH = 448;
+  __shared__ double prod[CH * D];
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t i = tile * 64 + lane;
+    const bool valid = i < n;
+    const int32_t rb = valid ? ptr[i] : 0, re = valid ? ptr[i + 1] : 0;
+    const int32_t base = __shfl(rb, 0);
+    const int32_t end = ptr[min(n, (tile + 1) * 64)];
+    double acc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = 0.0;
+    for (int32_t c0 = base; c0 < end; c0 += CH) {
+      const int32_t c1 = min(end, c0 + CH);
+      for (int32_t g = c0 + lane; g < c1; g += 64) {
+        const int64_t m = idx[g];
+        const double* a = vals + (int64_t)g * D * D;
+        double xv[D];
+#pragma unroll
+        for (int l = 0; l < D; ++l) xv[l] = x[D * m + l];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < D; ++l) s += a[k * D + l] * xv[l];
+          prod[(g - c0) * D + k] = s;
+        }
+      }
+      __syncthreads();
+      for (int32_t g = max(rb, c0); g < min(re, c1); ++g)
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[k] += prod[(g - c0) * D + k];
+      __syncthreads();
+    }
+    if (valid)
+#pragma unroll
+      for (int k = 0; k < D; ++k) y[D * i + k] = acc[k];
+  }
+}
+
+// x = dinv .* b   (one damped-Jacobi sweep from a zero guess; dinv already holds omega/diag)
+__global__ void k_amg_jacobi0(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b,
+                              double* __restrict__ x) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = dinv[i] * b[i];
+}
+// x += dinv .* (b - t)   with t = A x
+__global__ void k_amg_jacobi(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b,
+                             const double* __restrict__ t, double* __restrict__ x) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] += dinv[i] * (b[i] - t[i]);
+}
+
+// coarse rhs: bc_I = sum_{n in I} P_n^T (b_n - t_n)
+template <int DR, int DC>
+__global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
+                               const uint8_t* __restrict__ iso, const double* __restrict__ xy,
+                               const double* __restrict__ cxy, const double* __restrict__ b,
+                               const double* __restrict__ t, double* __restrict__ bc) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  double s[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) s[c] = 0.0;
+  const double cx = cxy[2 * I], cy = cxy[2 * I + 1];
+  for (int32_t k = aptr[I]; k < aptr[I + 1]; ++k) {
+    const int64_t n = amem[k];
+    double Pn[DR][DC];
+    amg_P<DR, DC>(xy[2 * n] - cx, xy[2 * n + 1] - cy, iso + DR * n, Pn);
+#pragma unroll
+    for (int r = 0; r < DR; ++r) {
+      const double res = b[DR * n + r] - t[DR * n + r];
+#pragma unroll
+      for (int c = 0; c < DC; ++c) s[c] += Pn[r][c] * res;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DC; ++c) bc[DC * I + c] = s[c];
+}
+
+// x_n += P_n e_{agg[n]}
+template <int DR, int DC>
+__global__ void k_amg_prolong(int64_t n, const int32_t* __restrict__ agg, const uint8_t* __restrict__ iso,
+                              const double* __restrict__ xy, const double* __restrict__ cxy,
+                              const double* __restrict__ ec, double* __restrict__ x) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t I = agg[i];
+  double Pn[DR][DC];
+  amg_P<DR, DC>(xy[2 * i] - cxy[2 * I], xy[2 * i + 1] - cxy[2 * I + 1], iso + DR * i, Pn);
+#pragma unroll
+  for (int r = 0; r < DR; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) s += Pn[r][c] * ec[DC * I + c];
+    x[DR * i + r] += s;
+  }
+}
+
+// coarsest level: scatter the block matrix into a dense m x m array, invert it in place (Gauss-Jordan,
+// SPD so no pivoting) with one workgroup, then x = Ainv b per cycle
+template <int D>
+__global__ void k_amg_to_dense(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                               const double* __restrict__ vals, double* __restrict__ A, int64_t m) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g)
+    for (int k = 0; k < D; ++k)
+      for (int l = 0; l < D; ++l) A[(D * i + k) * m + D * (int64_t)idx[g] + l] = vals[(int64_t)g * D * D + k * D + l];
+}
+
+__global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ A, int64_t m) {
+  // in-place Gauss-Jordan without pivoting; rows/cols with a zero pivot are treated as identity
+  __shared__ double piv_row[AMG_COARSEST_DOFS];
+  __shared__ double piv_col[AMG_COARSEST_DOFS];
+  for (int64_t p = 0; p < m; ++p) {
+    double pv = A[p * m + p];
+    if (pv == 0.0) pv = 1.0;
+    const double ip = 1.0 / pv;
+    for (int64_t j = threadIdx.x; j < m; j += blockDim.x) {
+      piv_row[j] = A[p * m + j];
+      piv_col[j] = A[j * m + p];
+    }
+    __syncthreads();
+    for (int64_t q = threadIdx.x; q < m * m; q += blockDim.x) {
+      const int64_t i = q / m, j = q % m;
+      double v;
+      if (i == p && j == p) v = ip;
+      else if (i == p) v = piv_row[j] * ip;
+      else if (j == p) v = -piv_col[i] * ip;
+      else v = A[q] - piv_col[i] * piv_row[j] * ip;
+      A[q] = v;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_amg_dense_apply(int64_t m, const double* __restrict__ Ainv, const double* __restrict__ b,
+                                  double* __restrict__ x) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  double s = 0.0;
+  for (int64_t j = 0; j < m; ++j) s += Ainv[i * m + j] * b[j];
+  x[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// hierarchy management
+// ------------------------------------------------------------------------------------------
+void pf_amg_free(pf_ctx* ctx) {
+  pf_amg* H = ctx->amg;
+  if (!H) return;
+  for (int l = 0; l < H->nlevels; ++l) {
+    AmgLevel& Lv = H->L[l];
+    if (Lv.owns_graph) { pf_free(Lv.ptr); pf_free(Lv.idx); }
+    if (l > 0) pf_free(Lv.vals);
+    if (Lv.owns_xy) pf_free(Lv.xy);
+    pf_free(Lv.dinv); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
+    pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
+  }
+  pf_free(H->dense_inv);
+  pf_free(H->gersh);
+  delete H;
+  ctx->amg = nullptr;
+}
+
+template <typename T>
+static int to_device(pf_ctx* ctx, const std::vector<T>& h, T*& d) {
+  PF_HIP(hipMalloc(&d, std::max<size_t>(1, h.size()) * sizeof(T)));
+  if (!h.empty()) PF_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  return PF_OK;
+}
+
+// graph-only part, once per pattern
+static int amg_build_hierarchy(pf_ctx* ctx) {
+  pf_amg* H = new pf_amg();
+  ctx->amg = H;
+  const int d0 = ctx->d, dc = (d0 == 2) ? 3 : 1;
+  std::vector<int32_t> ptr(ctx->nnodes + 1), idx(ctx->nblocks);
+  PF_HIP(hipMemcpyAsync(ptr.data(), ctx->nptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipMemcpyAsync(idx.data(), ctx->nidx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t n = ctx->nnodes;
+  H->L[0].n = n; H->L[0].dr = d0; H->L[0].ptr = ctx->nptr; H->L[0].idx = ctx->nidx; H->L[0].nblk = ctx->nblocks;
+  H->L[0].xy = ctx->X;
+  int l = 0;
+  while (true) {
+    AmgLevel& Lv = H->L[l];
+    const int64_t ndof = Lv.n * Lv.dr;
+    PF_HIP(hipMalloc(&Lv.dinv, sizeof(double) * ndof));
+    PF_HIP(hipMalloc(&Lv.iso, (size_t)ndof));
+    PF_HIP(hipMalloc(&Lv.t, sizeof(double) * ndof));
+    if (l > 0) {
+      PF_HIP(hipMalloc(&Lv.x, sizeof(double) * ndof));
+      PF_HIP(hipMalloc(&Lv.b, sizeof(double) * ndof));
+      PF_HIP(hipMalloc(&Lv.vals, sizeof(double) * Lv.nblk * Lv.dr * Lv.dr));
+    }
+    const bool last = (l > 0 && ndof <= AMG_COARSEST_DOFS) || l + 1 >= AMG_MAX_LEVELS;
+    if (last) break;
+    std::vector<int32_t> agg, aptr, amem, cptr, cidx;
+    int64_t nc = 0;
+    aggregate_host(n, ptr, idx, agg, nc);
+    if (nc >= n || nc == 0) break;  // no coarsening possible
+    coarse_graph_host(n, ptr, idx, agg, nc, aptr, amem, cptr, cidx);
+    Lv.nc = nc;
+    int rc = to_device(ctx, agg, Lv.agg);
+    if (rc == PF_OK) rc = to_device(ctx, aptr, Lv.aptr);
+    if (rc == PF_OK) rc = to_device(ctx, amem, Lv.amem);
+    AmgLevel& Nx = H->L[l + 1];
+    Nx.n = nc; Nx.dr = dc; Nx.nblk = (int64_t)cidx.size(); Nx.owns_graph = true; Nx.owns_xy = true;
+    if (rc == PF_OK) rc = to_device(ctx, cptr, Nx.ptr);
+    if (rc == PF_OK) rc = to_device(ctx, cidx, Nx.idx);
+    if (rc) return rc;
+    PF_HIP(hipMalloc(&Nx.xy, sizeof(double) * 2 * nc));
+    k_amg_centroids<<<(unsigned)cdiv(nc, 256), 256, 0, ctx->stream>>>(nc, Lv.aptr, Lv.amem, Lv.xy, Nx.xy);
+    PF_LAUNCH_CHECK();
+    PF_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+    ptr.swap(cptr);
+    idx.swap(cidx);
+    n = nc;
+    ++l;
+  }
+  H->nlevels = l + 1;
+  AmgLevel& C = H->L[l];
+  H->dense_m = C.n * C.dr;
+  if (H->nlevels > 1 && H->dense_m <= AMG_COARSEST_DOFS)
+    PF_HIP(hipMalloc(&H->dense_inv, sizeof(double) * H->dense_m * H->dense_m));
+  int64_t maxdof = 1;
+  for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
+  PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
+  return PF_OK;
+}
+
+template <int D>
+static int amg_level_rows(pf_ctx* ctx, AmgLevel& Lv, double* scratch, double* lmax_host) {
+  const int64_t ndof = Lv.n * D;
+  k_amg_rows<D><<<(unsigned)cdiv(Lv.n, 256), 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, scratch);
+  PF_LAUNCH_CHECK();
+  // max of the Gershgorin bound and min of the diagonal, on the host (setup path)
+  std::vector<double> h(ndof), dg(ndof);
+  PF_HIP(hipMemcpyAsync(h.data(), scratch, sizeof(double) * ndof, hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipMemcpyAsync(dg.data(), Lv.dinv, sizeof(double) * ndof, hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  double lm = 1.0, dmin = 1e300;
+  for (int64_t i = 0; i < ndof; ++i) { lm = std::max(lm, h[i]); dmin = std::min(dmin, dg[i]); }
+  *lmax_host = lm;
+  if (!(dmin > 0.0)) return PF_E_UNSUPPORTED;  // not positive definite: the caller falls back to Jacobi
+  Lv.omega = 4.0 / (3.0 * lm);
+  k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, Lv.omega, Lv.dinv, Lv.iso);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// numeric part, once per matrix.  Returns PF_E_UNSUPPORTED (without touching ctx->err) when a diagonal
+// entry is not positive -- e.g. the all-negative-detJ arm mesh -- so pf_cg can use Jacobi.
+int pf_amg_setup(pf_ctx* ctx, const double* vals) {
+  if (!ctx->amg) {
+    int rc = amg_build_hierarchy(ctx);
+    if (rc) { pf_amg_free(ctx); return rc; }
+  }
+  pf_amg* H = ctx->amg;
+  H->L[0].vals = const_cast<double*>(vals);
+  double lm = 0.0;
+  for (int l = 0; l < H->nlevels; ++l) {
+    AmgLevel& Lv = H->L[l];
+    int rc = (Lv.dr == 1) ? amg_level_rows<1>(ctx, Lv, H->gersh, &lm)
+           : (Lv.dr == 2) ? amg_level_rows<2>(ctx, Lv, H->gersh, &lm) : amg_level_rows<3>(ctx, Lv, H->gersh, &lm);
+    if (rc) return rc;
+    if (l + 1 == H->nlevels) break;
+    AmgLevel& Nx = H->L[l + 1];
+    const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+#define PF_GAL(DR_, DC_)                                                                                      \
+    k_amg_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
+                                                         Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
+    if (Lv.dr == 1) PF_GAL(1, 1);
+    else if (Lv.dr == 2) PF_GAL(2, 3);
+    else PF_GAL(3, 3);
+#undef PF_GAL
+    PF_LAUNCH_CHECK();
+  }
+  if (H->dense_inv) {
+    AmgLevel& C = H->L[H->nlevels - 1];
+    PF_HIP(hipMemsetAsync(H->dense_inv, 0, sizeof(double) * H->dense_m * H->dense_m, ctx->stream));
+    const unsigned g = (unsigned)cdiv(C.n, 128);
+    if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    else k_amg_to_dense<3><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, H->dense_m);
+    PF_LAUNCH_CHECK();
+  }
+  return PF_OK;
+}
+
+static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y) {
+  if (level == 0) return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr);
+  const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
+  if (Lv.dr == 1) k_amg_spmv<1><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y);
+  else k_amg_spmv<3><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// z = M^-1 r : one V(1,1) cycle.  r and z are fine-level vectors of the caller.
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
+  pf_amg* H = ctx->amg;
+  if (!H) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: no hierarchy");
+  hipStream_t st = ctx->stream;
+  const int Lc = H->nlevels - 1;
+  auto vg = [](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); };
+  // down
+  for (int l = 0; l < Lc; ++l) {
+    AmgLevel& Lv = H->L[l];
+    AmgLevel& Nx = H->L[l + 1];
+    const double* b = (l == 0) ? r : Lv.b;
+    double* x = (l == 0) ? z : Lv.x;
+    const int64_t ndof = Lv.n * Lv.dr;
+    k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, x);
+    int rc = amg_spmv(ctx, Lv, l, x, Lv.t);
+    if (rc) return rc;
+    const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+    if (Lv.dr == 1) k_amg_restrict<1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
+    else if (Lv.dr == 2) k_amg_restrict<2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
+    else k_amg_restrict<3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
+    PF_LAUNCH_CHECK();
+  }
+  // coarsest
+  {
+    AmgLevel& C = H->L[Lc];
+    const double* b = (Lc == 0) ? r : C.b;
+    double* x = (Lc == 0) ? z : C.x;
+    const int64_t ndof = C.n * C.dr;
+    if (H->dense_inv && Lc > 0) {
+      k_amg_dense_apply<<<(unsigned)cdiv(ndof, 64), 64, 0, st>>>(ndof, H->dense_inv, b, x);
+    } else {  // could not coarsen down to the dense size: a few Jacobi sweeps
+      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, x);
+      for (int s = 0; s < 4 && Lc > 0; ++s) {
+        int rc = amg_spmv(ctx, C, Lc, x, C.t);
+        if (rc) return rc;
+        k_amg_jacobi<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, C.t, x);
+      }
+    }
+    PF_LAUNCH_CHECK();
+  }
+  // up
+  for (int l = Lc - 1; l >= 0; --l) {
+    AmgLevel& Lv = H->L[l];
+    AmgLevel& Nx = H->L[l + 1];
+    const double* b = (l == 0) ? r : Lv.b;
+    double* x = (l == 0) ? z : Lv.x;
+    const int64_t ndof = Lv.n * Lv.dr;
+    const unsigned g = (unsigned)cdiv(Lv.n, 256);
+    if (Lv.dr == 1) k_amg_prolong<1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x);
+    else if (Lv.dr == 2) k_amg_prolong<2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x);
+    else k_amg_prolong<3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x);
+    int rc = amg_spmv(ctx, Lv, l, x, Lv.t);
+    if (rc) return rc;
+    k_amg_jacobi<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, Lv.t, x);
+    PF_LAUNCH_CHECK();
+  }
+  return PF_OK;
+}
+
+int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap) {
+  pf_amg* H = ctx->amg;
+  if (!H) return pf_fail(ctx, PF_E_INVALID, "no AMG hierarchy has been built on this context");
+  *nlevels = H->nlevels;
+  for (int l = 0; l < H->nlevels && l < cap; ++l) {
+    nodes[l] = H->L[l].n;
+    dofs_per_node[l] = H->L[l].dr;
+    omega[l] = H->L[l].omega;
+  }
+  return PF_OK;
+}
+
+extern "C" int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega,
+                           int cap) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(nlevels && nodes && dofs_per_node && omega && cap > 0, "pf_amg_info: NULL argument");
+  return pf_amg_describe(ctx, nlevels, nodes, dofs_per_node, omega, cap);
+}

@@ -11,6 +11,8 @@
 #define PF_NPART 4096
 #define PF_NPART_ARRAYS 8
 
+struct pf_amg;
+
 struct pf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -37,6 +39,8 @@ struct pf_ctx {
   void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
   int npt = 0;                 // nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
+
+  pf_amg* amg = nullptr;       // AMG hierarchy (graph part built once per pattern, pf_amg.hip)
 
   // ---- scratch owned by the ctx ----
   double* scal = nullptr;      // PF_NPART_ARRAYS x PF_NPART per-block partial sums
@@ -85,3 +89,7 @@ int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, co
                                   double* Kvals);
 int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part);
+void pf_amg_free(pf_ctx* ctx);
+int pf_amg_setup(pf_ctx* ctx, const double* vals);   // PF_E_UNSUPPORTED: matrix not positive definite
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z);
+int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);

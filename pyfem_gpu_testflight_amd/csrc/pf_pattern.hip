@@ -225,6 +225,7 @@ extern "C" int pf_ctx_create(int device, pf_ctx** out) {
 }
 
 int pf_pattern_free(pf_ctx* ctx) {
+  pf_amg_free(ctx);
   pf_free(ctx->nptr);
   pf_free(ctx->nidx);
   pf_free(ctx->n2e_ptr);

@@ -576,7 +576,8 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
                      int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d && vals && b && x, "pf_cg: no pattern / NULL argument");
-  PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI, "pf_cg: unknown preconditioner");
+  PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI || precond == PF_PRECOND_AMG,
+             "pf_cg: unknown preconditioner");
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);  // scipy's default
@@ -591,6 +592,12 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   const unsigned vg = vec_grid(n);
   const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
 
+  if (precond == PF_PRECOND_AMG) {
+    const int arc = pf_amg_setup(ctx, vals);
+    if (arc == PF_E_UNSUPPORTED) precond = PF_PRECOND_JACOBI;  // not positive definite (e.g. detJ < 0 meshes)
+    else if (arc) return arc;
+  }
+  const bool amg = precond == PF_PRECOND_AMG;
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
     if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
@@ -603,6 +610,13 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   if (rc) return rc;
   k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
   PF_LAUNCH_CHECK();
+  if (amg) {  // z = M^-1 r by one V-cycle, p = z, r.z
+    rc = pf_amg_apply(ctx, r, z);
+    if (rc) return rc;
+    PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, part(ctx, PA_RZ0));
+    PF_LAUNCH_CHECK();
+  }
   static thread_local double h[2 * NPART];
   PF_HIP(hipMemcpyAsync(h, part(ctx, PA_RR), sizeof(double) * 2 * NPART, hipMemcpyDeviceToHost, st));  // RR | BB
   PF_HIP(hipStreamSynchronize(st));
@@ -620,6 +634,11 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
       if (rc) return rc;
       k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, (int)vg, part(ctx, PA_PAP), ns, p, Ap, dinv, x, r, z, rz_new,
                                          part(ctx, PA_RR));
+      if (amg) {
+        rc = pf_amg_apply(ctx, r, z);
+        if (rc) return rc;
+        k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, rz_new);
+      }
       k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, rz_old, (int)vg, z, p);
       cur ^= 1;
     }

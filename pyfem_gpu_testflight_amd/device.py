@@ -202,6 +202,16 @@ class HipContext:
             _lib.check(self._ctx, rc, "pf_cg")
         return x, iters.value, relres.value
 
+    def amg_info(self):
+        """Hierarchy of the last AMG-preconditioned solve: list of (nodes, dofs per node, omega)."""
+        cap = 16
+        nl = _lib._i32()
+        nodes = (_lib._i64 * cap)()
+        dpn = (_lib._i32 * cap)()
+        om = (_lib._f64 * cap)()
+        self._call("pf_amg_info", C.byref(nl), nodes, dpn, om, cap)
+        return [(nodes[i], dpn[i], om[i]) for i in range(nl.value)]
+
     def time_kernel(self, which, reps, in0=None, in1=None, out0=None, E=0.0, nu=0.0, p=0.0):
         ms = _lib._f64()
         self._sync_stream()

@@ -30,6 +30,12 @@ from .utils import time_this
 # below 1e-8 ||u||_inf (BASELINE.json north_star) on ill-conditioned large meshes.
 DEFAULT_RTOL = 1e-10
 
+# preconditioner of the device PCG: "amg" (aggregation AMG V-cycle, the counterpart of the reference's
+# pyamg preconditioners, pyfem.py:2393-2400 and :2098; falls back to Jacobi on matrices that are not
+# positive definite) or "jacobi"
+DEFAULT_PRECOND = "amg"
+_PRECOND = {"none": _lib.PF_PRECOND_NONE, "jacobi": _lib.PF_PRECOND_JACOBI, "amg": _lib.PF_PRECOND_AMG}
+
 
 # ------------------------------------------------------------------------------------------
 # tables (host copies for API parity; the kernels carry the same constants at compile time)
@@ -406,10 +412,11 @@ class Helmholtz(ModelBase):
         self.R = DeviceCSR(self.hctx, Rv)
         self.RT = self.R  # the mass matrix is symmetric (ref keeps R.transpose(), pyfem.py:2096)
         self.rtol = DEFAULT_RTOL
+        self.precond = DEFAULT_PRECOND
         self.last_iters = 0
 
     def _solve(self, b_dev):
-        x, it, _ = self.hctx.cg(self.K.vals, b_dev, rtol=self.rtol)
+        x, it, _ = self.hctx.cg(self.K.vals, b_dev, rtol=self.rtol, precond=_PRECOND[self.precond])
         self.last_iters = it
         return x
 
@@ -470,6 +477,7 @@ class Assembler:
     def __init__(self, model):
         self.model = model
         self.rtol = DEFAULT_RTOL
+        self.precond = DEFAULT_PRECOND
         self.last_iters = None
         self.last_relres = None
 
@@ -487,8 +495,9 @@ class Assembler:
         """ref: pyfem.py:2403-2423.
         "direct": scipy spsolve on the exported matrix -- the reference's own third-party call, kept
                   for small meshes / parity checks (not an accelerated leg).
-        "cg" and "gmres": device Jacobi-PCG.  K is SPD after symmetric BC elimination, so CG reaches
-                  the same solution GMRES does; the reference's pyamg preconditioner is not available."""
+        "cg" and "gmres": device PCG with the aggregation-AMG V-cycle (self.precond = "amg", default) or
+                  Jacobi.  K is SPD after symmetric BC elimination, so CG reaches the same solution GMRES
+                  does."""
         if method == "direct":
             from scipy.sparse.linalg import spsolve
 
@@ -498,7 +507,7 @@ class Assembler:
         on_device = isinstance(rhs, torch.Tensor)
         b = rhs if on_device else hctx.to_device(rhs, torch.float64)
         try:
-            x, it, rr = hctx.cg(K.vals, b, rtol=self.rtol)
+            x, it, rr = hctx.cg(K.vals, b, rtol=self.rtol, precond=_PRECOND[self.precond])
         except RuntimeError as e:
             raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
         self.last_iters, self.last_relres = it, rr
