@@ -215,7 +215,7 @@ extern "C" int pf_ctx_create(int device, pf_ctx** out) {
   PF_HIP(hipSetDevice(device));
   ctx = new pf_ctx();
   ctx->device = device;
-  hipError_t e = hipMalloc(&ctx->scal, ((size_t)PF_NPART * PF_NPART_ARRAYS + 16) * sizeof(double));  // + trash line
+  hipError_t e = hipMalloc(&ctx->scal, ((size_t)PF_NPART * PF_NPART_ARRAYS + 32) * sizeof(double));  // + trash line [0,16) + AMG scalar [16]
   if (e != hipSuccess) {
     delete ctx;
     return pf_fail(nullptr, PF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));

@@ -1,0 +1,26 @@
+import os, sys, time, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pyfem_gpu_testflight_amd import pyfem, _lib
+nx = int(os.environ.get("NX", 512)); ny = int(os.environ.get("NY", 512))
+c = pyfem.ProblemCreator(nx + 1, ny + 1)
+conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+q = pyfem.QuadratureBilinear2D(); b = pyfem.BasisBilinear2D(q)
+m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+h = m.hctx
+rng = np.random.RandomState(4)
+for label, rho in (("uniform", 1.0), ("random", 0.05 + 0.95 * rng.rand(X.shape[0]))):
+    K = m.compute_jacobian(rho)
+    rhs = h.to_device(m.compute_rhs(), torch.float64)
+    K, rhs = m.apply_dirichlet_bcs(K, rhs, True)
+    def run(pre, **env):
+        for k, v in env.items(): os.environ[k] = str(v)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        x, it, rr = h.cg(K.vals, rhs, rtol=1e-8, precond=pre, check_every=10)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        return it, dt
+    it, dt = run(_lib.PF_PRECOND_JACOBI)
+    print(f"{label}: jacobi iters={it} {dt*1e3:.1f} ms", flush=True)
+    for ns, over, osc in itertools.product([1, 2], [1.0, 1.5, 2.0], [1.0]):
+        it, dt = run(_lib.PF_PRECOND_AMG, PF_AMG_NSMOOTH=ns, PF_AMG_OVER=over, PF_AMG_OMEGA_SCALE=osc)
+        print(f"{label}: amg nsmooth={ns} over={over} omega_scale={osc}: iters={it} {dt*1e3:.1f} ms  levels={[(l[0], round(l[2],3)) for l in h.amg_info()]}", flush=True)
