@@ -138,10 +138,10 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * (the reference's `cg(K, rhs, tol=1e-8, atol=0.0)`, pyfem.py:2418).  x holds the initial
  * guess on entry.  Returns PF_E_NOCONV when maxiter is hit (iters/relres still written).
  * iters, relres: HOST out pointers.  check_every: residual is read back to the host every
- * that many iterations (<=0: default 50); iteration count is exact to that granularity. */
+ * that many iterations (<=0: default, 50 for Jacobi / 5 for AMG); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
-/* PF_PRECOND_AMG: aggregation-AMG V(1,1) cycle -- the device counterpart of the reference's
+/* PF_PRECOND_AMG: aggregation-AMG V(2,2) cycle -- the device counterpart of the reference's
  * pyamg.smoothed_aggregation_solver(K).aspreconditioner() (pyfem.py:2393-2400) and of
  * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,
  * the coarse operators per call.  If the matrix has a non-positive diagonal entry (not SPD) pf_cg

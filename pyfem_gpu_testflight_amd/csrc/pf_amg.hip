@@ -12,8 +12,11 @@
 //     in-plane rotation about the aggregate centroid) for plane elasticity -> 3 x 3 coarse blocks;
 //     dofs whose row is decoupled (Dirichlet rows after apply_dirichlet_bcs) are kept out of P and are
 //     solved exactly by the smoother;
-//   * V(1,1) cycle with damped Jacobi (omega from a Gershgorin bound of D^-1 A, so the smoother is a
-//     contraction on every level), dense inverse on the coarsest level (<= 384 dofs).
+//   * V(2,2) cycle with damped Jacobi, omega = 4/(3*1.1*lambda_max(D^-1 A)) with lambda_max from ten
+//     device power iterations per level (invariant under the scaling of individual dofs, unlike a
+//     Gershgorin row sum: translations and rotations have different units on the coarse levels), the
+//     coarse correction scaled by 2 (plain aggregation under-corrects), dense inverse on the coarsest
+//     level (<= 384 dofs).
 // The cycle is a fixed symmetric positive definite operator, so it is a valid CG preconditioner.
 // Plain (unsmoothed) aggregation is used in this round; smoothing the prolongator is the next step.
 #include <stdlib.h>
@@ -54,9 +57,10 @@ struct pf_amg {
   double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
   int64_t dense_m = 0;
   double* gersh = nullptr;      // scratch for the Gershgorin bound / power iteration
-  int nsmooth = 1;              // damped-Jacobi sweeps before and after the coarse correction
-  double over = 1.8;            // scaling of the coarse-grid correction: plain aggregation under-corrects
-                                // (512^2 plane stress: 100 PCG iterations at 1.0, 70 at 1.5-2.0; any value > 0 keeps M SPD)
+  int nsmooth = 2;              // damped-Jacobi sweeps before and after the coarse correction
+  double over = 2.0;            // scaling of the coarse-grid correction: plain aggregation under-corrects.
+                                // 2048^2 plane stress, rtol 1e-8 (tools/amg_sweep.py): V(1,1)/1.0 180 its 572 ms,
+                                // V(2,2)/2.0 60 its 231 ms, Jacobi-PCG 16 380 its 7.3 s.  Any value > 0 keeps M SPD.
   double omega_scale = 1.0;
 };
 

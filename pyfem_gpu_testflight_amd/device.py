@@ -189,7 +189,7 @@ class HipContext:
         self._call("pf_extract_diag", _ptr(vals), _ptr(out))
         return out
 
-    def cg(self, vals, b, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI, check_every=50,
+    def cg(self, vals, b, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI, check_every=0,
            allow_maxiter=False):
         """Jacobi-PCG on device.  Returns (x, iters, relres); raises RuntimeError on non-convergence
         like the reference (pyfem.py:2421-2422) unless allow_maxiter (fixed-iteration benchmarking)."""
