@@ -48,7 +48,7 @@ enum {
 
 enum { PF_QUAD4 = 4, PF_TRI3 = 3 };          /* nodes per element selects the element */
 enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
-enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2 };
+enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECOND_AMG_REUSE = 3 };
 
 /* ---- context -------------------------------------------------------------------------- */
 int pf_ctx_create(int device, pf_ctx** out);

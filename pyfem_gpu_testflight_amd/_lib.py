@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpyfem_hip.so")
 
 PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
-PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG = 0, 1, 2
+PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE = 0, 1, 2, 3
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double

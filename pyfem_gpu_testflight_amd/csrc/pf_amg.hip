@@ -27,7 +27,7 @@
 #include "pf_common.h"
 
 static constexpr int AMG_MAX_LEVELS = 12;
-static constexpr int AMG_COARSEST_DOFS = 384;
+static constexpr int AMG_COARSEST_DOFS = 160;  // dense inverse: cost ~ m^3 on one workgroup per numeric setup
 
 struct AmgLevel {
   int64_t n = 0;             // nodes
@@ -56,7 +56,9 @@ struct pf_amg {
   AmgLevel L[AMG_MAX_LEVELS];
   double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
   int64_t dense_m = 0;
-  double* gersh = nullptr;      // scratch for the Gershgorin bound / power iteration
+  double* gersh = nullptr;      // scratch vector for the power iteration
+  double* lam = nullptr;        // device: per-level |D^-1 A v|^2 + the not-SPD flag (AMG_MAX_LEVELS + 1 doubles)
+  bool numeric_ok = false;      // the numeric setup below matches L[0].vals
   int nsmooth = 2;              // damped-Jacobi sweeps before and after the coarse correction
   double over = 2.0;            // scaling of the coarse-grid correction: plain aggregation under-corrects.
                                 // 2048^2 plane stress, rtol 1e-8 (tools/amg_sweep.py): V(1,1)/1.0 180 its 572 ms,
@@ -127,11 +129,11 @@ static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const 
 // ------------------------------------------------------------------------------------------
 // device kernels
 // ------------------------------------------------------------------------------------------
-// decoupled dofs + Gershgorin bound of D^-1 A per dof
+// decoupled dofs + raw diagonal per dof; bad[0] is raised when a diagonal entry is negative
 template <int D>
 __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                            const double* __restrict__ vals, uint8_t* __restrict__ iso,
-                           double* __restrict__ diag, double* __restrict__ bound) {
+                           double* __restrict__ diag, double* __restrict__ bad) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   double off[D], dg[D];
@@ -152,13 +154,16 @@ __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int
   for (int k = 0; k < D; ++k) {
     iso[D * i + k] = (off[k] == 0.0) ? 1 : 0;
     if (dg[k] == 0.0) dg[k] = 1.0;  // empty / decoupled coarse dof: identity
+    if (!(dg[k] > 0.0)) bad[0] = 1.0;  // benign race: every writer stores the same value
     diag[D * i + k] = dg[k];
-    bound[D * i + k] = (fabs(dg[k]) + off[k]) / fabs(dg[k]);
   }
 }
 
-__global__ void k_amg_scale_dinv(int64_t n, double omega, double* __restrict__ d, const uint8_t* __restrict__ iso) {
+// lam2[0] = |D^-1 A v|^2 of the last power iteration; omega = scale * 4 / (3 * 1.1 * lambda_max)
+__global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ lam2, double scale, double* __restrict__ d,
+                                 const uint8_t* __restrict__ iso) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const double omega = scale * 4.0 / (3.3 * sqrt(lam2[0]));
   if (i < n) d[i] = (iso[i] ? 1.0 : omega) / d[i];  // decoupled dofs are solved exactly
 }
 
@@ -248,11 +253,17 @@ __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, con
   }
 }
 
-// generic block SpMV for the coarse levels: 64-node tiles, blocks streamed lane-per-block through LDS
-template <int D>
+// generic block SpMV for the coarse levels: 64-node tiles, blocks streamed lane-per-block through LDS.
+// MODE fuses the smoother into the product (the coarse levels are launch-bound, every fused pass counts):
+//   AMG_AX   y = A x                         AMG_RESID  y = b - A x
+//   AMG_SMOOTH y = x + dinv .* (b - A x)     (one damped-Jacobi sweep, y != x)
+//   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv .* (b - A x1)
+enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
+template <int D, int MODE>
 __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
                                                  const int32_t* __restrict__ idx, const double* __restrict__ vals,
-                                                 const double* __restrict__ x, double* __restrict__ y) {
+                                                 const double* __restrict__ x, double* __restrict__ y,
+                                                 const double* __restrict__ dinv, const double* __restrict__ b) {
   constexpr int CH = 448;
   __shared__ double prod[CH * D];
   const int lane = threadIdx.x;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
         const double* a = vals + (int64_t)g * D * D;
         double xv[D];
 #pragma unroll
-        for (int l = 0; l < D; ++l) xv[l] = x[D * m + l];
+        for (int l = 0; l < D; ++l) xv[l] = (MODE == AMG_SMOOTH0) ? dinv[D * m + l] * b[D * m + l] : x[D * m + l];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
           double s = 0.0;
@@ -290,7 +301,14 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
     }
     if (valid)
 #pragma unroll
-      for (int k = 0; k < D; ++k) y[D * i + k] = acc[k];
+      for (int k = 0; k < D; ++k) {
+        const int64_t q = D * i + k;
+        double out = acc[k];
+        if constexpr (MODE == AMG_RESID) out = b[q] - out;
+        if constexpr (MODE == AMG_SMOOTH) out = x[q] + dinv[q] * (b[q] - out);
+        if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * (2.0 * b[q] - out);
+        y[q] = out;
+      }
   }
 }
 
@@ -300,19 +318,12 @@ __global__ void k_amg_jacobi0(int64_t n, const double* __restrict__ dinv, const 
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     x[i] = dinv[i] * b[i];
 }
-// x += dinv .* (b - t)   with t = A x
-__global__ void k_amg_jacobi(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b,
-                             const double* __restrict__ t, double* __restrict__ x) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] += dinv[i] * (b[i] - t[i]);
-}
-
-// coarse rhs: bc_I = sum_{n in I} P_n^T (b_n - t_n)
+// coarse rhs: bc_I = sum_{n in I} P_n^T res_n
 template <int DR, int DC>
 __global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
                                const uint8_t* __restrict__ iso, const double* __restrict__ xy,
-                               const double* __restrict__ cxy, const double* __restrict__ b,
-                               const double* __restrict__ t, double* __restrict__ bc) {
+                               const double* __restrict__ cxy, const double* __restrict__ resid,
+                               double* __restrict__ bc) {
   const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (I >= nc) return;
   double s[DC];
@@ -325,7 +336,7 @@ __global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, con
     amg_P<DR, DC>(xy[2 * n] - cx, xy[2 * n + 1] - cy, iso + DR * n, Pn);
 #pragma unroll
     for (int r = 0; r < DR; ++r) {
-      const double res = b[DR * n + r] - t[DR * n + r];
+      const double res = resid[DR * n + r];
 #pragma unroll
       for (int c = 0; c < DC; ++c) s[c] += Pn[r][c] * res;
     }
@@ -365,38 +376,46 @@ __global__ void k_amg_to_dense(int64_t n, const int32_t* __restrict__ ptr, const
       for (int l = 0; l < D; ++l) A[(D * i + k) * m + D * (int64_t)idx[g] + l] = vals[(int64_t)g * D * D + k * D + l];
 }
 
-__global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ A, int64_t m) {
-  // in-place Gauss-Jordan without pivoting; rows/cols with a zero pivot are treated as identity
+__global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ A, int m) {
+  // in-place Gauss-Jordan without pivoting (SPD); rows/cols with a zero pivot are treated as identity.
+  // thread (ty, tx) sweeps rows ty, ty+32, ... and columns tx, tx+32, ...: no integer division
   __shared__ double piv_row[AMG_COARSEST_DOFS];
   __shared__ double piv_col[AMG_COARSEST_DOFS];
-  for (int64_t p = 0; p < m; ++p) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int p = 0; p < m; ++p) {
     double pv = A[p * m + p];
     if (pv == 0.0) pv = 1.0;
     const double ip = 1.0 / pv;
-    for (int64_t j = threadIdx.x; j < m; j += blockDim.x) {
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
       piv_row[j] = A[p * m + j];
       piv_col[j] = A[j * m + p];
     }
     __syncthreads();
-    for (int64_t q = threadIdx.x; q < m * m; q += blockDim.x) {
-      const int64_t i = q / m, j = q % m;
-      double v;
-      if (i == p && j == p) v = ip;
-      else if (i == p) v = piv_row[j] * ip;
-      else if (j == p) v = -piv_col[i] * ip;
-      else v = A[q] - piv_col[i] * piv_row[j] * ip;
-      A[q] = v;
+    for (int i = ty; i < m; i += 32) {
+      const double ci = piv_col[i];
+      for (int j = tx; j < m; j += 32) {
+        double v;
+        if (i == p && j == p) v = ip;
+        else if (i == p) v = piv_row[j] * ip;
+        else if (j == p) v = -ci * ip;
+        else v = A[i * m + j] - ci * piv_row[j] * ip;
+        A[i * m + j] = v;
+      }
     }
     __syncthreads();
   }
 }
 
-__global__ void k_amg_dense_apply(int64_t m, const double* __restrict__ Ainv, const double* __restrict__ b,
+// x = Ainv b; Ainv is symmetric, so lane i walks column i (= row i) with coalesced reads
+__global__ void k_amg_dense_apply(int m, const double* __restrict__ Ainv, const double* __restrict__ b,
                                   double* __restrict__ x) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  __shared__ double sb[AMG_COARSEST_DOFS];
+  for (int j = threadIdx.x; j < m; j += blockDim.x) sb[j] = b[j];
+  __syncthreads();
+  const int i = threadIdx.x;
   if (i >= m) return;
   double s = 0.0;
-  for (int64_t j = 0; j < m; ++j) s += Ainv[i * m + j] * b[j];
+  for (int j = 0; j < m; ++j) s += Ainv[j * m + i] * sb[j];
   x[i] = s;
 }
 
@@ -416,6 +435,7 @@ void pf_amg_free(pf_ctx* ctx) {
   }
   pf_free(H->dense_inv);
   pf_free(H->gersh);
+  pf_free(H->lam);
   delete H;
   ctx->amg = nullptr;
 }
@@ -484,14 +504,26 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   int64_t maxdof = 1;
   for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
   PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
+  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 1)));
   return PF_OK;
 }
 
-static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y) {
-  if (level == 0) return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr);
+static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y, int mode = AMG_AX,
+                    const double* b = nullptr) {
+  if (level == 0) {
+    if (mode == AMG_SMOOTH0) return pf_fail(ctx, PF_E_INVALID, "amg_spmv: AMG_SMOOTH0 is a coarse-level mode");
+    return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr, mode == AMG_SMOOTH ? Lv.dinv : nullptr,
+                          mode == AMG_AX ? nullptr : b);
+  }
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
-  if (Lv.dr == 1) k_amg_spmv<1><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y);
-  else k_amg_spmv<3><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y);
+#define PF_AS(D_, M_) k_amg_spmv<D_, M_><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, Lv.dinv, b)
+#define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else PF_AS(3, M_); } while (0)
+  if (mode == AMG_AX) PF_ASD(AMG_AX);
+  else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
+  else if (mode == AMG_RESID) PF_ASD(AMG_RESID);
+  else PF_ASD(AMG_SMOOTH0);
+#undef PF_ASD
+#undef PF_AS
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -510,11 +542,11 @@ __global__ void k_amg_pow_norm(int64_t n, const double* __restrict__ s, double* 
   if (i < n) v[i] *= rsqrt(s[0]);
 }
 
-// lambda_max(D^-1 A) by a few power iterations (all on device, one scalar read at the end).  Lv.dinv still
-// holds the raw diagonal; v is scratch of at least ndof doubles, sdev one device double.  Unlike a
-// Gershgorin row sum this is invariant under the scaling of individual dofs, which matters on the
-// coarse levels where translations and the rotation have different units.
-static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* sdev, double* lam_host) {
+// lambda_max(D^-1 A) by a few power iterations, all on the device: lam2 (one device double) ends up
+// holding |D^-1 A v|^2 with |v| = 1.  Lv.dinv still holds the raw diagonal; v is scratch of at least ndof
+// doubles.  Unlike a Gershgorin row sum this is invariant under the scaling of individual dofs, which
+// matters on the coarse levels where translations and the rotation have different units.
+static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2) {
   const int64_t ndof = Lv.n * Lv.dr;
   const unsigned g = (unsigned)cdiv(ndof, 256);
   k_amg_pow_init<<<g, 256, 0, ctx->stream>>>(ndof, v);
@@ -522,63 +554,41 @@ static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, dou
     int rc = amg_spmv(ctx, Lv, level, v, Lv.t);
     if (rc) return rc;
     k_amg_pow_div<<<g, 256, 0, ctx->stream>>>(ndof, Lv.dinv, Lv.t, v);
-    rc = pf_dot(ctx, ndof, v, v, nullptr, sdev);
+    rc = pf_dot(ctx, ndof, v, v, nullptr, lam2);
     if (rc) return rc;
-    if (it + 1 < 10) k_amg_pow_norm<<<g, 256, 0, ctx->stream>>>(ndof, sdev, v);
+    if (it + 1 < 10) k_amg_pow_norm<<<g, 256, 0, ctx->stream>>>(ndof, lam2, v);
   }
   PF_LAUNCH_CHECK();
-  double s = 0.0;
-  PF_HIP(hipMemcpyAsync(&s, sdev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  PF_HIP(hipStreamSynchronize(ctx->stream));
-  *lam_host = sqrt(s);  // |D^-1 A v| with |v| = 1
   return PF_OK;
 }
 
-template <int D>
-static int amg_level_rows(pf_ctx* ctx, pf_amg* H, AmgLevel& Lv, int level, double* scratch, double* lmax_host) {
-  const int64_t ndof = Lv.n * D;
-  k_amg_rows<D><<<(unsigned)cdiv(Lv.n, 256), 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, scratch);
-  PF_LAUNCH_CHECK();
-  // max of the Gershgorin bound and min of the diagonal, on the host (setup path)
-  std::vector<double> h(ndof), dg(ndof);
-  PF_HIP(hipMemcpyAsync(h.data(), scratch, sizeof(double) * ndof, hipMemcpyDeviceToHost, ctx->stream));
-  PF_HIP(hipMemcpyAsync(dg.data(), Lv.dinv, sizeof(double) * ndof, hipMemcpyDeviceToHost, ctx->stream));
-  PF_HIP(hipStreamSynchronize(ctx->stream));
-  double lm = 1.0, dmin = 1e300;
-  for (int64_t i = 0; i < ndof; ++i) { lm = std::max(lm, h[i]); dmin = std::min(dmin, dg[i]); }
-  *lmax_host = lm;
-  if (!(dmin > 0.0)) return PF_E_UNSUPPORTED;  // not positive definite: the caller falls back to Jacobi
-  // damping from lambda_max(D^-1 A): power iteration (a slight under-estimate, hence the 1.1)
-  double lam = lm;
-  int prc = amg_power_lambda(ctx, Lv, level, scratch, ctx->scal + (size_t)PF_NPART * PF_NPART_ARRAYS + 16, &lam);
-  if (prc) return prc;
-  lam *= 1.1;
-  if (!(lam > 0.0) || !(lam < 1e300)) lam = lm;
-  Lv.omega = H->omega_scale * 4.0 / (3.0 * lam);
-  k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, Lv.omega, Lv.dinv, Lv.iso);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-// numeric part, once per matrix.  Returns PF_E_UNSUPPORTED (without touching ctx->err) when a diagonal
-// entry is not positive -- e.g. the all-negative-detJ arm mesh -- so pf_cg can use Jacobi.
-int pf_amg_setup(pf_ctx* ctx, const double* vals) {
+// numeric part, once per matrix: diagonals, Galerkin products, damping factors, coarsest inverse -- all
+// queued on the stream with ONE host read at the end (the per-level lambda estimates and the SPD flag).
+// Returns PF_E_UNSUPPORTED (without touching ctx->err) when a diagonal entry is not positive -- e.g. the
+// all-negative-detJ arm mesh -- so pf_cg can use Jacobi.  With reuse != 0 the numeric setup of
+// the previous call is kept if it was made for the same value array (the caller asserts the values are
+// unchanged, e.g. the constant Helmholtz filter matrix).
+int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (!ctx->amg) {
     int rc = amg_build_hierarchy(ctx);
     if (rc) { pf_amg_free(ctx); return rc; }
   }
   pf_amg* H = ctx->amg;
+  if (reuse && H->numeric_ok && H->L[0].vals == vals) return PF_OK;
+  H->numeric_ok = false;
   H->L[0].vals = const_cast<double*>(vals);
   if (const char* e = getenv("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
   if (const char* e = getenv("PF_AMG_OVER")) H->over = atof(e);
   if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
-  double lm = 0.0;
+  double* bad = H->lam + AMG_MAX_LEVELS;
+  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 1), ctx->stream));
   for (int l = 0; l < H->nlevels; ++l) {
     AmgLevel& Lv = H->L[l];
-    int rc = (Lv.dr == 1) ? amg_level_rows<1>(ctx, H, Lv, l, H->gersh, &lm)
-           : (Lv.dr == 2) ? amg_level_rows<2>(ctx, H, Lv, l, H->gersh, &lm)
-                          : amg_level_rows<3>(ctx, H, Lv, l, H->gersh, &lm);
-    if (rc) return rc;
+    const unsigned gr = (unsigned)cdiv(Lv.n, 256);
+    if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
+    else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
+    else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
+    PF_LAUNCH_CHECK();
     if (l + 1 == H->nlevels) break;
     AmgLevel& Nx = H->L[l + 1];
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
@@ -591,45 +601,79 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals) {
 #undef PF_GAL
     PF_LAUNCH_CHECK();
   }
+  // damping per level from lambda_max(D^-1 A) (power iteration under-estimates slightly, hence the 1.1)
+  for (int l = 0; l < H->nlevels; ++l) {
+    AmgLevel& Lv = H->L[l];
+    const int64_t ndof = Lv.n * Lv.dr;
+    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l);
+    if (rc) return rc;
+    k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, H->lam + l, H->omega_scale, Lv.dinv, Lv.iso);
+    PF_LAUNCH_CHECK();
+  }
   if (H->dense_inv) {
     AmgLevel& C = H->L[H->nlevels - 1];
     PF_HIP(hipMemsetAsync(H->dense_inv, 0, sizeof(double) * H->dense_m * H->dense_m, ctx->stream));
     const unsigned g = (unsigned)cdiv(C.n, 128);
     if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
     else k_amg_to_dense<3><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
-    k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, H->dense_m);
+    k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
     PF_LAUNCH_CHECK();
   }
+  double h[AMG_MAX_LEVELS + 1];
+  PF_HIP(hipMemcpyAsync(h, H->lam, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  if (h[AMG_MAX_LEVELS] != 0.0) return PF_E_UNSUPPORTED;  // not positive definite
+  for (int l = 0; l < H->nlevels; ++l) {
+    const double lam = 1.1 * sqrt(h[l]);
+    if (!(lam > 0.0) || !(lam < 1e300)) return PF_E_UNSUPPORTED;
+    H->L[l].omega = H->omega_scale * 4.0 / (3.0 * lam);
+  }
+  H->numeric_ok = true;
   return PF_OK;
 }
 
-// z = M^-1 r : one V(1,1) cycle.  r and z are fine-level vectors of the caller.
+// z = M^-1 r : one V(nsmooth, nsmooth) cycle.  r and z are fine-level vectors of the caller.  The damped
+// Jacobi sweeps are fused into the products (x_out = x_in + dinv (b - A x_in)), so the iterate ping-pongs
+// between the level's x and t buffers: it changes buffer 2 nsmooth - 1 times per level (always odd), so
+// it starts in t and the level's result lands in x (= z on the fine level).
 int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
   pf_amg* H = ctx->amg;
   if (!H) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: no hierarchy");
   hipStream_t st = ctx->stream;
   const int Lc = H->nlevels - 1;
   auto vg = [](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); };
+  double* cur[AMG_MAX_LEVELS];
+  double* oth[AMG_MAX_LEVELS];
+  int rc;
   // down
   for (int l = 0; l < Lc; ++l) {
     AmgLevel& Lv = H->L[l];
     AmgLevel& Nx = H->L[l + 1];
     const double* b = (l == 0) ? r : Lv.b;
-    double* x = (l == 0) ? z : Lv.x;
+    double* c = Lv.t;
+    double* o = (l == 0) ? z : Lv.x;
     const int64_t ndof = Lv.n * Lv.dr;
-    k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, x);
-    int rc = amg_spmv(ctx, Lv, l, x, Lv.t);
-    if (rc) return rc;
-    for (int s = 1; s < H->nsmooth; ++s) {
-      k_amg_jacobi<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, Lv.t, x);
-      rc = amg_spmv(ctx, Lv, l, x, Lv.t);
-      if (rc) return rc;
+    int done;
+    if (l > 0 && H->nsmooth >= 2) {  // first two sweeps in one launch; counts as one buffer change
+      if ((rc = amg_spmv(ctx, Lv, l, nullptr, o, AMG_SMOOTH0, b))) return rc;
+      std::swap(c, o);
+      done = 2;
+    } else {
+      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, c);
+      done = 1;
     }
+    for (; done < H->nsmooth; ++done) {
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
+      std::swap(c, o);
+    }
+    if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
-    if (Lv.dr == 1) k_amg_restrict<1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
-    else if (Lv.dr == 2) k_amg_restrict<2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
-    else k_amg_restrict<3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, b, Lv.t, Nx.b);
+    if (Lv.dr == 1) k_amg_restrict<1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else if (Lv.dr == 2) k_amg_restrict<2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else k_amg_restrict<3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
     PF_LAUNCH_CHECK();
+    cur[l] = c;
+    oth[l] = o;
   }
   // coarsest
   {
@@ -638,13 +682,14 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     double* x = (Lc == 0) ? z : C.x;
     const int64_t ndof = C.n * C.dr;
     if (H->dense_inv && Lc > 0) {
-      k_amg_dense_apply<<<(unsigned)cdiv(ndof, 64), 64, 0, st>>>(ndof, H->dense_inv, b, x);
-    } else {  // could not coarsen down to the dense size: a few Jacobi sweeps
-      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, x);
-      for (int s = 0; s < 4 && Lc > 0; ++s) {
-        int rc = amg_spmv(ctx, C, Lc, x, C.t);
-        if (rc) return rc;
-        k_amg_jacobi<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, C.t, x);
+      k_amg_dense_apply<<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
+    } else {  // could not coarsen down to the dense size (or a one-level hierarchy): Jacobi sweeps
+      double* c = x;
+      double* o = C.t;
+      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, c);
+      for (int s = 0; s < 4 && Lc > 0; ++s) {  // even count: the result is back in x
+        if ((rc = amg_spmv(ctx, C, Lc, c, o, AMG_SMOOTH, b))) return rc;
+        std::swap(c, o);
       }
     }
     PF_LAUNCH_CHECK();
@@ -654,18 +699,18 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     AmgLevel& Lv = H->L[l];
     AmgLevel& Nx = H->L[l + 1];
     const double* b = (l == 0) ? r : Lv.b;
-    double* x = (l == 0) ? z : Lv.x;
-    const int64_t ndof = Lv.n * Lv.dr;
+    double* c = cur[l];
+    double* o = oth[l];
     const unsigned g = (unsigned)cdiv(Lv.n, 256);
-    if (Lv.dr == 1) k_amg_prolong<1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x, H->over);
-    else if (Lv.dr == 2) k_amg_prolong<2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x, H->over);
-    else k_amg_prolong<3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, x, H->over);
+    if (Lv.dr == 1) k_amg_prolong<1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else if (Lv.dr == 2) k_amg_prolong<2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else k_amg_prolong<3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
     for (int s = 0; s < H->nsmooth; ++s) {
-      int rc = amg_spmv(ctx, Lv, l, x, Lv.t);
-      if (rc) return rc;
-      k_amg_jacobi<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, Lv.t, x);
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
+      std::swap(c, o);
     }
     PF_LAUNCH_CHECK();
+    if (c != ((l == 0) ? z : Lv.x)) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: buffer parity");
   }
   return PF_OK;
 }

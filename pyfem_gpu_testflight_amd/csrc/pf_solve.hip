@@ -84,6 +84,8 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 
 // ------------------------------------------------------------------------------------------
 // y = A x ; optionally dot_part[blockIdx.x] = sum over this wave's rows of x_i y_i
+//   smoother epilogues for the AMG cycle (no extra pass over the vectors): with sm_b and sm_dinv
+//   y = x + dinv .* (b - A x) (one damped-Jacobi sweep, y != x), with sm_b alone y = b - A x.
 //   R = node rows per lane (tile = 64*R nodes), U = blocks per lane in flight, CH = LDS strip entries.
 //   d=1 moves a third of the bytes of d=2 per node, so it takes R=2 / U=6 to amortise the per-tile
 //   overhead (r01: 50 % of peak at R=1/U=3).
@@ -92,7 +94,8 @@ template <int D, int R, int U, int CH>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
-                                             double* __restrict__ dot_part) {
+                                             double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
+                                             const double* __restrict__ sm_b) {
   using V = typename Vec<D>::T;
   constexpr int TILE = 64 * R;
   __shared__ V prod[CH];
@@ -167,6 +170,21 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
     for (int r = 0; r < R; ++r) {
       const int64_t n = tile * TILE + r * 64 + lane;
       if (n < nnodes) {
+        if (sm_b) {
+          if constexpr (D == 1) {
+            const double res = sm_b[n] - acc[r];
+            acc[r] = sm_dinv ? x[n] + sm_dinv[n] * res : res;
+          } else {
+            const double2 bv = *reinterpret_cast<const double2*>(sm_b + 2 * n);
+            double2 res = make_double2(bv.x - acc[r].x, bv.y - acc[r].y);
+            if (sm_dinv) {
+              const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
+              const double2 dv = *reinterpret_cast<const double2*>(sm_dinv + 2 * n);
+              res = make_double2(xv.x + dv.x * res.x, xv.y + dv.y * res.y);
+            }
+            acc[r] = res;
+          }
+        }
         if constexpr (D == 1) {
           y[n] = acc[r];
           if (dot_part) dacc += x[n] * acc[r];
@@ -447,7 +465,8 @@ static inline unsigned spmv_grid_d(int64_t nnodes, int d) {
 }
 static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
 
-int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part) {
+int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
+                   const double* sm_dinv, const double* sm_b) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
 #ifdef PF_SPMV_SWEEP
   const char* sh = getenv("PF_SPMV_SHAPE");
@@ -455,7 +474,7 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
 #define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
   if (shape == ID && ctx->d == D_) {                                                                        \
     grid = (unsigned)std::min<int64_t>(cdiv(ctx->nnodes, 64 * R_), SPMV_MAXGRID);                            \
-    k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part); \
+    k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b); \
     PF_LAUNCH_CHECK();                                                                                      \
     return PF_OK;                                                                                           \
   }
@@ -464,9 +483,9 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
 #undef PF_TRY
 #endif
   if (ctx->d == 1)
-    k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
+    k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   else
-    k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part);
+    k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -576,8 +595,11 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
                      int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d && vals && b && x, "pf_cg: no pattern / NULL argument");
-  PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI || precond == PF_PRECOND_AMG,
+  PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI || precond == PF_PRECOND_AMG ||
+                 precond == PF_PRECOND_AMG_REUSE,
              "pf_cg: unknown preconditioner");
+  const int amg_reuse = precond == PF_PRECOND_AMG_REUSE;
+  if (amg_reuse) precond = PF_PRECOND_AMG;
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);  // scipy's default
@@ -593,7 +615,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
 
   if (precond == PF_PRECOND_AMG) {
-    const int arc = pf_amg_setup(ctx, vals);
+    const int arc = pf_amg_setup(ctx, vals, amg_reuse);
     if (arc == PF_E_UNSUPPORTED) precond = PF_PRECOND_JACOBI;  // not positive definite (e.g. detJ < 0 meshes)
     else if (arc) return arc;
   }

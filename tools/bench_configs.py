@@ -132,29 +132,31 @@ def topo_iteration(name, nx, ny):
     xk = h.to_device(np.random.default_rng(0).uniform(1e-3, 1, X.shape[0]), torch.float64)
     asm = pyfem.Assembler(model)
     asm.rtol = 1e-8
-    filtr.apply(xk)  # first solves build the (graph-only) AMG hierarchies once per mesh; not timed
-    Kw = model.compute_jacobian(xk)
-    Kw, rw = model.apply_dirichlet_bcs(Kw, h.to_device(model.compute_rhs(), torch.float64), True)
-    h.cg(Kw.vals, rw, rtol=1e-2, precond=_lib.PF_PRECOND_AMG)
-    sync()
-    t0 = time.perf_counter()
-    rho = filtr.apply(xk).clamp(1e-3, 1.0)
-    sync()
-    t1 = time.perf_counter()
-    K = model.compute_jacobian(rho)
-    rhs = h.to_device(model.compute_rhs(), torch.float64)
-    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
-    sync()
-    t2 = time.perf_counter()
-    u = asm._solve_linear_system(K, rhs, "cg")
-    comp = float(rhs.dot(u))
-    sync()
-    t3 = time.perf_counter()
     g = torch.ones_like(xk)
-    for _ in range(3):
-        filtr.apply_gradient(g)
-    sync()
-    t4 = time.perf_counter()
+
+    def iteration():
+        sync()
+        t0 = time.perf_counter()
+        rho = filtr.apply(xk).clamp(1e-3, 1.0)
+        sync()
+        t1 = time.perf_counter()
+        K = model.compute_jacobian(rho)
+        rhs = h.to_device(model.compute_rhs(), torch.float64)
+        K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+        sync()
+        t2 = time.perf_counter()
+        u = asm._solve_linear_system(K, rhs, "cg")
+        comp = float(rhs.dot(u))
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(3):
+            filtr.apply_gradient(g)
+        sync()
+        t4 = time.perf_counter()
+        return t0, t1, t2, t3, t4, comp
+
+    iteration()  # the first pass builds the (graph-only) AMG hierarchies once per mesh and loads every kernel
+    t0, t1, t2, t3, t4, comp = iteration()
     return {"config": name, "nelems": h.nelems, "filter_apply_s": t1 - t0, "filter_iters": filtr.last_iters,
             "assemble_bc_s": t2 - t1, "elasticity_solve_s": t3 - t2, "elasticity_cg_iters": asm.last_iters,
             "compliance": comp, "three_filter_gradients_s": t4 - t3, "iteration_total_s": t4 - t0}
