@@ -356,32 +356,34 @@ struct V3Tile {       // wave-uniform tile scalars (scalar loads, two tiles ahea
 // All prefetch loads are UNCONDITIONAL with clamped indices: a load under `if (active)` that is merged
 // with a default at the join makes hipcc wait for it on the spot (s_waitcnt vmcnt right behind the
 // issue), which exposes a full memory latency per tile.
-__device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, int32_t npt, int64_t nnodes,
-                                               const int32_t* __restrict__ nptr,
-                                               const int32_t* __restrict__ n2e_ptr) {  // uniform -> s_load
-  V3Tile T;
-  const int64_t tc = min(t, t1 - 1);
-  const int64_t na = tc * npt, nb = min(na + npt, nnodes);
-  T.n0 = (int32_t)na;
-  T.vb = n2e_ptr[na];
-  T.ve = (t < t1) ? n2e_ptr[nb] : T.vb;
-  T.base = nptr[na];
-  T.nblk = nptr[nb] - T.base;
+__device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, const int4* __restrict__ tile_desc) {
+  V3Tile T;  // t is wave-uniform: ONE 16-byte scalar load
+  const int4 dsc = tile_desc[min(t, t1 - 1)];
+  T.n0 = dsc.x;
+  T.vb = dsc.y;
+  T.ve = (t < t1) ? dsc.y + ((dsc.w >> 8) & 255) : dsc.y;
+  T.base = dsc.z;
+  T.nblk = (int32_t)((uint32_t)dsc.w >> 16);
   return T;
 }
 
+template <int ABL = 0>
 __device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t nvis, int64_t nnodes,
                                              const int4* __restrict__ vis_rec, const int32_t* __restrict__ nptr) {
   V3Rec B;
   const int32_t jj = T.vb + lane;
   B.active = jj < T.ve;
   B.n0 = T.n0;
-  B.rec = vis_rec[min(jj, nvis - 1)];
+  if constexpr (ABL & 16) {  // ablation: no record stream (fake positions inside the first row)
+    B.rec = make_int4(T.n0, T.n0 + 1, T.n0 + 2, (int)((lane & 3) | (1 << 6) | (2 << 12) | (3 << 18) | ((lane & 3) << 24) | ((lane >> 2) << 26)));
+  } else {
+    B.rec = vis_rec[min(jj, nvis - 1)];
+  }
   B.rp = nptr[min((int64_t)T.n0 + lane, nnodes)];
   return B;
 }
 
-template <int P, bool RHO>
+template <int P, bool RHO, int ABL = 0>
 __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __restrict__ X,
                                               const double* __restrict__ rho, V3Visit<P, RHO>& C) {
   const uint32_t w = (uint32_t)B.rec.w;
@@ -395,6 +397,11 @@ __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __re
   nd[1] = (a == 1) ? n : ((a < 1) ? B.rec.x : B.rec.y);
   nd[2] = (a == 2) ? n : ((a < 2) ? B.rec.y : B.rec.z);
   nd[3] = (a == 3) ? n : B.rec.z;
+  if constexpr (ABL & 16) {  // ablation: no coordinate gathers
+#pragma unroll
+    for (int b = 0; b < P; ++b) { C.el.x[b] = (double)nd[b]; C.el.y[b] = (double)(nd[b] + b); C.rho_e[b] = 1.0; }
+    return;
+  }
   const double2 p0 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[0]);
   const double2 p1 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[1]);
   const double2 p2 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[2]);
@@ -450,8 +457,10 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
     for (int b = 0; b < P; ++b) {
       const int blk = roff + (int)((Cuse.w >> (6 * b)) & 63);
 #pragma unroll
-      for (int k = 0; k < V; ++k)
-        __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      for (int k = 0; k < V; ++k) {
+        if constexpr (ABL & 8) img[k * plane + blk] = v[b][k];  // ablation: plain LDS store (wrong sums)
+        else __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
   }
 
@@ -493,10 +502,10 @@ __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V
 }
 
 template <int P, class Phys, bool RHO, int NOUT, int ABL = 0>
-__global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt, int32_t maxrow,
+__global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
-                                                    const int32_t* __restrict__ n2e_ptr,
+                                                    const int4* __restrict__ tile_desc,
                                                     const int4* __restrict__ vis_rec, int32_t nvis, int32_t strided,
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1, double* __restrict__ trash) {
@@ -504,22 +513,26 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   double* const img = reinterpret_cast<double*>(smem);
   const int plane = npt * maxrow + 1;  // odd plane stride: the V planes start on different banks
   const int lane = threadIdx.x;
-  const int64_t ntiles = (nnodes + npt - 1) / npt;
   // tile walk: contiguous run per wave (tstride == 1) or round-robin over the grid (tstride == gridDim)
+  // strided == 2: XCD-aware round-robin.  Workgroups are dealt to the 8 XCDs round-robin (b % 8), so with
+  // the plain strided walk neighbouring tiles always sit on different XCDs: the cache line shared by two
+  // adjacent segments is then written back partially by two L2s.  Renumber the blocks so that one XCD's
+  // blocks take a contiguous eighth of every grid-wide row of tiles.
   const int64_t tstride = strided ? gridDim.x : 1;
-  const int64_t t0 = strided ? blockIdx.x : ntiles * blockIdx.x / gridDim.x;
+  const int64_t vblk = (strided == 2) ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int64_t t0 = strided ? vblk : ntiles * blockIdx.x / gridDim.x;
   const int64_t t1 = strided ? ntiles : ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
 
   // Pipeline state.  Two register sets (a/b) are used on alternate tiles, so nothing a load is about to
   // write is ever copied: a rotation by copy would have to wait for the loads just issued.
-  V3Tile T0 = v3_load_tile(t0, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Tile T1 = v3_load_tile(t0 + tstride, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Tile T2 = v3_load_tile(t0 + 2 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
-  V3Rec Ba = v3_load_rec(T0, lane, nvis, nnodes, vis_rec, nptr);
-  V3Rec Bb = v3_load_rec(T1, lane, nvis, nnodes, vis_rec, nptr);
+  V3Tile T0 = v3_load_tile(t0, t1, tile_desc);
+  V3Tile T1 = v3_load_tile(t0 + tstride, t1, tile_desc);
+  V3Tile T2 = v3_load_tile(t0 + 2 * tstride, t1, tile_desc);
+  V3Rec Ba = v3_load_rec<ABL>(T0, lane, nvis, nnodes, vis_rec, nptr);
+  V3Rec Bb = v3_load_rec<ABL>(T1, lane, nvis, nnodes, vis_rec, nptr);
   V3Visit<P, RHO> Ca, Cb;
-  v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
+  v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "five stores are younger than it" (back edge: vmcnt(5) is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -533,14 +546,14 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int32_t npt,
   int64_t t = t0;
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
-    const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
-    v3_load_visit<P, RHO>(Bb, X, pr.rho, Cb);
-    Ba = v3_load_rec(T2, lane, nvis, nnodes, vis_rec, nptr);
+    const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, tile_desc);
+    v3_load_visit<P, RHO, ABL>(Bb, X, pr.rho, Cb);
+    Ba = v3_load_rec<ABL>(T2, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
-    const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, npt, nnodes, nptr, n2e_ptr);
-    v3_load_visit<P, RHO>(Ba, X, pr.rho, Ca);
-    Bb = v3_load_rec(T3, lane, nvis, nnodes, vis_rec, nptr);
+    const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, tile_desc);
+    v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca);
+    Bb = v3_load_rec<ABL>(T3, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
     T0 = T2; T1 = T3; T2 = T4;
   }
@@ -968,19 +981,30 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
         if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 5, 1>;
         else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 5, 4>;
         else if (abl == 5) k3 = k_assemble_v3<P, Phys, RHO, 5, 5>;
+        else if (abl == 8) k3 = k_assemble_v3<P, Phys, RHO, 5, 8>;
+        else if (abl == 9) k3 = k_assemble_v3<P, Phys, RHO, 5, 9>;
+        else if (abl == 12) k3 = k_assemble_v3<P, Phys, RHO, 5, 12>;
+        else if (abl == 13) k3 = k_assemble_v3<P, Phys, RHO, 5, 13>;
+        else if (abl == 16) k3 = k_assemble_v3<P, Phys, RHO, 5, 16>;
+        else if (abl == 25) k3 = k_assemble_v3<P, Phys, RHO, 5, 25>;
+        else if (abl == 29) k3 = k_assemble_v3<P, Phys, RHO, 5, 29>;
       }
     } else if (per_lane <= 10 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 10, 0>;
     }
     if (lds3 > 48 * 1024)
       PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    const int64_t nt = cdiv(ctx->nnodes, ctx->npt);
+    const int64_t nt = ctx->ntiles;
     int wpc = 24;  // persistent waves per CU (r03 sweep: 24-32 best)
     const char* g3 = getenv("PF_GATHER_WAVES_PER_CU");
     if (g3 && atoi(g3) > 0) wpc = atoi(g3);
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
-    hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->npt, ctx->max_row_blocks, ctx->X,
-                       ctx->nptr, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), (int32_t)(ctx->nelems * ctx->P), (int32_t)!(getenv("PF_TILE_ORDER") && getenv("PF_TILE_ORDER")[0] == 'c'), pr, out0, out1,
+    // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
+    const char* to = getenv("PF_TILE_ORDER");
+    int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
+    if (tile_order == 2 && (grid3 & 7)) tile_order = 1;
+    hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks, ctx->X,
+                       ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc), reinterpret_cast<const int4*>(ctx->vis_rec), (int32_t)(ctx->nelems * ctx->P), tile_order, pr, out0, out1,
                        ctx->scal + (size_t)PF_NPART * PF_NPART_ARRAYS /* 16 spare doubles: trash line */);
     PF_LAUNCH_CHECK();
     return PF_OK;

@@ -37,7 +37,9 @@ struct pf_ctx {
                                //   position of conn[e,b] in row n of the node graph
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
-  int npt = 0;                 // nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
+  int npt = 0;                 // max nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
+  void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | visits<<8 | blocks<<16}
+  int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 
   pf_amg* amg = nullptr;       // AMG hierarchy (graph part built once per pattern, pf_amg.hip)

@@ -15,6 +15,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "pf_common.h"
+#include <vector>
 
 thread_local std::string g_pf_err;
 
@@ -132,10 +133,10 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
 
 // visit-ordered element records for the assembly kernel, ONE 16-byte load per incident pair jj of
 // node n:  {o0, o1, o2, w}  where o* are the element's node ids other than n (ascending local index) and
-//   w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | (n mod npt)<<26
+//   w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | (slot of n in its tile)<<26
 // (pos_b = position of element node b in n's row, a = local index of n in the element).
 template <int P>
-__global__ void k_build_visits(int64_t nnodes, int npt, const int32_t* __restrict__ conn,
+__global__ void k_build_visits(int64_t nnodes, const uint8_t* __restrict__ slot, const int32_t* __restrict__ conn,
                                const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
                                const uint8_t* __restrict__ n2e_pos, int4* __restrict__ vis_rec) {
   int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -146,7 +147,7 @@ __global__ void k_build_visits(int64_t nnodes, int npt, const int32_t* __restric
     const int a = ea - e * P;
     int32_t o[3] = {0, 0, 0};
     int k = 0;
-    uint32_t w = ((uint32_t)a << 24) | ((uint32_t)(n & (npt - 1)) << 26);
+    uint32_t w = ((uint32_t)a << 24) | ((uint32_t)slot[n] << 26);
     for (int b = 0; b < P; ++b) {
       if (b != a) o[k++] = conn[(int64_t)e * P + b];
       w |= (uint32_t)n2e_pos[(int64_t)jj * 4 + b] << (6 * b);
@@ -234,6 +235,8 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->diagpos);
   pf_free(ctx->e2pos);
   pf_free(ctx->vis_rec);
+  pf_free(ctx->tile_desc);
+  ctx->ntiles = 0;
   ctx->npt = 0;
   ctx->d = 0;
   ctx->nblocks = 0;
@@ -392,12 +395,55 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   ctx->npt = ctx->max_valence <= 4 ? 16 : ctx->max_valence <= 8 ? 8 : ctx->max_valence <= 16 ? 4
            : ctx->max_valence <= 32 ? 2 : ctx->max_valence <= 64 ? 1 : 0;
   if (ctx->npt) {
+    // Tiles: runs of <= npt consecutive nodes.  A tile's rows are one contiguous segment of the value array,
+    // copied out by one wave; neighbouring segments are written by different CUs, and a cache line shared by
+    // two of them reaches HBM as two partial writes (tools/micro/wbench.hip: 4.0-4.4 TB/s instead of 5.5).
+    // So a tile may stop up to 3 nodes early when that puts its end on a better-aligned block boundary
+    // (128 bytes = 128/(8 d d) blocks); interior rows then stay aligned until the next irregular row.
+    // Greedy and sequential, hence on the host: two int32 arrays down, 16 bytes per tile + 1 byte per node up.
+    std::vector<int32_t> hp(nn + 1), hv(nn + 1);
+    PF_HIP(hipMemcpyAsync(hp.data(), ctx->nptr, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipMemcpyAsync(hv.data(), ctx->n2e_ptr, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    int lgA = 0;
+    while ((8 * d * d << lgA) < 128) ++lgA;
+    std::vector<int32_t> desc;
+    desc.reserve(4 * (size_t)(nn / ctx->npt + 16));
+    std::vector<uint8_t> slot(nn);
+    const bool fixed = getenv("PF_TILE_FIXED") != nullptr;  // ablation: npt nodes per tile, no alignment search
+    for (int64_t n0 = 0; n0 < nn;) {
+      int64_t emax = std::min<int64_t>(n0 + ctx->npt, nn);
+      while (hv[emax] - hv[n0] > 64) --emax;  // cannot happen with npt from max_valence; kept as a guard
+      int64_t e = emax;
+      if (emax < nn && !fixed) {
+        int best = -1;
+        for (int64_t c = emax; c > n0 && c > emax - 4; --c) {
+          const int score = std::min(hp[c] ? __builtin_ctz((unsigned)hp[c]) : 31, lgA);
+          if (score > best) { best = score; e = c; }
+        }
+      }
+      for (int64_t n = n0; n < e; ++n) slot[n] = (uint8_t)(n - n0);
+      desc.push_back((int32_t)n0);
+      desc.push_back(hv[n0]);
+      desc.push_back(hp[n0]);
+      desc.push_back((int32_t)((e - n0) | ((int64_t)(hv[e] - hv[n0]) << 8) | ((int64_t)(hp[e] - hp[n0]) << 16)));
+      n0 = e;
+    }
+    ctx->ntiles = (int64_t)desc.size() / 4;
+    PF_REQUIRE((int64_t)ctx->npt * ctx->max_row_blocks < 65536, "pf_pattern_build: tile too large for the descriptor");
+    uint8_t* dslot = nullptr;
+    PF_HIP(hipMalloc(&ctx->tile_desc, sizeof(int32_t) * desc.size()));
+    PF_HIP(hipMalloc(&dslot, nn));
+    PF_HIP(hipMemcpyAsync(ctx->tile_desc, desc.data(), sizeof(int32_t) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
+    PF_HIP(hipMemcpyAsync(dslot, slot.data(), nn, hipMemcpyHostToDevice, ctx->stream));
     PF_HIP(hipMalloc(&ctx->vis_rec, sizeof(int4) * (size_t)total));
     if (ctx->P == 4)
-      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
+      k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     else
-      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->npt, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
+      k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     PF_LAUNCH_CHECK();
+    PF_HIP(hipStreamSynchronize(ctx->stream));  // the host staging vectors go out of scope
+    (void)hipFree(dslot);
   }
   ctx->d = d;
   return PF_OK;
