@@ -62,6 +62,9 @@ def _qb(pyfem, etype):
     if etype == "quad":
         q = pyfem.QuadratureBilinear2D()
         return q, pyfem.BasisBilinear2D(q)
+    if etype == "block":
+        q = pyfem.QuadratureBlock3D()
+        return q, pyfem.BasisBlock3D(q)
     q = pyfem.QuadratureTriangle2D()
     return q, pyfem.BasisTriangle2D(q)
 
@@ -111,9 +114,87 @@ def elasticity_case(pyfem, name, X, conn, dof_fixed, nodal_force, etype, rho=Non
     return out
 
 
+def main_3d(pyfem):
+    """3-D 8-node block element (row f4): elasticity, Helmholtz, LinearPoisson K, mesh generator."""
+    from scipy.sparse.linalg import spsolve
+
+    c = pyfem.ProblemCreator(6, 4, 3, element_type="block")
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    elasticity_case(pyfem, "ps3d_6x4x3_block", X, conn, dof_fixed, nodal_force, "block")
+    c = pyfem.ProblemCreator(5, 4, 4, element_type="block")
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    rng = np.random.RandomState(11)
+    Xd = X + 0.05 * (rng.rand(*X.shape) - 0.5)
+    rho = 0.1 + 0.9 * rng.rand(X.shape[0])
+    o = elasticity_case(pyfem, "ps3d_5x4x4_block_ramp_distorted", Xd, conn, dof_fixed, nodal_force, "block", rho=rho, p=5.0)
+    # sensitivities of the same case (tests/test_elasticity.py:68-104 pattern)
+    q, b = _qb(pyfem, "block")
+    model = pyfem.LinearElasticity(Xd, conn, dof_fixed, None, nodal_force, q, b, p=5.0)
+    np.random.seed(0)
+    phi, psi = np.random.rand(3 * Xd.shape[0]), np.random.rand(3 * Xd.shape[0])
+    sens = model._compute_K_dv_sens(rho, phi, psi).copy()
+    np.savez_compressed(os.path.join(OUT, "sens3d_5x4x4_block.npz"), X=Xd, conn=conn.astype(np.int32), rho=rho, phi=phi,
+                        psi=psi, sens=sens, p=np.float64(5.0), u=o["u"],
+                        compliance_grad=model.compliance_grad(rho, o["u"]).copy())
+    print(f"sens3d_5x4x4_block: |sens|={np.linalg.norm(sens):.13e}")
+
+    # Helmholtz filter on blocks (Helmholtz is dimension-generic, pyfem.py:2085-2177)
+    c = pyfem.ProblemCreator(5, 4, 3, element_type="block")
+    conn, X, x = c.create_helmhotz_problem()
+    m = pyfem.Helmholtz(0.1, X, conn, q, b)
+    g = np.random.RandomState(5).rand(X.shape[0])
+    out = dict(X=X, conn=conn.astype(np.int32), x=x, r0=np.float64(0.1), rho=m.apply(x), g=g, gx=m.apply_gradient(g),
+               Ke0=m.Ke_mat[0].copy() if hasattr(m, "Ke_mat") else np.zeros(1))
+    out.update(_csr(m.K, "K"))
+    out.update(_csr(m.R, "R"))
+    np.savez_compressed(os.path.join(OUT, "helm3d_5x4x3_block.npz"), **out)
+    print(f"helm3d_5x4x3_block: nnz={m.K.nnz}")
+
+    # LinearPoisson on blocks (examples/heat_conduction.py shape): K, rhs (with the reference's quirks), solve
+    def gfunc(x):
+        return x[..., 0] * (x[..., 1] - 2.0) + x[..., 2]
+
+    c = pyfem.ProblemCreator(5, 4, 3, element_type="block")
+    conn, X, dof_fixed = c.create_poisson_problem()
+    rng = np.random.RandomState(12)
+    X = X + 0.04 * (rng.rand(*X.shape) - 0.5)
+    rho = 0.1 + 0.9 * rng.rand(X.shape[0])
+    vals = 0.1 * rng.rand(len(dof_fixed))
+    model = pyfem.LinearPoisson(X, conn, dof_fixed, vals, q, b, gfunc, p=5.0)
+    K = model.compute_jacobian(rho)
+    rhs = model.compute_rhs().copy()
+    out = dict(X=X, conn=conn.astype(np.int32), dof_fixed=np.asarray(dof_fixed, dtype=np.int32), rho=rho, p=np.float64(5.0),
+               Ke0=model.Ke_mat[0].copy(), rhs=rhs.copy(), fixed_vals=vals)
+    out.update(_csr(K, "K"))
+    Kbc, rhs_bc = model.apply_dirichlet_bcs(K.copy(), rhs.copy(), enforce_symmetric_K=True)
+    out["rhs_bc"] = rhs_bc.copy()
+    out["u"] = spsolve(Kbc.tocsc(), rhs_bc)
+    np.random.seed(0)
+    phi, psi = np.random.rand(X.shape[0]), np.random.rand(X.shape[0])
+    out["phi"], out["psi"] = phi, psi
+    out["sens"] = model._compute_K_dv_sens(rho, phi, psi).copy()
+    np.savez_compressed(os.path.join(OUT, "poi3d_5x4x3_block.npz"), **out)
+    print(f"poi3d_5x4x3_block: nnz={K.nnz}")
+
+    # mesh generator pins
+    c = pyfem.ProblemCreator(4, 3, 3, element_type="block")
+    conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+    _, _, x = c.create_helmhotz_problem()
+    _, _, pfix = c.create_poisson_problem()
+    np.savez_compressed(os.path.join(OUT, "mesh3d_4x3x3.npz"), conn=conn.astype(np.int32), X=X,
+                        dof_fixed=np.asarray(dof_fixed, dtype=np.int32),
+                        force_nodes=np.array(list(nodal_force.keys()), dtype=np.int32),
+                        force_vals=np.array(list(nodal_force.values()), dtype=float), helm_x=x,
+                        poisson_fixed=np.asarray(pfix, dtype=np.int32))
+    print("mesh3d_4x3x3 written")
+
+
 def main():
     pyfem, parse_inp = _import_reference()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-3d" in sys.argv:
+        return main_3d(pyfem)
+    main_3d(pyfem)
 
     # --- PS32: the reference's own test case (tests/test_elasticity.py:23-51) ------------
     c = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)

@@ -33,6 +33,10 @@ def quadrature(etype):
         return pts, np.ones(4)
     if etype == "tri":
         return np.array([[1.0 / 3, 1.0 / 3]]), np.array([0.5])
+    if etype == "block":  # 2x2x2 Gauss, z fastest, x slowest, w=1 (ref: pyfem.py:97-112)
+        g = 1.0 / np.sqrt(3.0)
+        pts = np.array([[sx * g, sy * g, sz * g] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+        return pts, np.ones(8)
     raise ValueError(f"unknown element_type: {etype}")
 
 
@@ -40,6 +44,16 @@ def shape_tables(etype):
     """N (Q,P) and dN/dxi (Q,P,2) at the quadrature points
     (ref: pyfem.py:222-250 driver, :262-284 quad, :365-377 tri)."""
     pts, _ = quadrature(etype)
+    if etype == "block":  # trilinear hexahedron, nodes CCW on z=-1 then z=+1 (ref: pyfem.py:287-338)
+        sg = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1],
+                       [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+        f = 1.0 + pts[:, None, :] * sg[None, :, :]  # (Q,P,3): 1 + s_l xi
+        N = 0.125 * f[..., 0] * f[..., 1] * f[..., 2]
+        dN = np.empty((8, 8, 3))
+        dN[..., 0] = 0.125 * sg[None, :, 0] * f[..., 1] * f[..., 2]
+        dN[..., 1] = 0.125 * sg[None, :, 1] * f[..., 0] * f[..., 2]
+        dN[..., 2] = 0.125 * sg[None, :, 2] * f[..., 0] * f[..., 1]
+        return N, dN
     if etype == "quad":
         xi, et = pts[:, 0], pts[:, 1]
         N = 0.25 * np.stack(
@@ -84,6 +98,44 @@ def structured_mesh(nnodes_x, nnodes_y, etype="quad"):
     return conn.astype(np.int64), X
 
 
+def structured_mesh3d(nnodes_x, nnodes_y, nnodes_z, Lx=None, Ly=None, Lz=None):
+    """ProblemCreator(element_type="block"): node id = i + j*nx + k*nx*ny, element e = i + j*nex + k*nex*ney with
+    nodes [(k,j,i),(k,j,i+1),(k,j+1,i+1),(k,j+1,i)] then the same on k+1; default Lx=(nx-1)/(ny-1), Ly=1,
+    Lz=(nz-1)/(ny-1)  (ref: pyfem.py:2469-2492, 2531-2548)."""
+    Lx = (nnodes_x - 1) / (nnodes_y - 1) if Lx is None else Lx
+    Ly = 1.0 if Ly is None else Ly
+    Lz = (nnodes_z - 1) / (nnodes_y - 1) if Lz is None else Lz
+    x, y, z = np.linspace(0, Lx, nnodes_x), np.linspace(0, Ly, nnodes_y), np.linspace(0, Lz, nnodes_z)
+    X = np.stack([np.tile(x, nnodes_y * nnodes_z), np.tile(np.repeat(y, nnodes_x), nnodes_z),
+                  np.repeat(z, nnodes_x * nnodes_y)], axis=1)
+    k, j, i = np.meshgrid(np.arange(nnodes_z - 1), np.arange(nnodes_y - 1), np.arange(nnodes_x - 1), indexing="ij")
+    n0 = (i + j * nnodes_x + k * nnodes_x * nnodes_y).ravel()
+    lo = np.stack([n0, n0 + 1, n0 + 1 + nnodes_x, n0 + nnodes_x], axis=1)
+    conn = np.concatenate([lo, lo + nnodes_x * nnodes_y], axis=1)
+    return conn.astype(np.int64), X
+
+
+def elasticity_problem3d(nnodes_x, nnodes_y, nnodes_z):
+    """x=0 face fully fixed; point loads [0,-1,0] on the nodes (k, j=0, i=nx-1)  (ref: pyfem.py:2737-2755)."""
+    face = (np.arange(nnodes_y)[None, :] * nnodes_x + np.arange(nnodes_z)[:, None] * nnodes_x * nnodes_y).ravel()
+    dof_fixed = (3 * face[:, None] + np.arange(3)[None, :]).ravel()
+    nodal_force = {int(nnodes_x - 1 + k * nnodes_x * nnodes_y): [0.0, -1.0, 0.0] for k in range(nnodes_z)}
+    return dof_fixed, nodal_force
+
+
+def helmholtz_input3d(nnodes_x, nnodes_y, nnodes_z):
+    """0.95 in the octant i<nx/2, j<ny/2, k<nz/2, else 1e-3  (ref: pyfem.py:2758-2773)."""
+    i = np.tile(np.arange(nnodes_x), nnodes_y * nnodes_z)
+    j = np.tile(np.repeat(np.arange(nnodes_y), nnodes_x), nnodes_z)
+    k = np.repeat(np.arange(nnodes_z), nnodes_x * nnodes_y)
+    return np.where((i < nnodes_x / 2) & (j < nnodes_y / 2) & (k < nnodes_z / 2), 0.95, 1e-3)
+
+
+def poisson_fixed3d(nnodes_x, nnodes_y, nnodes_z):
+    """Nodes of the x=0 face, k-major (ref: pyfem.py:2728-2735)."""
+    return (np.arange(nnodes_y)[None, :] * nnodes_x + np.arange(nnodes_z)[:, None] * nnodes_x * nnodes_y).ravel()
+
+
 def elasticity_problem(nnodes_x, nnodes_y):
     """x=0 column fully fixed, point load [0,-1] at node (j=0, i=nx-1)
     (ref: pyfem.py:2737-2755)."""
@@ -116,17 +168,66 @@ def create_conn_dof(conn, ndof):
 
 def geometry(X, conn, dN):
     """Jq = dx_j/dxi_k (ref: utils.py:172-185), detJq (utils.py:189-200; closed form
-    here, the reference calls LAPACK det), Ngrad = dN . invJ (utils.py:225-264)."""
-    Xe = X[conn]  # (E,P,2)                                   ref: utils.py:155-168
+    here, the reference calls LAPACK det), Ngrad = dN . invJ (utils.py:225-264; 2x2 and 3x3 closed forms)."""
+    Xe = X[conn]  # (E,P,ndims)                               ref: utils.py:155-168
     Jq = np.einsum("qlk,ilj->iqjk", dN, Xe)
-    detJ = Jq[..., 0, 0] * Jq[..., 1, 1] - Jq[..., 0, 1] * Jq[..., 1, 0]
     inv = np.empty_like(Jq)
-    inv[..., 0, 0] = Jq[..., 1, 1] / detJ
-    inv[..., 0, 1] = -Jq[..., 0, 1] / detJ
-    inv[..., 1, 0] = -Jq[..., 1, 0] / detJ
-    inv[..., 1, 1] = Jq[..., 0, 0] / detJ
+    if X.shape[1] == 2:
+        detJ = Jq[..., 0, 0] * Jq[..., 1, 1] - Jq[..., 0, 1] * Jq[..., 1, 0]
+        inv[..., 0, 0] = Jq[..., 1, 1] / detJ
+        inv[..., 0, 1] = -Jq[..., 0, 1] / detJ
+        inv[..., 1, 0] = -Jq[..., 1, 0] / detJ
+        inv[..., 1, 1] = Jq[..., 0, 0] / detJ
+    else:
+        J = Jq
+        c00 = J[..., 1, 1] * J[..., 2, 2] - J[..., 1, 2] * J[..., 2, 1]
+        c01 = J[..., 1, 0] * J[..., 2, 2] - J[..., 1, 2] * J[..., 2, 0]
+        c02 = J[..., 1, 0] * J[..., 2, 1] - J[..., 1, 1] * J[..., 2, 0]
+        detJ = J[..., 0, 0] * c00 - J[..., 0, 1] * c01 + J[..., 0, 2] * c02
+        inv[..., 0, 0] = c00 / detJ
+        inv[..., 0, 1] = -(J[..., 0, 1] * J[..., 2, 2] - J[..., 0, 2] * J[..., 2, 1]) / detJ
+        inv[..., 0, 2] = (J[..., 0, 1] * J[..., 1, 2] - J[..., 0, 2] * J[..., 1, 1]) / detJ
+        inv[..., 1, 0] = -c01 / detJ
+        inv[..., 1, 1] = (J[..., 0, 0] * J[..., 2, 2] - J[..., 0, 2] * J[..., 2, 0]) / detJ
+        inv[..., 1, 2] = -(J[..., 0, 0] * J[..., 1, 2] - J[..., 0, 2] * J[..., 1, 0]) / detJ
+        inv[..., 2, 0] = c02 / detJ
+        inv[..., 2, 1] = -(J[..., 0, 0] * J[..., 2, 1] - J[..., 0, 1] * J[..., 2, 0]) / detJ
+        inv[..., 2, 2] = (J[..., 0, 0] * J[..., 1, 1] - J[..., 0, 1] * J[..., 1, 0]) / detJ
     Ngrad = np.einsum("jkm,ijml->ijkl", dN, inv)
     return detJ, Ngrad
+
+
+def elasticity3d_C0(E=10.0, nu=0.3):
+    """6x6 isotropic, strain order xx,yy,zz,xy,yz,xz with engineering shear (ref: pyfem.py:1752-1757)."""
+    C0 = np.zeros((6, 6))
+    C0[0, 0] = C0[1, 1] = C0[2, 2] = 1 - nu
+    C0[0, 1] = C0[0, 2] = C0[1, 0] = C0[1, 2] = C0[2, 0] = C0[2, 1] = nu
+    C0[3, 3] = C0[4, 4] = C0[5, 5] = 0.5 - nu
+    return C0 * E / ((1 + nu) * (1 - 2 * nu))
+
+
+def _Bmat(Ngrad):
+    """Strain-displacement matrix (ref: pyfem.py:1976-2013)."""
+    nE, Q, P, nd = Ngrad.shape
+    if nd == 2:
+        Be = np.zeros((nE, Q, 3, 2 * P))
+        Be[:, :, 0, 0::2] = Ngrad[..., 0]
+        Be[:, :, 1, 1::2] = Ngrad[..., 1]
+        Be[:, :, 2, 0::2] = Ngrad[..., 1]
+        Be[:, :, 2, 1::2] = Ngrad[..., 0]
+        return Be
+    Be = np.zeros((nE, Q, 6, 3 * P))
+    Nx, Ny, Nz = Ngrad[..., 0], Ngrad[..., 1], Ngrad[..., 2]
+    Be[:, :, 0, 0::3] = Nx
+    Be[:, :, 1, 1::3] = Ny
+    Be[:, :, 2, 2::3] = Nz
+    Be[:, :, 3, 0::3] = Ny
+    Be[:, :, 3, 1::3] = Nx
+    Be[:, :, 4, 1::3] = Nz
+    Be[:, :, 4, 2::3] = Ny
+    Be[:, :, 5, 0::3] = Nz
+    Be[:, :, 5, 2::3] = Nx
+    return Be
 
 
 def plane_stress_C0(E=10.0, nu=0.3):
@@ -150,12 +251,8 @@ def elasticity_Ke(X, conn, etype, rho=None, E=10.0, nu=0.3, p=0.0):
     rho = np.ones(X.shape[0]) if rho is None else np.asarray(rho, dtype=float)
     rho_q = np.einsum("jl,il->ij", N, rho[conn])  # ref: utils.py:204-221
     Cq = ramp(rho_q, p)
-    Be = np.zeros((nE, Q, 3, 2 * P))  # ref: pyfem.py:1992-1997
-    Be[:, :, 0, 0::2] = Ngrad[..., 0]
-    Be[:, :, 1, 1::2] = Ngrad[..., 1]
-    Be[:, :, 2, 0::2] = Ngrad[..., 1]
-    Be[:, :, 2, 1::2] = Ngrad[..., 0]
-    C0 = plane_stress_C0(E, nu)
+    Be = _Bmat(Ngrad)
+    C0 = plane_stress_C0(E, nu) if X.shape[1] == 2 else elasticity3d_C0(E, nu)
     return np.einsum("iq,q,iqnj,iq,nm,iqmk->ijk", detJ, wq, Be, Cq, C0, Be, optimize=True)
 
 
@@ -170,14 +267,10 @@ def elasticity_K_dv_sens(X, conn, etype, rho, phi, psi, E=10.0, nu=0.3, p=0.0):
     rho = np.asarray(rho, dtype=float)
     rho_q = np.einsum("jl,il->ij", N, rho[conn])
     Cqderiv = np.einsum("ql,iq->iql", N, (1 + p) / (1 + p * (1 - rho_q)) ** 2)
-    Be = np.zeros((nE, Q, 3, 2 * P))
-    Be[:, :, 0, 0::2] = Ngrad[..., 0]
-    Be[:, :, 1, 1::2] = Ngrad[..., 1]
-    Be[:, :, 2, 0::2] = Ngrad[..., 1]
-    Be[:, :, 2, 1::2] = Ngrad[..., 0]
-    C0 = plane_stress_C0(E, nu)
+    Be = _Bmat(Ngrad)
+    C0 = plane_stress_C0(E, nu) if X.shape[1] == 2 else elasticity3d_C0(E, nu)
     Ke_deriv = np.einsum("iq,q,iqnj,iqo,nm,iqmk->ijko", detJ, wq, Be, Cqderiv, C0, Be, optimize=True)
-    conn_dof = create_conn_dof(conn, 2)
+    conn_dof = create_conn_dof(conn, X.shape[1])
     inner = np.einsum("ij,ik,ijko->io", phi[conn_dof], psi[conn_dof], Ke_deriv)
     out = np.zeros(X.shape[0])
     for i in range(P):
@@ -285,7 +378,8 @@ def elasticity_rhs(ndof, nodal_force):
     """Point loads by assignment (ref: pyfem.py:1761-1768)."""
     rhs = np.zeros(ndof)
     for node, f in nodal_force.items():
-        rhs[2 * node : 2 * node + 2] = f
+        d = len(f)
+        rhs[d * node : d * node + d] = f
     return rhs
 
 
@@ -311,9 +405,10 @@ def jacobi_pcg(K, b, rtol=1e-8, maxiter=None, x0=None):
 def solve_elasticity(X, conn, etype, dof_fixed, nodal_force, method="direct", rho=None, E=10.0, nu=0.3, p=0.0,
                      rtol=1e-8):
     """Assembler.solve for LinearElasticity (ref: pyfem.py:2299-2317)."""
-    conn_dof = create_conn_dof(conn, 2)
+    nd = X.shape[1]
+    conn_dof = create_conn_dof(conn, nd)
     K = assemble_csr(elasticity_Ke(X, conn, etype, rho, E, nu, p), conn_dof)
-    rhs = elasticity_rhs(2 * X.shape[0], nodal_force)
+    rhs = elasticity_rhs(nd * X.shape[0], nodal_force)
     Kbc, rhs = apply_dirichlet_bcs(K, rhs, dof_fixed, None, True)
     if method == "direct":
         return spsolve(Kbc, rhs), K, Kbc, rhs

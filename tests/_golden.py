@@ -15,6 +15,8 @@ ELASTICITY_CASES = {
     "ps11x8_tri": "tri",
     "ps11x8_tri_ramp": "tri",
     "arm_tri": "tri",
+    "ps3d_6x4x3_block": "block",
+    "ps3d_5x4x4_block_ramp_distorted": "block",
 }
 HELMHOLTZ_CASES = {"helm32_quad": "quad", "helm12x9_tri": "tri"}
 
@@ -29,7 +31,7 @@ def csr_of(g, prefix, n):
 
 
 def force_dict(g):
-    return {int(n): [float(v[0]), float(v[1])] for n, v in zip(g["force_nodes"], g["force_vals"])}
+    return {int(n): [float(x) for x in v] for n, v in zip(g["force_nodes"], g["force_vals"])}
 
 
 def relmax(a, b):

@@ -19,7 +19,7 @@ def test_elasticity_matches_reference(name):
     Ke = orc.elasticity_Ke(X, conn, etype, rho=rho, p=float(g["p"]))
     assert relmax(Ke[0], g["Ke0"]) < K_TOL
     assert relmax(Ke[-1], g["Ke_last"]) < K_TOL
-    K = orc.assemble_csr(Ke, orc.create_conn_dof(conn, 2))
+    K = orc.assemble_csr(Ke, orc.create_conn_dof(conn, X.shape[1]))
     assert K.nnz == int(g["K_nnz"])
     assert abs(np.linalg.norm(K.data) - float(g["K_norm"])) < 1e-12 * float(g["K_norm"])
     assert relmax(K.diagonal(), g["K_diag"]) < K_TOL
@@ -108,7 +108,8 @@ def test_mesh_generator_matches_reference():
         assert np.array_equal(orc.helmholtz_input(6, 4), g[f"{etype}_helm_x"])
 
 
-@pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri")])
+@pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri"),
+                                        ("sens3d_5x4x4_block", "block")])
 def test_sensitivity_matches_reference(name, etype):
     """_compute_K_dv_sens and compliance_grad as the reference itself computed them (p = 5)."""
     g = load(name)
@@ -150,3 +151,54 @@ def test_poisson_matches_reference(name):
         pr = np.random.rand(u.shape[0])
         assert abs(pr.dot(u) / -7082.301628403809 - 1) < 1e-10
         assert np.allclose(Ke[0, 0], [2 / 3, -1 / 6, -1 / 3, -1 / 6], atol=1e-13)
+
+
+# ---- 3-D 8-node block element ------------------------------------------------
+def _gfunc3d(x):  # source term used by oracle/gen_golden.py main_3d
+    return x[..., 0] * (x[..., 1] - 2.0) + x[..., 2]
+
+
+def test_block_tables_and_mesh_match_reference():
+    g = load("mesh3d_4x3x3")
+    conn, X = orc.structured_mesh3d(4, 3, 3)
+    assert np.array_equal(conn, g["conn"]) and np.allclose(X, g["X"], rtol=0, atol=1e-15)
+    dof_fixed, force = orc.elasticity_problem3d(4, 3, 3)
+    assert np.array_equal(dof_fixed, g["dof_fixed"])
+    assert list(force.keys()) == list(g["force_nodes"]) and np.array_equal(np.array(list(force.values())), g["force_vals"])
+    assert np.array_equal(orc.helmholtz_input3d(4, 3, 3), g["helm_x"])
+    assert np.array_equal(orc.poisson_fixed3d(4, 3, 3), g["poisson_fixed"])
+    N, dN = orc.shape_tables("block")
+    assert np.allclose(N.sum(axis=1), 1.0) and np.allclose(dN.sum(axis=1), 0.0)
+
+
+def test_block_helmholtz_matches_reference():
+    g = load("helm3d_5x4x3_block")
+    X, conn = g["X"], g["conn"].astype(np.int64)
+    f = orc.HelmholtzFilter(float(g["r0"]), X, conn, "block")
+    n = X.shape[0]
+    for M, pre in ((f.K, "K"), (f.R, "R")):
+        ref = csr_of(g, pre, n)
+        assert np.array_equal(M.indptr, ref.indptr) and np.array_equal(M.indices, ref.indices)
+        assert np.abs(M.data - ref.data).max() < K_TOL * np.abs(ref.data).max()
+    assert relmax(f.apply(g["x"]), g["rho"]) < 1e-10
+    assert relmax(f.apply_gradient(g["g"]), g["gx"]) < 1e-10
+
+
+def test_block_poisson_matches_reference():
+    g = load("poi3d_5x4x3_block")
+    X, conn = g["X"], g["conn"].astype(np.int64)
+    p = float(g["p"])
+    Ke = orc.poisson_Ke(X, conn, "block", g["rho"], p)
+    assert relmax(Ke[0], g["Ke0"]) < K_TOL
+    K = orc.assemble_csr(Ke, conn)
+    ref = csr_of(g, "K", X.shape[0])
+    assert np.array_equal(K.indptr, ref.indptr) and np.array_equal(K.indices, ref.indices)
+    assert np.abs(K.data - ref.data).max() < K_TOL * np.abs(ref.data).max()
+    rhs = orc.poisson_rhs(X, conn, "block", _gfunc3d)  # N[j,k] quirk: NOT the consistent load vector in 3-D
+    assert relmax(rhs, g["rhs"]) < K_TOL
+    Kbc, rhs_bc = orc.apply_dirichlet_bcs(K, rhs, g["dof_fixed"], g["fixed_vals"], True)
+    assert relmax(rhs_bc, g["rhs_bc"]) < 1e-12
+    from scipy.sparse.linalg import spsolve
+
+    assert relmax(spsolve(Kbc.tocsc(), rhs_bc), g["u"]) < U_TOL
+    assert relmax(orc.poisson_K_dv_sens(X, conn, "block", g["rho"], g["phi"], g["psi"], p), g["sens"]) < 1e-13
