@@ -46,7 +46,7 @@ enum {
   PF_E_NOCONV = -4     /* CG hit maxiter (reference: RuntimeError, pyfem.py:2421-2422) */
 };
 
-enum { PF_QUAD4 = 4, PF_TRI3 = 3 };          /* nodes per element selects the element */
+enum { PF_QUAD4 = 4, PF_TRI3 = 3, PF_BLOCK8 = 8 };  /* nodes per element selects the element */
 enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
 enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECOND_AMG_REUSE = 3 };
 
@@ -63,11 +63,15 @@ int pf_version(void);
  * Checks conn.min()==0 and conn.max()==nnodes-1 like pyfem.py:680-681 (PF_E_INVALID). */
 int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P,
                 const int32_t* conn, int on_device);
+/* 3-D: X (nnodes, 3), conn (nelems, 8) in BasisBlock3D node order (pyfem.py:287-338; ProblemCreator
+ * element_type="block", pyfem.py:2531-2548).  pf_pattern_build then takes ndof_per_node 1 or 3. */
+int pf_mesh_set3d(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P /* PF_BLOCK8 */,
+                  const int32_t* conn, int on_device);
 
 /* ---- symbolic pattern: replaces utils.create_dof (utils.py:268-298) +
  *      ModelBase._compute_nz_pattern (pyfem.py:838-858) + the structure half of
  *      coo_matrix(...).tocsr() (pyfem.py:930-931) ------------------------------------------- */
-int pf_pattern_build(pf_ctx* ctx, int ndof_per_node /* 1 or 2 */);
+int pf_pattern_build(pf_ctx* ctx, int ndof_per_node /* 1 or the space dimension */);
 /* nrows = d*nnodes, nnz = d*d*nblocks */
 int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks, int32_t* max_row_blocks);
 /* node graph (device out): nptr int32[nnodes+1], nidx int32[nblocks]; either may be NULL */
@@ -116,6 +120,17 @@ int pf_sens_poisson2d(pf_ctx* ctx, double p, const double* rho, const double* ph
 int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
                                      double* Ke_out);
 int pf_element_matrices_helmholtz2d(pf_ctx* ctx, double r0, double* Ke_out, double* Re_out);
+
+/* ---- 3-D 8-node block element: QuadratureBlock3D / BasisBlock3D (pyfem.py:97-112,
+ *      287-338), 3x3 geometry (utils.py:172-264), 3-D C0 and Bmat (pyfem.py:1752-1757, 1999-2011).
+ *      Fused quadrature + scatter like the 2-D kernels; value layout: 3x3 (or 1x1) blocks in node-graph order.
+ *      rho: nodal density (RAMP with p) or NULL. ------------------------------------------------------------ */
+int pf_assemble_elasticity3d(pf_ctx* ctx, double E, double nu, double p, const double* rho, double* Kvals);
+int pf_assemble_poisson3d(pf_ctx* ctx, double p, const double* rho, double* Kvals);        /* pyfem.py:1176-1187 */
+int pf_assemble_helmholtz3d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);         /* pyfem.py:2127-2177 */
+/* kind: 0 elasticity (Ke (E,24,24)), 1 Poisson (Ke (E,8,8)), 2 Helmholtz (Ke and Re (E,8,8)); model.Ke_mat users */
+int pf_element_matrices3d(pf_ctx* ctx, int kind, double E, double nu, double p, double r0, const double* rho,
+                          double* Ke_out, double* Re_out);
 
 /* block layout -> scipy CSR data order (identity copy for d == 1) */
 int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr_data);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "pf_last_error": (C.c_char_p, [_vp]),
     "pf_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "pf_mesh_set": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, C.c_int]),
+    "pf_mesh_set3d": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, C.c_int]),
     "pf_pattern_build": (C.c_int, [_vp, C.c_int]),
     "pf_pattern_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "pf_pattern_get_graph": (C.c_int, [_vp, _vp, _vp]),
@@ -35,6 +36,10 @@ SIGNATURES = {
     "pf_assemble_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_sens_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "pf_assemble_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_assemble_elasticity3d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp]),
+    "pf_assemble_poisson3d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_assemble_helmholtz3d": (C.c_int, [_vp, _f64, _vp, _vp]),
+    "pf_element_matrices3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     "pf_element_matrices_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_quad_points": (C.c_int, [_vp, _vp]),
     "pf_poisson_rhs": (C.c_int, [_vp, _vp, _vp]),

@@ -569,6 +569,7 @@ static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, dou
 // the previous call is kept if it was made for the same value array (the caller asserts the values are
 // unchanged, e.g. the constant Helmholtz filter matrix).
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
+  if (ctx->d == 3) return PF_E_UNSUPPORTED;  // 3-D elasticity needs six rigid-body modes per aggregate: Jacobi for now
   if (!ctx->amg) {
     int rc = amg_build_hierarchy(ctx);
     if (rc) { pf_amg_free(ctx); return rc; }

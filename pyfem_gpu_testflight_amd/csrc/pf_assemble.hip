@@ -1046,6 +1046,7 @@ int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* 
 extern "C" int pf_assemble_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho, int mode,
                                         double* Kvals) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 2, "pf_assemble_elasticity2d: pattern must be built with ndof_per_node = 2");
   PF_REQUIRE(Kvals, "pf_assemble_elasticity2d: Kvals is NULL");
   PF_REQUIRE(mode == PF_SCATTER_GATHER || mode == PF_SCATTER_ATOMIC, "pf_assemble_elasticity2d: unknown mode");
@@ -1054,6 +1055,7 @@ extern "C" int pf_assemble_elasticity2d(pf_ctx* ctx, double E, double nu, double
 
 extern "C" int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 1, "pf_assemble_helmholtz2d: pattern must be built with ndof_per_node = 1");
   PF_REQUIRE(Kvals || Rvals, "pf_assemble_helmholtz2d: both outputs NULL");
   return pf_launch_assemble_helmholtz(ctx, r0, Kvals, Rvals);
@@ -1062,6 +1064,7 @@ extern "C" int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, do
 extern "C" int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
                                                 double* Ke_out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->conn && Ke_out, "pf_element_matrices_elasticity2d: no mesh / NULL output");
   ElasticityParams pr = make_elasticity(E, nu, p, rho);
   const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
@@ -1078,6 +1081,7 @@ extern "C" int pf_element_matrices_elasticity2d(pf_ctx* ctx, double E, double nu
 
 extern "C" int pf_element_matrices_helmholtz2d(pf_ctx* ctx, double r0, double* Ke_out, double* Re_out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->conn && (Ke_out || Re_out), "pf_element_matrices_helmholtz2d: no mesh / NULL outputs");
   HelmholtzParams pr{r0 * r0, nullptr};
   const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
@@ -1092,6 +1096,7 @@ extern "C" int pf_element_matrices_helmholtz2d(pf_ctx* ctx, double r0, double* K
 extern "C" int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho, const double* phi,
                                     const double* psi, double* out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 2, "pf_sens_elasticity2d: pattern must be built with ndof_per_node = 2");
   PF_REQUIRE(rho && phi && psi && out, "pf_sens_elasticity2d: NULL argument");
   PF_REQUIRE(ctx->vis_rec, "pf_sens_elasticity2d: node valence above 64 is not supported");
@@ -1108,6 +1113,7 @@ extern "C" int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, 
 // ---- LinearPoisson (row f4, 2-D part) ---------------------------------------------------------------
 extern "C" int pf_assemble_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Kvals) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 1, "pf_assemble_poisson2d: pattern must be built with ndof_per_node = 1");
   PF_REQUIRE(Kvals, "pf_assemble_poisson2d: Kvals is NULL");
   PoissonParams pr{p, rho};
@@ -1120,6 +1126,7 @@ extern "C" int pf_assemble_poisson2d(pf_ctx* ctx, double p, const double* rho, d
 
 extern "C" int pf_element_matrices_poisson2d(pf_ctx* ctx, double p, const double* rho, double* Ke_out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->conn && Ke_out, "pf_element_matrices_poisson2d: no mesh / NULL output");
   PoissonParams pr{p, rho};
   const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
@@ -1136,6 +1143,7 @@ extern "C" int pf_element_matrices_poisson2d(pf_ctx* ctx, double p, const double
 
 extern "C" int pf_quad_points(pf_ctx* ctx, double* Xq_out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->conn && Xq_out, "pf_quad_points: no mesh / NULL output");
   const unsigned grid = (unsigned)cdiv(ctx->nelems, 256);
   if (ctx->P == 4) k_quad_points<4><<<grid, 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, Xq_out);
@@ -1146,6 +1154,7 @@ extern "C" int pf_quad_points(pf_ctx* ctx, double* Xq_out) {
 
 extern "C" int pf_poisson_rhs(pf_ctx* ctx, const double* gq, double* rhs_out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 1 && gq && rhs_out, "pf_poisson_rhs: needs a scalar pattern / NULL argument");
   const unsigned grid = (unsigned)cdiv(ctx->nnodes, 128);
   if (ctx->P == 4) k_poisson_rhs<4><<<grid, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->conn, ctx->n2e_ptr, ctx->n2e, gq, rhs_out);
@@ -1157,6 +1166,7 @@ extern "C" int pf_poisson_rhs(pf_ctx* ctx, const double* gq, double* rhs_out) {
 extern "C" int pf_sens_poisson2d(pf_ctx* ctx, double p, const double* rho, const double* phi, const double* psi,
                                  double* out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->ndims == 2, "this entry point is for 2-D meshes (pf_mesh_set); 3-D blocks have their own *3d entry points");
   PF_REQUIRE(ctx->d == 1, "pf_sens_poisson2d: pattern must be built with ndof_per_node = 1");
   PF_REQUIRE(rho && phi && psi && out, "pf_sens_poisson2d: NULL argument");
   PF_REQUIRE(ctx->vis_rec, "pf_sens_poisson2d: node valence above 64 is not supported");

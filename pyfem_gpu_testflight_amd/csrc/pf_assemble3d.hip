@@ -1,0 +1,324 @@
+// NUMERIC phase for the 3-D 8-node block element: fused quadrature + scatter.
+//
+// Reference path (examples/block/block.py, examples/heat_conduction.py, SciTech2023/performance_test.py):
+//   QuadratureBlock3D (pyfem.py:97-112, 2x2x2 Gauss, x slowest / z fastest), BasisBlock3D (pyfem.py:287-338),
+//   utils.compute_jtrans / compute_jdet / compute_basis_grad 3x3 branch (utils.py:172-264),
+//   LinearElasticity 3-D C0 (pyfem.py:1752-1757) + Bmat (pyfem.py:1999-2011) + einsum Ke (pyfem.py:2016-2027),
+//   LinearPoisson Ke (pyfem.py:1176-1187), Helmholtz Ke/Re (pyfem.py:2127-2177), coo->csr (pyfem.py:921-931).
+//
+// Same design as the 2-D kernel (pf_assemble.hip): lane = incident (node, element) pair, tile = up to 8
+// consecutive nodes (<= 64 pairs), LDS image of the tile's contiguous value segment, LDS fp64 adds, one
+// straight copy-out; every K value is written to HBM once, Ke (24x24 per element, 4.6 KB) never exists.
+// The lane integrates the d rows of its node: 3 x 24 values for elasticity.  With the isotropic C0
+//   K_ab[i][j] = sum_q w detJ C_q ( lam g_a[i] g_b[j] + mu g_a[j] g_b[i] + mu delta_ij g_a.g_b )
+// so the lane accumulates S_b[i][j] = sum_q (w detJ C_q g_a[i]) g_b[j] (9 FMA per node pair and point) and
+// applies lam/mu once at the end.  Unlike 2-D this kernel is VALU-bound (about 2.2 k fp64 FMA per pair against
+// 1.9 KB written per node), so it is not software-pipelined; occupancy (2 waves/SIMD at ~250 VGPRs) hides
+// the loads.
+#include "pf_common.h"
+
+namespace {
+
+constexpr double G3 = 0.57735026918962576451;  // 1/sqrt(3)
+
+enum { HEX_ELASTICITY = 0, HEX_POISSON = 1, HEX_HELMHOLTZ = 2 };
+template <int KIND> struct HexV { static constexpr int V = KIND == HEX_ELASTICITY ? 9 : KIND == HEX_HELMHOLTZ ? 2 : 1; };
+
+struct HexParams {
+  double lam, mu;     // elasticity: Lame constants of C0 (pyfem.py:1752-1757)
+  double p;           // RAMP parameter (pyfem.py:1923-1945 / 1279-1301)
+  double r02;         // Helmholtz r0^2
+  const double* rho;  // nodal density or NULL
+};
+
+// node signs in BasisBlock3D order (pyfem.py:296-307): CCW on z=-1, then z=+1
+__host__ __device__ constexpr int hsx(int l) { return ((l ^ (l >> 1)) & 1) ? 1 : -1; }
+__host__ __device__ constexpr int hsy(int l) { return (l & 2) ? 1 : -1; }
+__host__ __device__ constexpr int hsz(int l) { return (l & 4) ? 1 : -1; }
+
+// rows of node `a` (runtime local index) of the element matrix: v[b][*] = block (a, b)
+template <int KIND, bool RHO>
+__device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)[8], const double (&cy)[8],
+                                         const double (&cz)[8], const double (&rho)[8], int a,
+                                         double (&v)[8][HexV<KIND>::V]) {
+  constexpr int NS = KIND == HEX_ELASTICITY ? 9 : KIND == HEX_HELMHOLTZ ? 2 : 1;
+  const double sxa = ((a ^ (a >> 1)) & 1) ? 1.0 : -1.0, sya = (a & 2) ? 1.0 : -1.0, sza = (a & 4) ? 1.0 : -1.0;
+  double S[8][NS];
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int k = 0; k < NS; ++k) S[b][k] = 0.0;
+
+#pragma unroll 1
+  for (int q = 0; q < 8; ++q) {  // pyfem.py:97-112: q = 4 ix + 2 iy + iz
+    const double xi = (q & 4) ? G3 : -G3, et = (q & 2) ? G3 : -G3, ze = (q & 1) ? G3 : -G3;
+    const double fx[2] = {1.0 - xi, 1.0 + xi}, fy[2] = {1.0 - et, 1.0 + et}, fz[2] = {1.0 - ze, 1.0 + ze};
+    double pyz[2][2], pxz[2][2], pxy[2][2];  // 0.125 x pairs of factors
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        pyz[i][j] = 0.125 * fy[i] * fz[j];
+        pxz[i][j] = 0.125 * fx[i] * fz[j];
+        pxy[i][j] = 0.125 * fx[i] * fy[j];
+      }
+    // Jq[j][k] = sum_l X_l[j] dN_l/dxi_k (utils.py:172-185)
+    double J[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) J[j][k] = 0.0;
+    double rq = 0.0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const int ix = hsx(l) > 0, iy = hsy(l) > 0, iz = hsz(l) > 0;
+      const double d0 = hsx(l) * pyz[iy][iz], d1 = hsy(l) * pxz[ix][iz], d2 = hsz(l) * pxy[ix][iy];
+      J[0][0] += cx[l] * d0; J[0][1] += cx[l] * d1; J[0][2] += cx[l] * d2;
+      J[1][0] += cy[l] * d0; J[1][1] += cy[l] * d1; J[1][2] += cy[l] * d2;
+      J[2][0] += cz[l] * d0; J[2][1] += cz[l] * d1; J[2][2] += cz[l] * d2;
+      if constexpr (RHO) rq += pxy[ix][iy] * fz[iz] * rho[l];  // utils.py:204-221
+    }
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;  // utils.py:189-200
+    const double rd = 1.0 / det;
+    double inv[3][3];  // utils.py:250-260
+    inv[0][0] = c00 * rd;
+    inv[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * rd;
+    inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+    inv[1][0] = -c01 * rd;
+    inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+    inv[1][2] = -(J[0][0] * J[1][2] - J[0][2] * J[1][0]) * rd;
+    inv[2][0] = c02 * rd;
+    inv[2][1] = -(J[0][0] * J[2][1] - J[0][1] * J[2][0]) * rd;
+    inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+    double scale = det;  // weights are 1
+    if constexpr (RHO) scale *= rq / (1.0 + pr.p * (1.0 - rq));
+    // own node: factors from its runtime signs (no register array is indexed by a)
+    const double fxa = 1.0 + sxa * xi, fya = 1.0 + sya * et, fza = 1.0 + sza * ze;
+    const double a0 = 0.125 * sxa * fya * fza, a1 = 0.125 * sya * fxa * fza, a2 = 0.125 * sza * fxa * fya;
+    double ga[3];  // scale * grad N_a
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ga[j] = scale * (a0 * inv[0][j] + a1 * inv[1][j] + a2 * inv[2][j]);
+    const double Na = 0.125 * fxa * fya * fza;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int ix = hsx(b) > 0, iy = hsy(b) > 0, iz = hsz(b) > 0;
+      const double d0 = hsx(b) * pyz[iy][iz], d1 = hsy(b) * pxz[ix][iz], d2 = hsz(b) * pxy[ix][iy];
+      double gb[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gb[j] = d0 * inv[0][j] + d1 * inv[1][j] + d2 * inv[2][j];  // utils.py:263
+      if constexpr (KIND == HEX_ELASTICITY) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) S[b][3 * i + j] += ga[i] * gb[j];
+      } else {
+        S[b][0] += ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        if constexpr (KIND == HEX_HELMHOLTZ) S[b][1] += det * Na * (pxy[ix][iy] * fz[iz]);  // pyfem.py:2134
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    if constexpr (KIND == HEX_ELASTICITY) {
+      const double tr = S[b][0] + S[b][4] + S[b][8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          v[b][3 * i + j] = pr.lam * S[b][3 * i + j] + pr.mu * S[b][3 * j + i] + (i == j ? pr.mu * tr : 0.0);
+    } else if constexpr (KIND == HEX_HELMHOLTZ) {
+      v[b][0] = pr.r02 * S[b][0] + S[b][1];  // pyfem.py:2127-2131, 2176
+      v[b][1] = S[b][1];
+    } else {
+      v[b][0] = S[b][0];
+    }
+  }
+}
+
+__device__ __forceinline__ void hex_load(const double* __restrict__ X, const double* __restrict__ rho, const int4& r0,
+                                         const int4& r1, double (&cx)[8], double (&cy)[8], double (&cz)[8],
+                                         double (&re)[8]) {
+  const int32_t nd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const double* xp = X + 3 * (int64_t)nd[l];
+    cx[l] = xp[0];
+    cy[l] = xp[1];
+    cz[l] = xp[2];
+    re[l] = rho ? rho[nd[l]] : 1.0;
+  }
+}
+
+// dynamic LDS: double img[V * plane]
+template <int KIND, bool RHO>
+__global__ __launch_bounds__(64) void k_assemble_hex(int64_t ntiles, int32_t plane, const double* __restrict__ X,
+                                                     const int32_t* __restrict__ nptr,
+                                                     const int4* __restrict__ tile_desc,
+                                                     const int4* __restrict__ vis_rec, HexParams pr,
+                                                     double* __restrict__ out0, double* __restrict__ out1) {
+  constexpr int V = HexV<KIND>::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  double* const img = reinterpret_cast<double*>(smem3);
+  const int lane = threadIdx.x;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int4 dsc = tile_desc[t];
+    const int32_t n0 = dsc.x, vb = dsc.y, base = dsc.z;
+    const int32_t nv = (dsc.w >> 8) & 255;
+    const int32_t nblk = (int32_t)((uint32_t)dsc.w >> 16);
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      for (int32_t q = lane; q < nblk; q += 64) img[k * plane + q] = 0.0;
+    if (lane < nv) {
+      const int64_t jj = (int64_t)vb + lane;
+      const int4 r0 = vis_rec[3 * jj], r1 = vis_rec[3 * jj + 1], r2 = vis_rec[3 * jj + 2];
+      const int a = r2.z & 255, slot = (r2.z >> 8) & 255;
+      const int32_t roff = nptr[n0 + slot] - base;
+      double cx[8], cy[8], cz[8], re[8];
+      hex_load(X, RHO ? pr.rho : nullptr, r0, r1, cx, cy, cz, re);
+      double v[8][V];
+      hex_rows<KIND, RHO>(pr, cx, cy, cz, re, a, v);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t pw = (uint32_t)(b < 4 ? r2.x : r2.y);
+        const int blk = roff + (int)((pw >> (8 * (b & 3))) & 255);
+#pragma unroll
+        for (int k = 0; k < V; ++k)
+          __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+    // copy-out (one wave: LDS executes in order, no barrier)
+    if constexpr (V == 9) {
+      double* dst = out0 + (int64_t)base * 9;
+      const int32_t tot = nblk * 9;
+      for (int32_t e = lane; e < tot; e += 64) {
+        const int32_t blk = e / 9, k = e - 9 * blk;
+        dst[e] = img[k * plane + blk];
+      }
+    } else {
+      for (int32_t q = lane; q < nblk; q += 64) {
+        out0[base + q] = img[q];
+        if constexpr (V == 2) out1[base + q] = img[plane + q];
+      }
+    }
+  }
+}
+
+// Ke (E, 8*D, 8*D) row-major for the parity tests (model.Ke_mat of the reference); thread = (element, a)
+template <int KIND, bool RHO>
+__global__ void k_element_matrices_hex(int64_t nelems, const double* __restrict__ X, const int32_t* __restrict__ conn,
+                                       HexParams pr, double* __restrict__ Ke, double* __restrict__ Re) {
+  constexpr int V = HexV<KIND>::V;
+  constexpr int D = KIND == HEX_ELASTICITY ? 3 : 1;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nelems * 8) return;
+  const int64_t e = i >> 3;
+  const int a = (int)(i & 7);
+  const int32_t* c = conn + e * 8;
+  const int4 r0 = make_int4(c[0], c[1], c[2], c[3]), r1 = make_int4(c[4], c[5], c[6], c[7]);
+  double cx[8], cy[8], cz[8], re[8];
+  hex_load(X, RHO ? pr.rho : nullptr, r0, r1, cx, cy, cz, re);
+  double v[8][V];
+  hex_rows<KIND, RHO>(pr, cx, cy, cz, re, a, v);
+  constexpr int ED = 8 * D;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    if constexpr (KIND == HEX_ELASTICITY) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) Ke[(e * ED + 3 * a + k) * ED + 3 * b + l] = v[b][3 * k + l];
+    } else {
+      Ke[(e * ED + a) * ED + b] = v[b][0];
+      if constexpr (KIND == HEX_HELMHOLTZ)
+        if (Re) Re[(e * ED + a) * ED + b] = v[b][1];
+    }
+  }
+}
+
+template <int KIND, bool RHO>
+int launch_hex(pf_ctx* ctx, const HexParams& pr, double* out0, double* out1) {
+  constexpr int V = HexV<KIND>::V;
+  const int32_t plane = ctx->npt * ctx->max_row_blocks + 1;
+  const size_t lds = ((size_t)plane * V * 8 + 15) & ~(size_t)15;
+  auto k = k_assemble_hex<KIND, RHO>;
+  if (lds > 48 * 1024)
+    PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int wpc = 8;  // persistent waves per CU: ~250 VGPRs -> 2 per SIMD
+  if (const char* e = getenv("PF_HEX_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
+  const unsigned grid = (unsigned)std::min<int64_t>(ctx->ntiles, (int64_t)256 * wpc);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, ctx->stream, ctx->ntiles, plane, ctx->X, ctx->nptr,
+                     reinterpret_cast<const int4*>(ctx->tile_desc), reinterpret_cast<const int4*>(ctx->vis_rec), pr,
+                     out0, out1);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+int check3d(pf_ctx* ctx, int d, const char* who) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (ctx->ndims != 3 || ctx->P != 8) return pf_fail(ctx, PF_E_INVALID, std::string(who) + ": needs a pf_mesh_set3d mesh");
+  if (d && ctx->d != d)
+    return pf_fail(ctx, PF_E_INVALID, std::string(who) + ": pattern was not built with ndof_per_node = " + std::to_string(d));
+  if (d && (!ctx->npt || !ctx->tile_desc)) return pf_fail(ctx, PF_E_UNSUPPORTED, std::string(who) + ": node valence above 64");
+  return PF_OK;
+}
+
+HexParams lame(double E, double nu, double p, const double* rho) {
+  HexParams pr{};
+  pr.lam = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  pr.mu = E / (2.0 * (1.0 + nu));
+  pr.p = p;
+  pr.rho = rho;
+  return pr;
+}
+
+}  // namespace
+
+extern "C" int pf_assemble_elasticity3d(pf_ctx* ctx, double E, double nu, double p, const double* rho, double* Kvals) {
+  if (int rc = check3d(ctx, 3, "pf_assemble_elasticity3d")) return rc;
+  PF_REQUIRE(Kvals, "pf_assemble_elasticity3d: Kvals is NULL");
+  const HexParams pr = lame(E, nu, p, rho);
+  return rho ? launch_hex<HEX_ELASTICITY, true>(ctx, pr, Kvals, nullptr)
+             : launch_hex<HEX_ELASTICITY, false>(ctx, pr, Kvals, nullptr);
+}
+
+extern "C" int pf_assemble_poisson3d(pf_ctx* ctx, double p, const double* rho, double* Kvals) {
+  if (int rc = check3d(ctx, 1, "pf_assemble_poisson3d")) return rc;
+  PF_REQUIRE(Kvals, "pf_assemble_poisson3d: Kvals is NULL");
+  HexParams pr{};
+  pr.p = p;
+  pr.rho = rho;
+  return rho ? launch_hex<HEX_POISSON, true>(ctx, pr, Kvals, nullptr) : launch_hex<HEX_POISSON, false>(ctx, pr, Kvals, nullptr);
+}
+
+extern "C" int pf_assemble_helmholtz3d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals) {
+  if (int rc = check3d(ctx, 1, "pf_assemble_helmholtz3d")) return rc;
+  PF_REQUIRE(Kvals && Rvals, "pf_assemble_helmholtz3d: NULL output");
+  HexParams pr{};
+  pr.r02 = r0 * r0;
+  return launch_hex<HEX_HELMHOLTZ, false>(ctx, pr, Kvals, Rvals);
+}
+
+extern "C" int pf_element_matrices3d(pf_ctx* ctx, int kind, double E, double nu, double p, double r0, const double* rho,
+                                     double* Ke_out, double* Re_out) {
+  if (int rc = check3d(ctx, 0, "pf_element_matrices3d")) return rc;
+  PF_REQUIRE(Ke_out, "pf_element_matrices3d: Ke_out is NULL");
+  const unsigned grid = (unsigned)cdiv(ctx->nelems * 8, 128);
+  HexParams pr = lame(E, nu, p, rho);
+  pr.r02 = r0 * r0;
+  if (kind == HEX_ELASTICITY) {
+    if (rho) k_element_matrices_hex<HEX_ELASTICITY, true><<<grid, 128, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+    else k_element_matrices_hex<HEX_ELASTICITY, false><<<grid, 128, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+  } else if (kind == HEX_POISSON) {
+    if (rho) k_element_matrices_hex<HEX_POISSON, true><<<grid, 128, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+    else k_element_matrices_hex<HEX_POISSON, false><<<grid, 128, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, nullptr);
+  } else if (kind == HEX_HELMHOLTZ) {
+    k_element_matrices_hex<HEX_HELMHOLTZ, false><<<grid, 128, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, pr, Ke_out, Re_out);
+  } else {
+    return pf_fail(ctx, PF_E_INVALID, "pf_element_matrices3d: kind must be 0 (elasticity), 1 (Poisson) or 2 (Helmholtz)");
+  }
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}

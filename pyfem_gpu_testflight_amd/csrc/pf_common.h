@@ -20,8 +20,9 @@ struct pf_ctx {
 
   // ---- mesh (device copies) ----
   int64_t nnodes = 0, nelems = 0;
-  int P = 0;                 // nodes per element: 4 quad, 3 tri
-  double* X = nullptr;       // (nnodes,2)
+  int P = 0;                 // nodes per element: 4 quad, 3 tri, 8 block (3-D)
+  int ndims = 2;             // 2, or 3 for the 8-node block element
+  double* X = nullptr;       // (nnodes,ndims)
   int32_t* conn = nullptr;   // (nelems,P)
 
   // ---- symbolic pattern ----
@@ -33,10 +34,11 @@ struct pf_ctx {
   int32_t* nidx = nullptr;   // (nblocks)  neighbour node ids, ascending per row
   int32_t* n2e_ptr = nullptr;  // (nnodes+1) node -> incident (element, local index) list
   int32_t* n2e = nullptr;      // (nelems*P) entries e*P + a, ascending per node
-  uint8_t* n2e_pos = nullptr;  // (nelems*P*4) 4 bytes per incident pair j; byte b (< P):
+  uint8_t* n2e_pos = nullptr;  // (nelems*P*PS) PS = 4 (8 for blocks) bytes per incident pair j; byte b (< P):
                                //   position of conn[e,b] in row n of the node graph
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
+                               //   (blocks: 3 x int4 = 8 node ids, 8 position bytes, local index, tile slot)
   int npt = 0;                 // max nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
   void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | visits<<8 | blocks<<16}
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible

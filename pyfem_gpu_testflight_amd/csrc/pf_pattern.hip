@@ -126,7 +126,7 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
       int32_t m = conn[(int64_t)e * P + b];
       int k = 0;
       while (nb[k] != m) ++k;
-      n2e_pos[(int64_t)j * 4 + b] = (uint8_t)k;
+      n2e_pos[(int64_t)j * (P <= 4 ? 4 : 8) + b] = (uint8_t)k;
     }
   }
 }
@@ -153,6 +153,25 @@ __global__ void k_build_visits(int64_t nnodes, const uint8_t* __restrict__ slot,
       w |= (uint32_t)n2e_pos[(int64_t)jj * 4 + b] << (6 * b);
     }
     vis_rec[jj] = make_int4(o[0], o[1], o[2], (int32_t)w);
+  }
+}
+
+// 8-node blocks: three int4 per incident pair jj of node n:
+//   {id0..id3}, {id4..id7}  (all element nodes, n included) and {pos0..3 bytes, pos4..7 bytes, a | slot<<8, 0}
+__global__ void k_build_visits8(int64_t nnodes, const uint8_t* __restrict__ slot, const int32_t* __restrict__ conn,
+                                const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                                const uint8_t* __restrict__ n2e_pos, int4* __restrict__ vis_rec) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int32_t ea = n2e[jj];
+    const int32_t e = ea >> 3;
+    const int a = ea & 7;
+    const int32_t* c = conn + (int64_t)e * 8;
+    const uint32_t* pp = reinterpret_cast<const uint32_t*>(n2e_pos + (int64_t)jj * 8);
+    vis_rec[3 * (int64_t)jj + 0] = make_int4(c[0], c[1], c[2], c[3]);
+    vis_rec[3 * (int64_t)jj + 1] = make_int4(c[4], c[5], c[6], c[7]);
+    vis_rec[3 * (int64_t)jj + 2] = make_int4((int32_t)pp[0], (int32_t)pp[1], a | ((int32_t)slot[n] << 8), 0);
   }
 }
 
@@ -262,10 +281,8 @@ extern "C" int pf_ctx_set_stream(pf_ctx* ctx, void* s) {
   return PF_OK;
 }
 
-extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
-                           int on_device) {
-  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(P == PF_QUAD4 || P == PF_TRI3, "pf_mesh_set: only 4-node quads and 3-node triangles are on this path");
+static int mesh_set(pf_ctx* ctx, int ndims, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
+                    int on_device) {
   PF_REQUIRE(nnodes > 0 && nelems > 0 && X && conn, "pf_mesh_set: empty mesh");
   PF_REQUIRE(nnodes < (int64_t)1 << 30 && nelems * P < (int64_t)1 << 31, "pf_mesh_set: mesh too large for int32 indices");
   PF_HIP(hipSetDevice(ctx->device));
@@ -275,10 +292,11 @@ extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t
   ctx->nnodes = nnodes;
   ctx->nelems = nelems;
   ctx->P = P;
-  PF_HIP(hipMalloc(&ctx->X, sizeof(double) * 2 * nnodes));
+  ctx->ndims = ndims;
+  PF_HIP(hipMalloc(&ctx->X, sizeof(double) * ndims * nnodes));
   PF_HIP(hipMalloc(&ctx->conn, sizeof(int32_t) * P * nelems));
   hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  PF_HIP(hipMemcpyAsync(ctx->X, X, sizeof(double) * 2 * nnodes, kind, ctx->stream));
+  PF_HIP(hipMemcpyAsync(ctx->X, X, sizeof(double) * ndims * nnodes, kind, ctx->stream));
   PF_HIP(hipMemcpyAsync(ctx->conn, conn, sizeof(int32_t) * P * nelems, kind, ctx->stream));
   // conn range check (reference asserts: pyfem.py:680-681)
   int32_t* mm = nullptr;
@@ -295,6 +313,20 @@ extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t
                    "pf_mesh_set: conn must span 0..nnodes-1 (min " + std::to_string(got[0]) + ", max " +
                        std::to_string(got[1]) + ", nnodes " + std::to_string(nnodes) + ")");
   return PF_OK;
+}
+
+extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
+                           int on_device) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(P == PF_QUAD4 || P == PF_TRI3, "pf_mesh_set: only 4-node quads and 3-node triangles are on this path");
+  return mesh_set(ctx, 2, nnodes, X, nelems, P, conn, on_device);
+}
+
+extern "C" int pf_mesh_set3d(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
+                             int on_device) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(P == PF_BLOCK8, "pf_mesh_set3d: only the 8-node block element is on this path");
+  return mesh_set(ctx, 3, nnodes, X, nelems, P, conn, on_device);
 }
 
 static int exclusive_scan_i32(pf_ctx* ctx, int32_t* in, int32_t* out, int64_t n) {
@@ -341,8 +373,9 @@ static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
   PF_HIP(hipStreamSynchronize(ctx->stream));
   ctx->nblocks = total;
   PF_HIP(hipMalloc(&ctx->nidx, sizeof(int32_t) * (size_t)total));
-  PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * 4));
-  PF_HIP(hipMemsetAsync(ctx->n2e_pos, 0, (size_t)ctx->nelems * P * 4, ctx->stream));
+  constexpr int PS = P <= 4 ? 4 : 8;
+  PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * PS));
+  PF_HIP(hipMemsetAsync(ctx->n2e_pos, 0, (size_t)ctx->nelems * P * PS, ctx->stream));
   PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
   k_row_fill<P><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
                                                               ctx->nidx, ctx->n2e_pos, ctx->diagpos);
@@ -353,7 +386,8 @@ static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
 extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->conn, "pf_pattern_build: call pf_mesh_set first");
-  PF_REQUIRE(d == 1 || d == 2, "pf_pattern_build: ndof_per_node must be 1 or 2");
+  PF_REQUIRE(ctx->ndims == 2 ? (d == 1 || d == 2) : (d == 1 || d == 3),
+             "pf_pattern_build: ndof_per_node must be 1 or the space dimension");
   PF_HIP(hipSetDevice(ctx->device));
   pf_pattern_free(ctx);
   const int64_t nn = ctx->nnodes, total = ctx->nelems * ctx->P;
@@ -381,7 +415,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   PF_LAUNCH_CHECK();
   // row counts go into cnt (reused), scanned into nptr
   PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (nn + 1), ctx->stream));
-  rc = (ctx->P == 4) ? build_rows<4>(ctx, cnt, flag) : build_rows<3>(ctx, cnt, flag);
+  rc = (ctx->P == 8) ? build_rows<8>(ctx, cnt, flag) : (ctx->P == 4) ? build_rows<4>(ctx, cnt, flag) : build_rows<3>(ctx, cnt, flag);
   if (rc == PF_OK) rc = max_i32(ctx, cnt, nn, &ctx->max_row_blocks);
   (void)hipFree(cnt);
   (void)hipFree(cursor);
@@ -405,8 +439,8 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     PF_HIP(hipMemcpyAsync(hp.data(), ctx->nptr, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipMemcpyAsync(hv.data(), ctx->n2e_ptr, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
-    int lgA = 0;
-    while ((8 * d * d << lgA) < 128) ++lgA;
+    int lgA = 0;  // a segment start is 128-byte aligned iff its block index is a multiple of 128 / gcd(128, 8 d d)
+    for (int bytes = 8 * d * d; (bytes << lgA) % 128; ++lgA) {}
     std::vector<int32_t> desc;
     desc.reserve(4 * (size_t)(nn / ctx->npt + 16));
     std::vector<uint8_t> slot(nn);
@@ -436,8 +470,10 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     PF_HIP(hipMalloc(&dslot, nn));
     PF_HIP(hipMemcpyAsync(ctx->tile_desc, desc.data(), sizeof(int32_t) * desc.size(), hipMemcpyHostToDevice, ctx->stream));
     PF_HIP(hipMemcpyAsync(dslot, slot.data(), nn, hipMemcpyHostToDevice, ctx->stream));
-    PF_HIP(hipMalloc(&ctx->vis_rec, sizeof(int4) * (size_t)total));
-    if (ctx->P == 4)
+    PF_HIP(hipMalloc(&ctx->vis_rec, sizeof(int4) * (size_t)total * (ctx->P == 8 ? 3 : 1)));
+    if (ctx->P == 8)
+      k_build_visits8<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
+    else if (ctx->P == 4)
       k_build_visits<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     else
       k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
@@ -452,6 +488,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
 int pf_ensure_e2pos(pf_ctx* ctx) {
   if (ctx->e2pos) return PF_OK;
   const int P = ctx->P;
+  PF_REQUIRE(P != 8, "the atomic scatter cross-check is a 2-D mode");
   const int64_t n = ctx->nelems * P * P;
   PF_HIP(hipMalloc(&ctx->e2pos, (size_t)n));
   if (P == 4)
@@ -487,6 +524,8 @@ extern "C" int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices
   unsigned g = (unsigned)cdiv(ctx->nnodes, T);
   if (ctx->d == 1)
     k_csr_structure<1><<<g, T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, indptr, indices);
+  else if (ctx->d == 3)
+    k_csr_structure<3><<<g, T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, indptr, indices);
   else
     k_csr_structure<2><<<g, T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, indptr, indices);
   PF_LAUNCH_CHECK();
@@ -501,7 +540,10 @@ extern "C" int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr) {
     return PF_OK;
   }
   const int T = 128;
-  k_vals_to_csr<2><<<(unsigned)cdiv(ctx->nnodes, T), T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, vals, csr);
+  if (ctx->d == 3)
+    k_vals_to_csr<3><<<(unsigned)cdiv(ctx->nnodes, T), T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, vals, csr);
+  else
+    k_vals_to_csr<2><<<(unsigned)cdiv(ctx->nnodes, T), T, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, vals, csr);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

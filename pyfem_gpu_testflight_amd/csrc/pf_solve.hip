@@ -205,6 +205,67 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// d = 3 (3-D elasticity): 3x3 blocks, 72 B of values + 4 B of index per block.  One persistent wave per
+// 64-node tile; lanes stream the tile's contiguous block range (block g: nine coalesced doubles per lane
+// are 72-byte strided, so the nine loads of a wave cover the same 4.6 KB -- every line is used fully),
+// park the 3-vector product in an LDS strip, then lane-per-node sums its row.  Same epilogues as k_spmv.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __restrict__ nptr,
+                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
+                                              const double* __restrict__ x, double* __restrict__ y,
+                                              double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
+                                              const double* __restrict__ sm_b) {
+  constexpr int CH = 512;
+  __shared__ double prod[3 * CH];
+  const int lane = threadIdx.x;
+  double dacc = 0.0;
+  const int64_t ntiles = (nnodes + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n = tile * 64 + lane;
+    const bool valid = n < nnodes;
+    const int32_t rb = valid ? nptr[n] : 0, re = valid ? nptr[n + 1] : 0;
+    const int32_t base = __shfl(rb, 0);
+    const int32_t end = nptr[min(nnodes, (tile + 1) * 64)];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int32_t c0 = base; c0 < end; c0 += CH) {
+      const int32_t c1 = min(end, c0 + CH);
+      for (int32_t g = c0 + lane; g < c1; g += 64) {
+        const int64_t m = nidx[g];
+        const double* a = vals + 9 * (int64_t)g;
+        const double x0 = x[3 * m], x1 = x[3 * m + 1], x2 = x[3 * m + 2];
+        prod[(g - c0)] = a[0] * x0 + a[1] * x1 + a[2] * x2;           // plane layout: conflict-free strips
+        prod[CH + (g - c0)] = a[3] * x0 + a[4] * x1 + a[5] * x2;
+        prod[2 * CH + (g - c0)] = a[6] * x0 + a[7] * x1 + a[8] * x2;
+      }
+      __syncthreads();
+      for (int32_t g = max(rb, c0); g < min(re, c1); ++g) {
+        acc[0] += prod[g - c0];
+        acc[1] += prod[CH + g - c0];
+        acc[2] += prod[2 * CH + g - c0];
+      }
+      __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int64_t q = 3 * n + k;
+        double out = acc[k];
+        if (sm_b) {
+          const double res = sm_b[q] - out;
+          out = sm_dinv ? x[q] + sm_dinv[q] * res : res;
+        }
+        y[q] = out;
+        if (dot_part) dacc += x[q] * out;
+      }
+    }
+  }
+  if (dot_part) {
+    dacc = wave_sum(dacc);
+    if (lane == 0) dot_part[blockIdx.x] = dacc;
+  }
+}
+
 template <int D>
 __global__ void k_extract_diag(int64_t nnodes, const int32_t* __restrict__ nptr, const uint8_t* __restrict__ diagpos,
                                const double* __restrict__ vals, double* __restrict__ diag, int invert) {
@@ -482,7 +543,9 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
   PF_TRY(1, 2, 2, 3, 1280) PF_TRY(2, 2, 1, 5, 640) PF_TRY(3, 2, 2, 5, 1280) PF_TRY(4, 2, 1, 2, 640) PF_TRY(5, 2, 1, 3, 1024)
 #undef PF_TRY
 #endif
-  if (ctx->d == 1)
+  if (ctx->d == 3)
+    k_spmv3<<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+  else if (ctx->d == 1)
     k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   else
     k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
@@ -502,6 +565,7 @@ extern "C" int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag) {
   PF_REQUIRE(ctx->d && vals && diag, "pf_extract_diag: no pattern / NULL argument");
   const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
   if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
+  else if (ctx->d == 3) k_extract_diag<3><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
   else k_extract_diag<2><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
   PF_LAUNCH_CHECK();
   return PF_OK;
@@ -514,6 +578,8 @@ extern "C" int pf_apply_dirichlet(pf_ctx* ctx, double* Kvals, double* rhs, const
   const unsigned g = (unsigned)cdiv(ctx->nnodes, 128);
   if (ctx->d == 1)
     k_apply_dirichlet<1><<<g, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, Kvals, rhs, fixed_mask, fixed_vals, symmetric, diag_scale);
+  else if (ctx->d == 3)
+    k_apply_dirichlet<3><<<g, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, Kvals, rhs, fixed_mask, fixed_vals, symmetric, diag_scale);
   else
     k_apply_dirichlet<2><<<g, 128, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, Kvals, rhs, fixed_mask, fixed_vals, symmetric, diag_scale);
   PF_LAUNCH_CHECK();
@@ -623,6 +689,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
     if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
+    else if (ctx->d == 3) k_extract_diag<3><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
     else k_extract_diag<2><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
     PF_LAUNCH_CHECK();
   } else {
@@ -691,9 +758,10 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
     const int nrep = pass ? reps : 1;
     PF_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < nrep && rc == PF_OK; ++i) {
-      if (which == PF_K_ASSEMBLE_ELASTICITY) rc = pf_launch_assemble_elasticity(ctx, E, nu, p, in0, PF_SCATTER_GATHER, out0);
+      if (which == PF_K_ASSEMBLE_ELASTICITY && ctx->ndims == 3) rc = pf_assemble_elasticity3d(ctx, E, nu, p, in0, out0);
+      else if (which == PF_K_ASSEMBLE_ELASTICITY) rc = pf_launch_assemble_elasticity(ctx, E, nu, p, in0, PF_SCATTER_GATHER, out0);
       else if (which == PF_K_SPMV) rc = pf_launch_spmv(ctx, in0, in1, out0, nullptr);
-      else if (which == PF_K_ASSEMBLE_HELMHOLTZ) rc = pf_launch_assemble_helmholtz(ctx, E, out0, nullptr);
+      else if (which == PF_K_ASSEMBLE_HELMHOLTZ && ctx->ndims == 2) rc = pf_launch_assemble_helmholtz(ctx, E, out0, nullptr);
       else rc = pf_fail(ctx, PF_E_INVALID, "pf_time_kernel: unknown kernel");
     }
     PF_HIP(hipEventRecord(e1, ctx->stream));

@@ -36,14 +36,17 @@ class HipContext:
         _lib.check(None, self.lib.pf_ctx_create(self.device.index, C.byref(self._ctx)), "pf_ctx_create")
         X = np.ascontiguousarray(X, dtype=np.float64)
         conn = np.asarray(conn)
-        if X.ndim != 2 or X.shape[1] != 2:
-            raise ValueError("the accelerated path covers 2-D meshes (X of shape (nnodes, 2)) only")
-        if conn.ndim != 2 or conn.shape[1] not in (3, 4):
-            raise ValueError(f"unknown element_type: {conn.shape[1]}-node elements are not on the accelerated path")
+        if X.ndim != 2 or X.shape[1] not in (2, 3):
+            raise ValueError("X must have shape (nnodes, 2) or (nnodes, 3)")
+        self.ndims = X.shape[1]
+        if conn.ndim != 2 or conn.shape[1] not in ((3, 4) if self.ndims == 2 else (8,)):
+            raise ValueError(f"unknown element_type: {conn.shape[1]}-node elements in {self.ndims}-D are not on the "
+                             "accelerated path (2-D: 3-node triangles, 4-node quads; 3-D: 8-node blocks)")
         conn32 = np.ascontiguousarray(conn, dtype=np.int32)
         self.nnodes, self.nelems, self.P, self.d = X.shape[0], conn.shape[0], conn.shape[1], int(ndof_per_node)
         self._sync_stream()
-        self._call("pf_mesh_set", _lib._i64(self.nnodes), X.ctypes.data_as(C.c_void_p), _lib._i64(self.nelems),
+        self._call("pf_mesh_set" if self.ndims == 2 else "pf_mesh_set3d", _lib._i64(self.nnodes),
+                   X.ctypes.data_as(C.c_void_p), _lib._i64(self.nelems),
                    self.P, conn32.ctypes.data_as(C.c_void_p), 0)
         self._call("pf_pattern_build", self.d)
         nrows, nnz, nblocks, maxrow = _lib._i64(), _lib._i64(), _lib._i64(), _lib._i32()
@@ -107,13 +110,16 @@ class HipContext:
     def assemble_elasticity(self, E, nu, p, rho=None, mode=_lib.PF_SCATTER_GATHER, out=None):
         vals = self.empty(self.nnz) if out is None else out
         self._sync_stream()
-        self._call("pf_assemble_elasticity2d", E, nu, p, _ptr(rho), mode, _ptr(vals))
+        if self.ndims == 3:
+            self._call("pf_assemble_elasticity3d", E, nu, p, _ptr(rho), _ptr(vals))
+        else:
+            self._call("pf_assemble_elasticity2d", E, nu, p, _ptr(rho), mode, _ptr(vals))
         return vals
 
     def assemble_helmholtz(self, r0):
         K, R = self.empty(self.nnz), self.empty(self.nnz)
         self._sync_stream()
-        self._call("pf_assemble_helmholtz2d", r0, _ptr(K), _ptr(R))
+        self._call("pf_assemble_helmholtz2d" if self.ndims == 2 else "pf_assemble_helmholtz3d", r0, _ptr(K), _ptr(R))
         return K, R
 
     def sens_elasticity(self, E, nu, p, rho, phi, psi):
@@ -125,13 +131,16 @@ class HipContext:
     def assemble_poisson(self, p, rho=None, out=None):
         vals = self.empty(self.nnz) if out is None else out
         self._sync_stream()
-        self._call("pf_assemble_poisson2d", p, _ptr(rho), _ptr(vals))
+        self._call("pf_assemble_poisson2d" if self.ndims == 2 else "pf_assemble_poisson3d", p, _ptr(rho), _ptr(vals))
         return vals
 
     def element_matrices_poisson(self, p, rho=None):
         out = self.empty(self.nelems * self.P * self.P)
         self._sync_stream()
-        self._call("pf_element_matrices_poisson2d", p, _ptr(rho), _ptr(out))
+        if self.ndims == 3:
+            self._call("pf_element_matrices3d", 1, 0.0, 0.0, p, 0.0, _ptr(rho), _ptr(out), None)
+        else:
+            self._call("pf_element_matrices_poisson2d", p, _ptr(rho), _ptr(out))
         return out.view(self.nelems, self.P, self.P)
 
     def quad_points(self):
@@ -154,16 +163,22 @@ class HipContext:
         return out
 
     def element_matrices_elasticity(self, E, nu, p, rho=None):
-        D = self.P * 2
+        D = self.P * self.ndims
         out = self.empty(self.nelems * D * D)
         self._sync_stream()
-        self._call("pf_element_matrices_elasticity2d", E, nu, p, _ptr(rho), _ptr(out))
+        if self.ndims == 3:
+            self._call("pf_element_matrices3d", 0, E, nu, p, 0.0, _ptr(rho), _ptr(out), None)
+        else:
+            self._call("pf_element_matrices_elasticity2d", E, nu, p, _ptr(rho), _ptr(out))
         return out.view(self.nelems, D, D)
 
     def element_matrices_helmholtz(self, r0):
         Ke, Re = self.empty(self.nelems * self.P * self.P), self.empty(self.nelems * self.P * self.P)
         self._sync_stream()
-        self._call("pf_element_matrices_helmholtz2d", r0, _ptr(Ke), _ptr(Re))
+        if self.ndims == 3:
+            self._call("pf_element_matrices3d", 2, 0.0, 0.0, 0.0, r0, None, _ptr(Ke), _ptr(Re))
+        else:
+            self._call("pf_element_matrices_helmholtz2d", r0, _ptr(Ke), _ptr(Re))
         return Ke.view(self.nelems, self.P, self.P), Re.view(self.nelems, self.P, self.P)
 
     def vals_to_csr(self, vals):

@@ -71,6 +71,14 @@ class QuadratureBilinear2D(QuadratureBase):
         super().__init__([[-g, -g], [g, -g], [g, g], [-g, g]], [1.0, 1.0, 1.0, 1.0])
 
 
+class QuadratureBlock3D(QuadratureBase):
+    """ref: pyfem.py:97-112 -- 2x2x2 Gauss, x slowest / z fastest, unit weights."""
+
+    def __init__(self):
+        g = 1.0 / np.sqrt(3.0)
+        super().__init__([[sx * g, sy * g, sz * g] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], [1.0] * 8)
+
+
 class BasisBase:
     def __init__(self, ndims, nnodes_per_elem, quadrature):
         self.ndims = ndims
@@ -107,6 +115,25 @@ class BasisBilinear2D(BasisBase):
                 0.25 * (1 + q[1]), 0.25 * (1 + q[0]), -0.25 * (1 + q[1]), 0.25 * (1 - q[0])]
 
 
+class BasisBlock3D(BasisBase):
+    """ref: pyfem.py:287-338 -- trilinear 8-node block, nodes CCW on z=-1 then z=+1."""
+
+    _S = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]],
+                  dtype=float)
+
+    def __init__(self, quadrature):
+        super().__init__(3, 8, quadrature)
+
+    def _eval_shape_fun_on_quad_pt(self, q):
+        f = 1.0 + self._S * np.asarray(q)[None, :]
+        return list(0.125 * f[:, 0] * f[:, 1] * f[:, 2])
+
+    def _eval_shape_deriv_on_quad_pt(self, q):
+        f = 1.0 + self._S * np.asarray(q)[None, :]
+        d = 0.125 * self._S * np.stack([f[:, 1] * f[:, 2], f[:, 0] * f[:, 2], f[:, 0] * f[:, 1]], axis=1)
+        return list(d.ravel())
+
+
 class BasisTriangle2D(BasisBase):
     """ref: pyfem.py:341-377."""
 
@@ -123,11 +150,12 @@ class BasisTriangle2D(BasisBase):
 def _check_tables(quadrature, basis):
     """The kernels hard-wire the two (quadrature, basis) pairs on the path; refuse anything else."""
     ok = (isinstance(quadrature, QuadratureBilinear2D) and isinstance(basis, BasisBilinear2D)) or (
-        isinstance(quadrature, QuadratureTriangle2D) and isinstance(basis, BasisTriangle2D))
+        isinstance(quadrature, QuadratureTriangle2D) and isinstance(basis, BasisTriangle2D)) or (
+        isinstance(quadrature, QuadratureBlock3D) and isinstance(basis, BasisBlock3D))
     if not ok:
         raise NotImplementedError(
-            "accelerated path: only (QuadratureBilinear2D, BasisBilinear2D) and "
-            "(QuadratureTriangle2D, BasisTriangle2D) are implemented as HIP kernels")
+            "accelerated path: only (QuadratureBilinear2D, BasisBilinear2D), (QuadratureTriangle2D, "
+            "BasisTriangle2D) and (QuadratureBlock3D, BasisBlock3D) are implemented as HIP kernels")
 
 
 # ------------------------------------------------------------------------------------------
@@ -206,9 +234,6 @@ class LinearPoisson(ModelBase):
 
     @time_this
     def __init__(self, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, gfunc, kappa0=1.0, p=0.0, device=None):
-        X = np.asarray(X)
-        if X.shape[1] != 2:
-            raise NotImplementedError("accelerated path: 3-D Poisson is out of scope (SURVEY.md 8f, f4)")
         super().__init__(1, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
         self.gfunc = gfunc
         self.fun_vals = None
@@ -235,6 +260,8 @@ class LinearPoisson(ModelBase):
     def compute_rhs(self):
         """ref: pyfem.py:997-1004, 1138-1173."""
         torch = self.hctx.torch
+        if self.ndims == 3:
+            raise NotImplementedError("accelerated path: the 3-D element load vector is not built yet (K is)")
         Xq = self.hctx.quad_points().cpu().numpy()
         self.fun_vals = np.asarray(self.gfunc(Xq), dtype=float)
         gq = self.hctx.to_device(np.ascontiguousarray(self.fun_vals), torch.float64)
@@ -290,6 +317,8 @@ class LinearPoisson(ModelBase):
     def _compute_K_dv_sens(self, rho, phi, psi):
         """ref: pyfem.py:1240-1276, fused (no Ke_deriv tensor)."""
         torch = self.hctx.torch
+        if self.ndims == 3:
+            raise NotImplementedError("accelerated path: 3-D sensitivities are not built yet")
         if not hasattr(rho, "__len__"):
             rho = np.ones(self.nnodes) * rho
         rho_d = self._rho_device(rho)
@@ -307,13 +336,18 @@ class LinearElasticity(ModelBase):
     def __init__(self, X, conn, dof_fixed, dof_fixed_vals, nodal_force, quadrature, basis, E=10.0, nu=0.3, p=0.0,
                  device=None):
         X = np.asarray(X)
-        if X.shape[1] != 2:
-            raise NotImplementedError("accelerated path: 3-D elasticity is out of scope (SURVEY.md section 2, row 6)")
-        super().__init__(2, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
+        super().__init__(X.shape[1], X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
         self.nodal_force = nodal_force
         self.E, self.nu, self.p = float(E), float(nu), float(p)
-        self.C0 = E * np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, 0.5 * (1.0 - nu)]])
-        self.C0 *= 1.0 / (1.0 - nu**2)
+        if self.ndims == 2:  # ref: pyfem.py:1746-1750
+            self.C0 = E * np.array([[1.0, nu, 0.0], [nu, 1.0, 0.0], [0.0, 0.0, 0.5 * (1.0 - nu)]])
+            self.C0 *= 1.0 / (1.0 - nu**2)
+        else:  # ref: pyfem.py:1752-1757
+            self.C0 = np.zeros((6, 6))
+            self.C0[0, 0] = self.C0[1, 1] = self.C0[2, 2] = 1 - nu
+            self.C0[0, 1] = self.C0[0, 2] = self.C0[1, 0] = self.C0[1, 2] = self.C0[2, 0] = self.C0[2, 1] = nu
+            self.C0[3, 3] = self.C0[4, 4] = self.C0[5, 5] = 0.5 - nu
+            self.C0 *= E / ((1 + nu) * (1 - 2 * nu))
         self.scatter_mode = _lib.PF_SCATTER_GATHER
         self._last_rho = None
 
@@ -523,43 +557,58 @@ class Assembler:
 
 # ------------------------------------------------------------------------------------------
 class ProblemCreator:
-    """Vectorised equivalent of the reference's loop-based generator (pyfem.py:2426-2773) for the
-    2-D element types on the path; produces identical conn / X / dof_fixed / nodal_force."""
+    """Vectorised equivalent of the reference's loop-based generator (pyfem.py:2426-2773) for the element
+    types on the path (quad, tri, block); produces identical conn / X / dof_fixed / nodal_force."""
 
     def __init__(self, nnodes_x, nnodes_y, nnodes_z=None, Lx=None, Ly=None, Lz=None, element_type="quad"):
-        if nnodes_z is not None:
-            raise NotImplementedError("accelerated path: 3-D meshes are out of scope")
-        assert element_type == "quad" or element_type == "tri"
-        self.ndims = 2
+        if nnodes_z is None:
+            self.ndims = 2
+            nnodes_z = 1
+            assert element_type == "quad" or element_type == "tri"
+        else:
+            self.ndims = 3
+            assert element_type == "block" or element_type == "tet" or element_type == "brick20"
+            if element_type != "block":
+                raise NotImplementedError("accelerated path: of the 3-D elements only the 8-node block is built")
         Lx = (nnodes_x - 1) / (nnodes_y - 1) if Lx is None else Lx
         Ly = 1.0 if Ly is None else Ly
-        x = np.linspace(0, Lx, nnodes_x)
-        y = np.linspace(0, Ly, nnodes_y)
-        self.X = np.stack([np.tile(x, nnodes_y), np.repeat(y, nnodes_x)], axis=1)
-        self.nodes3d = np.arange(nnodes_x * nnodes_y).reshape((1, nnodes_y, nnodes_x))
-        n00 = self.nodes3d[0, :-1, :-1].ravel()
+        Lz = (nnodes_z - 1) / (nnodes_y - 1) if Lz is None else Lz
+        x, y, z = np.linspace(0, Lx, nnodes_x), np.linspace(0, Ly, nnodes_y), np.linspace(0, Lz, nnodes_z)
+        X = np.stack([np.tile(x, nnodes_y * nnodes_z), np.tile(np.repeat(y, nnodes_x), nnodes_z),
+                      np.repeat(z, nnodes_x * nnodes_y)], axis=1)
+        self.X = np.ascontiguousarray(X[:, : self.ndims])
+        self.nodes3d = np.arange(nnodes_x * nnodes_y * nnodes_z).reshape((nnodes_z, nnodes_y, nnodes_x))
+        if self.ndims == 2:
+            n00 = self.nodes3d[0, :-1, :-1].ravel()
+        else:
+            n00 = self.nodes3d[:-1, :-1, :-1].ravel()
         n10, n11, n01 = n00 + 1, n00 + 1 + nnodes_x, n00 + nnodes_x
         if element_type == "quad":
             conn = np.stack([n00, n10, n11, n01], axis=1)
-        else:
+        elif element_type == "tri":
             conn = np.empty((2 * n00.size, 3), dtype=int)
             conn[0::2] = np.stack([n00, n10, n11], axis=1)
             conn[1::2] = np.stack([n11, n01, n00], axis=1)
+        else:
+            lo = np.stack([n00, n10, n11, n01], axis=1)
+            conn = np.concatenate([lo, lo + nnodes_x * nnodes_y], axis=1)
         self.conn = conn.astype(int)
-        self.nnodes_x, self.nnodes_y, self.nnodes_z = nnodes_x, nnodes_y, 1
-        self.nnodes = nnodes_x * nnodes_y
+        self.nnodes_x, self.nnodes_y, self.nnodes_z = nnodes_x, nnodes_y, nnodes_z
+        self.nnodes = nnodes_x * nnodes_y * nnodes_z
 
     def create_poisson_problem(self):
-        return self.conn, self.X, list(self.nodes3d[0, :, 0])
+        return self.conn, self.X, list(self.nodes3d[:, :, 0].ravel())
 
     def create_linear_elasticity_problem(self):
-        col0 = self.nodes3d[0, :, 0]
-        dof_fixed = list(np.stack([2 * col0, 2 * col0 + 1], axis=1).ravel())
-        nodal_force = {int(self.nodes3d[0, 0, -1]): [0.0, -1.0]}
+        face = self.nodes3d[:, :, 0].ravel()
+        nd = self.ndims
+        dof_fixed = list((nd * face[:, None] + np.arange(nd)[None, :]).ravel())
+        nodal_force = {int(self.nodes3d[k, 0, -1]): [0.0, -1.0, 0.0][0:nd] for k in range(self.nnodes_z)}
         return self.conn, self.X, dof_fixed, nodal_force
 
     def create_helmhotz_problem(self):
-        i = np.tile(np.arange(self.nnodes_x), self.nnodes_y)
-        j = np.repeat(np.arange(self.nnodes_y), self.nnodes_x)
-        x = np.where((i < self.nnodes_x / 2) & (j < self.nnodes_y / 2), 0.95, 1e-3)
-        return self.conn, self.X, x
+        i = np.tile(np.arange(self.nnodes_x), self.nnodes_y * self.nnodes_z)
+        j = np.tile(np.repeat(np.arange(self.nnodes_y), self.nnodes_x), self.nnodes_z)
+        k = np.repeat(np.arange(self.nnodes_z), self.nnodes_x * self.nnodes_y)
+        inside = (i < self.nnodes_x / 2) & (j < self.nnodes_y / 2) & (k < self.nnodes_z / 2)
+        return self.conn, self.X, np.where(inside, 0.95, 1e-3)

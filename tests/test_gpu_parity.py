@@ -36,6 +36,9 @@ def _qb(pf, etype):
     if etype == "quad":
         q = pf.QuadratureBilinear2D()
         return q, pf.BasisBilinear2D(q)
+    if etype == "block":
+        q = pf.QuadratureBlock3D()
+        return q, pf.BasisBlock3D(q)
     q = pf.QuadratureTriangle2D()
     return q, pf.BasisTriangle2D(q)
 
@@ -69,7 +72,7 @@ def test_elasticity_K_matches_reference(pf, orc, name, mode):
     model.scatter_mode = _lib.PF_SCATTER_GATHER if mode == "gather" else _lib.PF_SCATTER_ATOMIC
     K = model.compute_jacobian() if "rho" not in g else model.compute_jacobian(g["rho"])
     Ks = K.to_scipy()
-    n = 2 * g["X"].shape[0]
+    n = g["X"].shape[1] * g["X"].shape[0]
     assert Ks.shape == (n, n) and Ks.nnz == int(g["K_nnz"])
     kmax = np.abs(g["K_diag"]).max()
     # fixtures from the reference itself
@@ -82,12 +85,14 @@ def test_elasticity_K_matches_reference(pf, orc, name, mode):
         assert np.abs(Ks.data - Kref.data).max() <= K_TOL * np.abs(Kref.data).max()
     # oracle on the same inputs, entry by entry
     Ko = orc.assemble_csr(orc.elasticity_Ke(g["X"], g["conn"].astype(np.int64), etype, rho=g.get("rho"),
-                                            p=float(g["p"])), orc.create_conn_dof(g["conn"].astype(np.int64), 2))
+                                            p=float(g["p"])),
+                          orc.create_conn_dof(g["conn"].astype(np.int64), g["X"].shape[1]))
     assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
     assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
 
 
-@pytest.mark.parametrize("name", ["ps13x9_quad_distorted", "ps11x8_tri_ramp", "arm_tri"])
+@pytest.mark.parametrize("name", ["ps13x9_quad_distorted", "ps11x8_tri_ramp", "arm_tri", "ps3d_6x4x3_block",
+                                  "ps3d_5x4x4_block_ramp_distorted"])
 def test_element_matrices(pf, orc, name):
     g = load(name)
     etype = ELASTICITY_CASES[name]
@@ -467,3 +472,107 @@ def test_amg_preconditioner(pf, orc, etype, shape):
         assert relmax(hm.apply(x), f.apply(x)) < U_TOL
         its["h" + pre] = hm.last_iters
     assert its["hamg"] * 3 < its["hjacobi"], its
+
+
+# ---- 3-D 8-node block element ------------------------------------------------
+def test_block_helmholtz(pf, orc):
+    g = load("helm3d_5x4x3_block")
+    q, b = _qb(pf, "block")
+    model = pf.Helmholtz(float(g["r0"]), g["X"], g["conn"], q, b)
+    n = g["X"].shape[0]
+    for M, pre in ((model.K, "K"), (model.R, "R")):
+        ref = csr_of(g, pre, n)
+        Ms = M.to_scipy()
+        assert np.array_equal(Ms.indptr, ref.indptr) and np.array_equal(Ms.indices, ref.indices)
+        assert np.abs(Ms.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
+    for precond in ("jacobi", "amg"):
+        model.precond = precond
+        assert relmax(model.apply(g["x"]), g["rho"]) < U_TOL
+        assert relmax(model.apply_gradient(g["g"]), g["gx"]) < U_TOL
+
+
+def test_block_poisson_K(pf, orc):
+    g = load("poi3d_5x4x3_block")
+    q, b = _qb(pf, "block")
+    model = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], g["fixed_vals"], q, b, lambda x: 0.0 * x[..., 0],
+                             p=float(g["p"]))
+    K = model.compute_jacobian(g["rho"])
+    Ks, ref = K.to_scipy(), csr_of(g, "K", g["X"].shape[0])
+    assert np.array_equal(Ks.indptr, ref.indptr) and np.array_equal(Ks.indices, ref.indices)
+    assert np.abs(Ks.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
+    assert np.abs(model.Ke_mat[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
+    # Dirichlet values + solve against the reference's u, with the reference's own rhs vector
+    rhs = g["rhs"].copy()
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+    assert relmax(rhs, g["rhs_bc"]) < 1e-12
+    u = pf.Assembler(model)._solve_linear_system(K, rhs, "cg")
+    assert relmax(u, g["u"]) < U_TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 2), (3, 2, 2), (9, 9, 2), (17, 3, 5), (6, 13, 7)])
+def test_block_ragged_sizes_match_oracle(pf, orc, shape):
+    """Tile edges (8 nodes / 64 incident pairs), boundary valences 1, 2, 4 and 8, random density."""
+    conn, X = orc.structured_mesh3d(*shape)
+    rng = np.random.RandomState(sum(shape))
+    X = X + 0.03 * (rng.rand(*X.shape) - 0.5) / max(shape)
+    rho = 0.2 + 0.8 * rng.rand(X.shape[0])
+    q, b = _qb(pf, "block")
+    dof_fixed, force = orc.elasticity_problem3d(*shape)
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+    Ks = model.compute_jacobian(rho).to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X, conn, "block", rho=rho, p=3.0), orc.create_conn_dof(conn, 3))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    v = rng.rand(Ks.shape[0])
+    assert relmax(model.compute_jacobian(rho).dot(v), Ko.dot(v)) < K_TOL
+
+
+def test_block_problem_creator_matches_reference(pf):
+    g = load("mesh3d_4x3x3")
+    c = pf.ProblemCreator(4, 3, 3, element_type="block")
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    assert np.array_equal(conn, g["conn"]) and np.allclose(X, g["X"], rtol=0, atol=1e-15)
+    assert np.array_equal(np.asarray(dof_fixed), g["dof_fixed"])
+    assert list(force.keys()) == list(g["force_nodes"]) and np.array_equal(np.array(list(force.values())), g["force_vals"])
+    assert np.array_equal(c.create_helmhotz_problem()[2], g["helm_x"])
+    assert np.array_equal(np.asarray(c.create_poisson_problem()[2]), g["poisson_fixed"])
+    N = pf.BasisBlock3D(pf.QuadratureBlock3D())
+    from oracle import pyfem_oracle as o
+
+    No, dNo = o.shape_tables("block")
+    assert np.allclose(N.eval_shape_fun(), No, atol=1e-15) and np.allclose(N.eval_shape_fun_deriv(), dNo, atol=1e-15)
+
+
+def test_block_full_size_properties(pf):
+    """48^3 blocks (SciTech2023/performance_test.py range): rigid-body null space, symmetry through
+    v^T K w = w^T K v, mesh-independent element row, Jacobi-PCG residual."""
+    import torch
+
+    n = 49
+    c = pf.ProblemCreator(n, n, n, element_type="block")
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q, b = _qb(pf, "block")
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    h = model.hctx
+    K = model.compute_jacobian()
+    kmax = float(K.vals.abs().max())
+    Xd = h.to_device(X, torch.float64)
+    for mode in range(6):  # 3 translations, 3 infinitesimal rotations
+        u = torch.zeros_like(Xd)
+        if mode < 3:
+            u[:, mode] = 1.0
+        else:
+            i, j = [(0, 1), (1, 2), (2, 0)][mode - 3]
+            u[:, i], u[:, j] = -Xd[:, j], Xd[:, i]
+        r = h.spmv(K.vals, u.reshape(-1).contiguous())
+        assert float(r.abs().max()) < 1e-10 * kmax * float(u.abs().max()) * 27
+    g = torch.Generator(device="cpu").manual_seed(3)
+    v = torch.rand(h.nrows, generator=g, dtype=torch.float64).to(h.device)
+    w = torch.rand(h.nrows, generator=g, dtype=torch.float64).to(h.device)
+    a, bb = float(v.dot(h.spmv(K.vals, w))), float(w.dot(h.spmv(K.vals, v)))
+    assert abs(a - bb) < 1e-11 * abs(a)
+    rhs = h.to_device(model.compute_rhs(), torch.float64)
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+    u, it, rr = h.cg(K.vals, rhs, rtol=1e-8)
+    res = rhs - h.spmv(K.vals, u)
+    assert float(res.norm() / rhs.norm()) < 2e-8 and it > 0
