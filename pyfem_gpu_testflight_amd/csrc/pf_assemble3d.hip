@@ -36,10 +36,21 @@ __host__ __device__ constexpr int hsx(int l) { return ((l ^ (l >> 1)) & 1) ? 1 :
 __host__ __device__ constexpr int hsy(int l) { return (l & 2) ? 1 : -1; }
 __host__ __device__ constexpr int hsz(int l) { return (l & 4) ? 1 : -1; }
 
-// rows of node `a` (runtime local index) of the element matrix: v[b][*] = block (a, b)
+// RAMP factor rho_q / (1 + p (1 - rho_q)) at quadrature point q (utils.py:204-221, pyfem.py:1923-1945)
+__device__ __forceinline__ double hex_ramp(double p, const double (&rho)[8], int q) {
+  const double xi = (q & 4) ? G3 : -G3, et = (q & 2) ? G3 : -G3, ze = (q & 1) ? G3 : -G3;
+  double rq = 0.0;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) rq += 0.125 * (1.0 + hsx(l) * xi) * (1.0 + hsy(l) * et) * (1.0 + hsz(l) * ze) * rho[l];
+  return rq / (1.0 + p * (1.0 - rq));
+}
+
+// rows of node `a` (runtime local index) of the element matrix: v[b][*] = block (a, b).
+// cq[q * cq_stride]: RAMP factor of point q (RHO only) -- parked in LDS by the caller, because the eight
+// density values would cost the 16 registers that decide between one and two waves per SIMD.
 template <int KIND, bool RHO>
 __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)[8], const double (&cy)[8],
-                                         const double (&cz)[8], const double (&rho)[8], int a,
+                                         const double (&cz)[8], const double* cq, int cq_stride, int a,
                                          double (&v)[8][HexV<KIND>::V]) {
   constexpr int NS = KIND == HEX_ELASTICITY ? 9 : KIND == HEX_HELMHOLTZ ? 2 : 1;
   const double sxa = ((a ^ (a >> 1)) & 1) ? 1.0 : -1.0, sya = (a & 2) ? 1.0 : -1.0, sza = (a & 4) ? 1.0 : -1.0;
@@ -48,6 +59,30 @@ __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)
   for (int b = 0; b < 8; ++b)
 #pragma unroll
     for (int k = 0; k < NS; ++k) S[b][k] = 0.0;
+
+  // The trilinear map in monomial form: x(xi) = c0 + c[0] xi + c[1] eta + c[2] zeta + c[3] xi eta + c[4] eta zeta
+  // + c[5] xi zeta + c[6] xi eta zeta.  A Jacobian column is then 3 FMAs per component instead of the 8-term
+  // sum of utils.py:172-185 (same polynomial, different rounding), and only 21 coordinate values stay live.
+  double mc[3][7];
+  {
+    const double (*cc[3])[8] = {&cx, &cy, &cz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t) mc[d][t] = 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const double xv = 0.125 * (*cc[d])[l];
+        mc[d][0] += hsx(l) * xv;
+        mc[d][1] += hsy(l) * xv;
+        mc[d][2] += hsz(l) * xv;
+        mc[d][3] += hsx(l) * hsy(l) * xv;
+        mc[d][4] += hsy(l) * hsz(l) * xv;
+        mc[d][5] += hsx(l) * hsz(l) * xv;
+        mc[d][6] += hsx(l) * hsy(l) * hsz(l) * xv;
+      }
+    }
+  }
 
 #pragma unroll 1
   for (int q = 0; q < 8; ++q) {  // pyfem.py:97-112: q = 4 ix + 2 iy + iz
@@ -62,21 +97,14 @@ __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)
         pxz[i][j] = 0.125 * fx[i] * fz[j];
         pxy[i][j] = 0.125 * fx[i] * fy[j];
       }
-    // Jq[j][k] = sum_l X_l[j] dN_l/dxi_k (utils.py:172-185)
+    // Jq[j][k] = d x_j / d xi_k
+    const double xe = xi * et, ez = et * ze, xz = xi * ze;
     double J[3][3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) J[j][k] = 0.0;
-    double rq = 0.0;
-#pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      const int ix = hsx(l) > 0, iy = hsy(l) > 0, iz = hsz(l) > 0;
-      const double d0 = hsx(l) * pyz[iy][iz], d1 = hsy(l) * pxz[ix][iz], d2 = hsz(l) * pxy[ix][iy];
-      J[0][0] += cx[l] * d0; J[0][1] += cx[l] * d1; J[0][2] += cx[l] * d2;
-      J[1][0] += cy[l] * d0; J[1][1] += cy[l] * d1; J[1][2] += cy[l] * d2;
-      J[2][0] += cz[l] * d0; J[2][1] += cz[l] * d1; J[2][2] += cz[l] * d2;
-      if constexpr (RHO) rq += pxy[ix][iy] * fz[iz] * rho[l];  // utils.py:204-221
+    for (int j = 0; j < 3; ++j) {
+      J[j][0] = mc[j][0] + mc[j][3] * et + mc[j][5] * ze + mc[j][6] * ez;
+      J[j][1] = mc[j][1] + mc[j][3] * xi + mc[j][4] * ze + mc[j][6] * xz;
+      J[j][2] = mc[j][2] + mc[j][5] * xi + mc[j][4] * et + mc[j][6] * xe;
     }
     const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
     const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
@@ -94,7 +122,7 @@ __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)
     inv[2][1] = -(J[0][0] * J[2][1] - J[0][1] * J[2][0]) * rd;
     inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
     double scale = det;  // weights are 1
-    if constexpr (RHO) scale *= rq / (1.0 + pr.p * (1.0 - rq));
+    if constexpr (RHO) scale *= cq[q * cq_stride];
     // own node: factors from its runtime signs (no register array is indexed by a)
     const double fxa = 1.0 + sxa * xi, fya = 1.0 + sya * et, fza = 1.0 + sza * ze;
     const double a0 = 0.125 * sxa * fya * fza, a1 = 0.125 * sya * fxa * fza, a2 = 0.125 * sza * fxa * fya;
@@ -102,8 +130,11 @@ __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)
 #pragma unroll
     for (int j = 0; j < 3; ++j) ga[j] = scale * (a0 * inv[0][j] + a1 * inv[1][j] + a2 * inv[2][j]);
     const double Na = 0.125 * fxa * fya * fza;
+    // elasticity: the gradients of the eight shape functions sum to zero, so the block of node 7 is minus the
+    // sum of the others -- 63 accumulators instead of 72 (the kernel is register-bound: 2 waves per SIMD)
+    constexpr int NB = KIND == HEX_ELASTICITY ? 7 : 8;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const int ix = hsx(b) > 0, iy = hsy(b) > 0, iz = hsz(b) > 0;
       const double d0 = hsx(b) * pyz[iy][iz], d1 = hsy(b) * pxz[ix][iz], d2 = hsz(b) * pxy[ix][iy];
       double gb[3];
@@ -119,6 +150,10 @@ __device__ __forceinline__ void hex_rows(const HexParams& pr, const double (&cx)
         if constexpr (KIND == HEX_HELMHOLTZ) S[b][1] += det * Na * (pxy[ix][iy] * fz[iz]);  // pyfem.py:2134
       }
     }
+  }
+  if constexpr (KIND == HEX_ELASTICITY) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[7][k] = -(((S[0][k] + S[1][k]) + (S[2][k] + S[3][k])) + ((S[4][k] + S[5][k]) + S[6][k]));
   }
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
@@ -154,7 +189,7 @@ __device__ __forceinline__ void hex_load(const double* __restrict__ X, const dou
 
 // dynamic LDS: double img[V * plane]
 template <int KIND, bool RHO>
-__global__ __launch_bounds__(64) void k_assemble_hex(int64_t ntiles, int32_t plane, const double* __restrict__ X,
+__global__ __launch_bounds__(64, 2) void k_assemble_hex(int64_t ntiles, int32_t plane, const double* __restrict__ X,
                                                      const int32_t* __restrict__ nptr,
                                                      const int4* __restrict__ tile_desc,
                                                      const int4* __restrict__ vis_rec, HexParams pr,
@@ -168,18 +203,29 @@ __global__ __launch_bounds__(64) void k_assemble_hex(int64_t ntiles, int32_t pla
     const int32_t n0 = dsc.x, vb = dsc.y, base = dsc.z;
     const int32_t nv = (dsc.w >> 8) & 255;
     const int32_t nblk = (int32_t)((uint32_t)dsc.w >> 16);
+    const bool active = lane < nv;
+    int4 r2 = make_int4(0, 0, 0, 0);
+    int32_t roff = 0;
+    double v[8][V];
+    if (active) {
+      const int64_t jj = (int64_t)vb + lane;
+      const int4 r0 = vis_rec[3 * jj], r1 = vis_rec[3 * jj + 1];
+      r2 = vis_rec[3 * jj + 2];
+      const int a = r2.z & 255, slot = (r2.z >> 8) & 255;
+      roff = nptr[n0 + slot] - base;
+      double cx[8], cy[8], cz[8], re[8];
+      hex_load(X, RHO ? pr.rho : nullptr, r0, r1, cx, cy, cz, re);
+      if constexpr (RHO) {  // the image is free until the adds below: park the eight RAMP factors there
+#pragma unroll
+        for (int q = 0; q < 8; ++q) img[q * 64 + lane] = hex_ramp(pr.p, re, q);
+      }
+      hex_rows<KIND, RHO>(pr, cx, cy, cz, img + lane, 64, a, v);
+    }
+    // one wave: LDS operations execute in program order, so no barrier between the phases
 #pragma unroll
     for (int k = 0; k < V; ++k)
       for (int32_t q = lane; q < nblk; q += 64) img[k * plane + q] = 0.0;
-    if (lane < nv) {
-      const int64_t jj = (int64_t)vb + lane;
-      const int4 r0 = vis_rec[3 * jj], r1 = vis_rec[3 * jj + 1], r2 = vis_rec[3 * jj + 2];
-      const int a = r2.z & 255, slot = (r2.z >> 8) & 255;
-      const int32_t roff = nptr[n0 + slot] - base;
-      double cx[8], cy[8], cz[8], re[8];
-      hex_load(X, RHO ? pr.rho : nullptr, r0, r1, cx, cy, cz, re);
-      double v[8][V];
-      hex_rows<KIND, RHO>(pr, cx, cy, cz, re, a, v);
+    if (active) {
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
         const uint32_t pw = (uint32_t)(b < 4 ? r2.x : r2.y);
@@ -189,7 +235,7 @@ __global__ __launch_bounds__(64) void k_assemble_hex(int64_t ntiles, int32_t pla
           __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
     }
-    // copy-out (one wave: LDS executes in order, no barrier)
+    // copy-out
     if constexpr (V == 9) {
       double* dst = out0 + (int64_t)base * 9;
       const int32_t tot = nblk * 9;
@@ -208,7 +254,7 @@ __global__ __launch_bounds__(64) void k_assemble_hex(int64_t ntiles, int32_t pla
 
 // Ke (E, 8*D, 8*D) row-major for the parity tests (model.Ke_mat of the reference); thread = (element, a)
 template <int KIND, bool RHO>
-__global__ void k_element_matrices_hex(int64_t nelems, const double* __restrict__ X, const int32_t* __restrict__ conn,
+__global__ __launch_bounds__(128) void k_element_matrices_hex(int64_t nelems, const double* __restrict__ X, const int32_t* __restrict__ conn,
                                        HexParams pr, double* __restrict__ Ke, double* __restrict__ Re) {
   constexpr int V = HexV<KIND>::V;
   constexpr int D = KIND == HEX_ELASTICITY ? 3 : 1;
@@ -220,8 +266,11 @@ __global__ void k_element_matrices_hex(int64_t nelems, const double* __restrict_
   const int4 r0 = make_int4(c[0], c[1], c[2], c[3]), r1 = make_int4(c[4], c[5], c[6], c[7]);
   double cx[8], cy[8], cz[8], re[8];
   hex_load(X, RHO ? pr.rho : nullptr, r0, r1, cx, cy, cz, re);
+  double cq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cq[q] = RHO ? hex_ramp(pr.p, re, q) : 1.0;
   double v[8][V];
-  hex_rows<KIND, RHO>(pr, cx, cy, cz, re, a, v);
+  hex_rows<KIND, RHO>(pr, cx, cy, cz, cq, 1, a, v);
   constexpr int ED = 8 * D;
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
@@ -242,7 +291,7 @@ template <int KIND, bool RHO>
 int launch_hex(pf_ctx* ctx, const HexParams& pr, double* out0, double* out1) {
   constexpr int V = HexV<KIND>::V;
   const int32_t plane = ctx->npt * ctx->max_row_blocks + 1;
-  const size_t lds = ((size_t)plane * V * 8 + 15) & ~(size_t)15;
+  const size_t lds = ((size_t)std::max<int64_t>((int64_t)plane * V, RHO ? 512 : 0) * 8 + 15) & ~(size_t)15;  // RHO: 8 x 64 RAMP factors
   auto k = k_assemble_hex<KIND, RHO>;
   if (lds > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
