@@ -131,6 +131,14 @@ int pf_assemble_helmholtz3d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals
 /* kind: 0 elasticity (Ke (E,24,24)), 1 Poisson (Ke (E,8,8)), 2 Helmholtz (Ke and Re (E,8,8)); model.Ke_mat users */
 int pf_element_matrices3d(pf_ctx* ctx, int kind, double E, double nu, double p, double r0, const double* rho,
                           double* Ke_out, double* Re_out);
+/* d(phi^T K(rho) psi)/d rho (nnodes,): scalar == 0 elasticity (phi, psi of length 3 nnodes; pyfem.py:1873-1920),
+ * scalar != 0 LinearPoisson (pyfem.py:1240-1276; E, nu ignored).  Fused: Ke_deriv is never formed. */
+int pf_sens3d(pf_ctx* ctx, int scalar, double E, double nu, double p, const double* rho, const double* phi,
+              const double* psi, double* out);
+/* LinearPoisson.compute_rhs pieces on blocks: Xq (nelems, 8, 3); rhs from g at those points (nelems, 8), with the
+ * reference's transposed shape-table indexing reproduced (pyfem.py:1131-1136, 861-875) */
+int pf_quad_points3d(pf_ctx* ctx, double* Xq_out);
+int pf_poisson_rhs3d(pf_ctx* ctx, const double* gq, double* rhs_out);
 
 /* block layout -> scipy CSR data order (identity copy for d == 1) */
 int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr_data);

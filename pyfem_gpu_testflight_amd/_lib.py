@@ -40,6 +40,9 @@ SIGNATURES = {
     "pf_assemble_poisson3d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_assemble_helmholtz3d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_element_matrices3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
+    "pf_sens3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "pf_quad_points3d": (C.c_int, [_vp, _vp]),
+    "pf_poisson_rhs3d": (C.c_int, [_vp, _vp, _vp]),
     "pf_element_matrices_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_quad_points": (C.c_int, [_vp, _vp]),
     "pf_poisson_rhs": (C.c_int, [_vp, _vp, _vp]),

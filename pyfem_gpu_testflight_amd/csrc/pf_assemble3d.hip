@@ -287,6 +287,189 @@ __global__ __launch_bounds__(128) void k_element_matrices_hex(int64_t nelems, co
   }
 }
 
+// monomial coefficients of a nodal field on the trilinear element (0.125 folded in):
+//   f(xi) = m[7] + m[0] xi + m[1] eta + m[2] zeta + m[3] xi eta + m[4] eta zeta + m[5] xi zeta + m[6] xi eta zeta
+__device__ __forceinline__ void hex_monomials(const double (&f)[8], double (&m)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) m[t] = 0.0;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const double v = 0.125 * f[l];
+    m[0] += hsx(l) * v;
+    m[1] += hsy(l) * v;
+    m[2] += hsz(l) * v;
+    m[3] += hsx(l) * hsy(l) * v;
+    m[4] += hsy(l) * hsz(l) * v;
+    m[5] += hsx(l) * hsz(l) * v;
+    m[6] += hsx(l) * hsy(l) * hsz(l) * v;
+    m[7] += v;
+  }
+}
+// d f / d xi_k at (xi, eta, zeta)
+__device__ __forceinline__ void hex_dlocal(const double (&m)[8], double xi, double et, double ze, double (&d)[3]) {
+  d[0] = m[0] + m[3] * et + m[5] * ze + m[6] * (et * ze);
+  d[1] = m[1] + m[3] * xi + m[4] * ze + m[6] * (xi * ze);
+  d[2] = m[2] + m[5] * xi + m[4] * et + m[6] * (xi * et);
+}
+__device__ __forceinline__ double hex_value(const double (&m)[8], double xi, double et, double ze) {
+  return m[7] + m[0] * xi + m[1] * et + m[2] * ze + m[3] * (xi * et) + m[4] * (et * ze) + m[5] * (xi * ze) +
+         m[6] * (xi * et * ze);
+}
+// J[j][k] = d x_j / d xi_k, its determinant and inverse (utils.py:172-264)
+__device__ __forceinline__ double hex_jacobian(const double (&mx)[8], const double (&my)[8], const double (&mz)[8],
+                                               double xi, double et, double ze, double (&inv)[3][3]) {
+  double J[3][3];
+  hex_dlocal(mx, xi, et, ze, J[0]);
+  hex_dlocal(my, xi, et, ze, J[1]);
+  hex_dlocal(mz, xi, et, ze, J[2]);
+  const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+  const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const double det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+  const double rd = 1.0 / det;
+  inv[0][0] = c00 * rd;
+  inv[0][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) * rd;
+  inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+  inv[1][0] = -c01 * rd;
+  inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+  inv[1][2] = -(J[0][0] * J[1][2] - J[0][2] * J[1][0]) * rd;
+  inv[2][0] = c02 * rd;
+  inv[2][1] = -(J[0][0] * J[2][1] - J[0][1] * J[2][0]) * rd;
+  inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+  return det;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sensitivity pass on blocks: out[o] = d(phi^T K(rho) psi)/d rho_o  (pyfem.py:1873-1920 / 1240-1276 with the
+// RAMP derivative of :1948-1973 / :1303-1329).  One lane per node o, its incident elements in ascending order:
+//   inner[e,o] = sum_q detJ N_o(q) r'(rho_q) eps(phi):C0:eps(psi),  r' = (1+p)/(1+p(1-rho_q))^2.
+// Strains come from the displacement gradient U = (d phi / d xi) J^-1, with d phi / d xi from the monomial form
+// of the nodal field -- Ke_deriv (E,24,24,8) = 36 KB per element in the reference is never formed.
+// ------------------------------------------------------------------------------------------
+template <bool SCALAR>
+__global__ __launch_bounds__(64) void k_sens_hex(int64_t nnodes, const double* __restrict__ X,
+                                                 const int32_t* __restrict__ n2e_ptr, const int4* __restrict__ vis_rec,
+                                                 HexParams pr, const double* __restrict__ phi,
+                                                 const double* __restrict__ psi, double* __restrict__ out) {
+  constexpr int NF = SCALAR ? 1 : 3;
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  double acc = 0.0;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int4 r0 = vis_rec[3 * (int64_t)jj], r1 = vis_rec[3 * (int64_t)jj + 1], r2 = vis_rec[3 * (int64_t)jj + 2];
+    const int a = r2.z & 255;
+    const double sxa = ((a ^ (a >> 1)) & 1) ? 1.0 : -1.0, sya = (a & 2) ? 1.0 : -1.0, sza = (a & 4) ? 1.0 : -1.0;
+    const int32_t nd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    double mx[8], my[8], mz[8], mr[8], mf[NF][8], mg[NF][8];
+    {
+      double t0[8], t1[8], t2[8], t3[8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const double* xp = X + 3 * (int64_t)nd[l];
+        t0[l] = xp[0]; t1[l] = xp[1]; t2[l] = xp[2]; t3[l] = pr.rho[nd[l]];
+      }
+      hex_monomials(t0, mx); hex_monomials(t1, my); hex_monomials(t2, mz); hex_monomials(t3, mr);
+#pragma unroll
+      for (int c = 0; c < NF; ++c) {
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { t0[l] = phi[NF * (int64_t)nd[l] + c]; t1[l] = psi[NF * (int64_t)nd[l] + c]; }
+        hex_monomials(t0, mf[c]); hex_monomials(t1, mg[c]);
+      }
+    }
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+      const double xi = (q & 4) ? G3 : -G3, et = (q & 2) ? G3 : -G3, ze = (q & 1) ? G3 : -G3;
+      double inv[3][3];
+      const double det = hex_jacobian(mx, my, mz, xi, et, ze, inv);
+      const double rq = hex_value(mr, xi, et, ze);
+      const double t = 1.0 + pr.p * (1.0 - rq);
+      const double dr = (1.0 + pr.p) / (t * t);
+      const double Na = 0.125 * (1.0 + sxa * xi) * (1.0 + sya * et) * (1.0 + sza * ze);
+      double U[NF][3], W[NF][3];  // U[i][j] = d phi_i / d x_j
+#pragma unroll
+      for (int c = 0; c < NF; ++c) {
+        double df[3], dg[3];
+        hex_dlocal(mf[c], xi, et, ze, df);
+        hex_dlocal(mg[c], xi, et, ze, dg);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          U[c][j] = df[0] * inv[0][j] + df[1] * inv[1][j] + df[2] * inv[2][j];
+          W[c][j] = dg[0] * inv[0][j] + dg[1] * inv[1][j] + dg[2] * inv[2][j];
+        }
+      }
+      double eCe;
+      if constexpr (SCALAR) {
+        eCe = U[0][0] * W[0][0] + U[0][1] * W[0][1] + U[0][2] * W[0][2];
+      } else {  // strain order xx,yy,zz,xy,yz,xz with engineering shear (pyfem.py:1999-2011)
+        const double tu = U[0][0] + U[1][1] + U[2][2], tw = W[0][0] + W[1][1] + W[2][2];
+        eCe = pr.lam * tu * tw + 2.0 * pr.mu * (U[0][0] * W[0][0] + U[1][1] * W[1][1] + U[2][2] * W[2][2]) +
+              pr.mu * ((U[0][1] + U[1][0]) * (W[0][1] + W[1][0]) + (U[1][2] + U[2][1]) * (W[1][2] + W[2][1]) +
+                       (U[0][2] + U[2][0]) * (W[0][2] + W[2][0]));
+      }
+      acc += det * dr * Na * eCe;
+    }
+  }
+  out[n] = acc;
+}
+
+// Xq[e,q,:] = sum_l N[q,l] X[conn[e,l],:]: where LinearPoisson evaluates its Python source term (pyfem.py:1138-1173)
+__global__ void k_quad_points_hex(int64_t nelems, const double* __restrict__ X, const int32_t* __restrict__ conn,
+                                  double* __restrict__ Xq) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nelems * 8) return;
+  const int64_t e = i >> 3;
+  const int q = (int)(i & 7);
+  const double xi = (q & 4) ? G3 : -G3, et = (q & 2) ? G3 : -G3, ze = (q & 1) ? G3 : -G3;
+  double s[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const double N = 0.125 * (1.0 + hsx(l) * xi) * (1.0 + hsy(l) * et) * (1.0 + hsz(l) * ze);
+    const double* xp = X + 3 * (int64_t)conn[e * 8 + l];
+    s[0] += N * xp[0]; s[1] += N * xp[1]; s[2] += N * xp[2];
+  }
+  Xq[3 * i + 0] = s[0]; Xq[3 * i + 1] = s[1]; Xq[3 * i + 2] = s[2];
+}
+
+// LinearPoisson load vector WITH the reference's indexing (pyfem.py:1131-1136, 861-875):
+//   rhs_e[e,j] = sum_k detJ[e,k] w_k N[j,k] g[e,k]   where N[j,k] = shape function of node k at quadrature point j
+// (the table is indexed [point, node] but contracted as if it were [node, point]; harmless on 2-D quads where the
+// table is symmetric, not here), scattered for all 8 columns since nquads == 8.  Reproduced as is; lane = node.
+__global__ __launch_bounds__(64) void k_poisson_rhs_hex(int64_t nnodes, const double* __restrict__ X,
+                                                        const int32_t* __restrict__ n2e_ptr,
+                                                        const int4* __restrict__ vis_rec, const int32_t* __restrict__ n2e,
+                                                        const double* __restrict__ gq, double* __restrict__ rhs) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  double acc = 0.0;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int4 r0 = vis_rec[3 * (int64_t)jj], r1 = vis_rec[3 * (int64_t)jj + 1], r2 = vis_rec[3 * (int64_t)jj + 2];
+    const int a = r2.z & 255;
+    const int64_t e = n2e[jj] >> 3;
+    const int32_t nd[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    double mx[8], my[8], mz[8];
+    {
+      double t0[8], t1[8], t2[8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const double* xp = X + 3 * (int64_t)nd[l];
+        t0[l] = xp[0]; t1[l] = xp[1]; t2[l] = xp[2];
+      }
+      hex_monomials(t0, mx); hex_monomials(t1, my); hex_monomials(t2, mz);
+    }
+    // "quadrature point a" of the transposed table
+    const double xa = (a & 4) ? G3 : -G3, ea = (a & 2) ? G3 : -G3, za = (a & 1) ? G3 : -G3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double xi = (k & 4) ? G3 : -G3, et = (k & 2) ? G3 : -G3, ze = (k & 1) ? G3 : -G3;
+      double inv[3][3];
+      const double det = hex_jacobian(mx, my, mz, xi, et, ze, inv);
+      const double Nk_at_a = 0.125 * (1.0 + hsx(k) * xa) * (1.0 + hsy(k) * ea) * (1.0 + hsz(k) * za);
+      acc += det * Nk_at_a * gq[8 * e + k];
+    }
+  }
+  rhs[n] = acc;
+}
+
 template <int KIND, bool RHO>
 int launch_hex(pf_ctx* ctx, const HexParams& pr, double* out0, double* out1) {
   constexpr int V = HexV<KIND>::V;
@@ -368,6 +551,34 @@ extern "C" int pf_element_matrices3d(pf_ctx* ctx, int kind, double E, double nu,
   } else {
     return pf_fail(ctx, PF_E_INVALID, "pf_element_matrices3d: kind must be 0 (elasticity), 1 (Poisson) or 2 (Helmholtz)");
   }
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_sens3d(pf_ctx* ctx, int scalar, double E, double nu, double p, const double* rho, const double* phi,
+                         const double* psi, double* out) {
+  if (int rc = check3d(ctx, scalar ? 1 : 3, "pf_sens3d")) return rc;
+  PF_REQUIRE(rho && phi && psi && out, "pf_sens3d: NULL argument");
+  const HexParams pr = lame(E, nu, p, rho);
+  const unsigned grid = (unsigned)cdiv(ctx->nnodes, 64);
+  if (scalar) k_sens_hex<true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
+  else k_sens_hex<false><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), pr, phi, psi, out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_quad_points3d(pf_ctx* ctx, double* Xq_out) {
+  if (int rc = check3d(ctx, 0, "pf_quad_points3d")) return rc;
+  PF_REQUIRE(Xq_out, "pf_quad_points3d: NULL output");
+  k_quad_points_hex<<<(unsigned)cdiv(ctx->nelems * 8, 256), 256, 0, ctx->stream>>>(ctx->nelems, ctx->X, ctx->conn, Xq_out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_poisson_rhs3d(pf_ctx* ctx, const double* gq, double* rhs_out) {
+  if (int rc = check3d(ctx, 1, "pf_poisson_rhs3d")) return rc;
+  PF_REQUIRE(gq && rhs_out, "pf_poisson_rhs3d: NULL argument");
+  k_poisson_rhs_hex<<<(unsigned)cdiv(ctx->nnodes, 64), 64, 0, ctx->stream>>>(ctx->nnodes, ctx->X, ctx->n2e_ptr, reinterpret_cast<const int4*>(ctx->vis_rec), ctx->n2e, gq, rhs_out);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

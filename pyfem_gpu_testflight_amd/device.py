@@ -125,7 +125,10 @@ class HipContext:
     def sens_elasticity(self, E, nu, p, rho, phi, psi):
         out = self.empty(self.nnodes)
         self._sync_stream()
-        self._call("pf_sens_elasticity2d", E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        if self.ndims == 3:
+            self._call("pf_sens3d", 0, E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        else:
+            self._call("pf_sens_elasticity2d", E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
         return out
 
     def assemble_poisson(self, p, rho=None, out=None):
@@ -144,22 +147,25 @@ class HipContext:
         return out.view(self.nelems, self.P, self.P)
 
     def quad_points(self):
-        Q = 4 if self.P == 4 else 1
-        out = self.empty(self.nelems * Q * 2)
+        Q = {3: 1, 4: 4, 8: 8}[self.P]
+        out = self.empty(self.nelems * Q * self.ndims)
         self._sync_stream()
-        self._call("pf_quad_points", _ptr(out))
-        return out.view(self.nelems, Q, 2)
+        self._call("pf_quad_points" if self.ndims == 2 else "pf_quad_points3d", _ptr(out))
+        return out.view(self.nelems, Q, self.ndims)
 
     def poisson_rhs(self, gq):
         out = self.empty(self.nnodes)
         self._sync_stream()
-        self._call("pf_poisson_rhs", _ptr(gq), _ptr(out))
+        self._call("pf_poisson_rhs" if self.ndims == 2 else "pf_poisson_rhs3d", _ptr(gq), _ptr(out))
         return out
 
     def sens_poisson(self, p, rho, phi, psi):
         out = self.empty(self.nnodes)
         self._sync_stream()
-        self._call("pf_sens_poisson2d", p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        if self.ndims == 3:
+            self._call("pf_sens3d", 1, 0.0, 0.0, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        else:
+            self._call("pf_sens_poisson2d", p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
         return out
 
     def element_matrices_elasticity(self, E, nu, p, rho=None):

@@ -260,8 +260,6 @@ class LinearPoisson(ModelBase):
     def compute_rhs(self):
         """ref: pyfem.py:997-1004, 1138-1173."""
         torch = self.hctx.torch
-        if self.ndims == 3:
-            raise NotImplementedError("accelerated path: the 3-D element load vector is not built yet (K is)")
         Xq = self.hctx.quad_points().cpu().numpy()
         self.fun_vals = np.asarray(self.gfunc(Xq), dtype=float)
         gq = self.hctx.to_device(np.ascontiguousarray(self.fun_vals), torch.float64)
@@ -317,8 +315,6 @@ class LinearPoisson(ModelBase):
     def _compute_K_dv_sens(self, rho, phi, psi):
         """ref: pyfem.py:1240-1276, fused (no Ke_deriv tensor)."""
         torch = self.hctx.torch
-        if self.ndims == 3:
-            raise NotImplementedError("accelerated path: 3-D sensitivities are not built yet")
         if not hasattr(rho, "__len__"):
             rho = np.ones(self.nnodes) * rho
         rho_d = self._rho_device(rho)

@@ -494,19 +494,30 @@ def test_block_helmholtz(pf, orc):
 def test_block_poisson_K(pf, orc):
     g = load("poi3d_5x4x3_block")
     q, b = _qb(pf, "block")
-    model = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], g["fixed_vals"], q, b, lambda x: 0.0 * x[..., 0],
-                             p=float(g["p"]))
+    model = pf.LinearPoisson(g["X"], g["conn"], g["dof_fixed"], g["fixed_vals"], q, b,
+                             lambda x: x[..., 0] * (x[..., 1] - 2.0) + x[..., 2], p=float(g["p"]))
     K = model.compute_jacobian(g["rho"])
     Ks, ref = K.to_scipy(), csr_of(g, "K", g["X"].shape[0])
     assert np.array_equal(Ks.indptr, ref.indptr) and np.array_equal(Ks.indices, ref.indices)
     assert np.abs(Ks.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
     assert np.abs(model.Ke_mat[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
-    # Dirichlet values + solve against the reference's u, with the reference's own rhs vector
-    rhs = g["rhs"].copy()
+    # load vector with the reference's transposed table indexing, Dirichlet values, solve
+    rhs = model.compute_rhs()
+    assert relmax(rhs, g["rhs"]) < K_TOL
     K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
     assert relmax(rhs, g["rhs_bc"]) < 1e-12
     u = pf.Assembler(model)._solve_linear_system(K, rhs, "cg")
     assert relmax(u, g["u"]) < U_TOL
+    assert relmax(model._compute_K_dv_sens(g["rho"], g["phi"], g["psi"]), g["sens"]) < K_TOL
+
+
+def test_block_sensitivity(pf):
+    g = load("sens3d_5x4x4_block")
+    q, b = _qb(pf, "block")
+    conn, X = g["conn"], g["X"]
+    model = pf.LinearElasticity(X, conn, [0, 1, 2], None, {1: [0.0, -1.0, 0.0]}, q, b, p=float(g["p"]))
+    assert relmax(model._compute_K_dv_sens(g["rho"], g["phi"], g["psi"]), g["sens"]) < K_TOL
+    assert relmax(model.compliance_grad(g["rho"], g["u"]), g["compliance_grad"]) < K_TOL
 
 
 @pytest.mark.parametrize("shape", [(2, 2, 2), (3, 2, 2), (9, 9, 2), (17, 3, 5), (6, 13, 7)])
