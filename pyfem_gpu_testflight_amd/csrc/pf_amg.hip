@@ -9,14 +9,15 @@
 //   * per matrix, on the device: Galerkin coarse operators A_c = P^T A P by an owner-computes gather
 //     (one lane per coarse row, no atomics), with the tentative prolongator built from the near-null
 //     space: the constant for scalar problems, the three rigid-body modes (two translations and the
-//     in-plane rotation about the aggregate centroid) for plane elasticity -> 3 x 3 coarse blocks;
+//     in-plane rotation about the aggregate centroid) for plane elasticity -> 3 x 3 coarse blocks, the six
+//     rigid-body modes (translations + rotations about the centroid) for 3-D elasticity -> 6 x 6 blocks;
 //     dofs whose row is decoupled (Dirichlet rows after apply_dirichlet_bcs) are kept out of P and are
 //     solved exactly by the smoother;
 //   * V(2,2) cycle with damped Jacobi, omega = 4/(3*1.1*lambda_max(D^-1 A)) with lambda_max from ten
 //     device power iterations per level (invariant under the scaling of individual dofs, unlike a
 //     Gershgorin row sum: translations and rotations have different units on the coarse levels), the
 //     coarse correction scaled by 2 (plain aggregation under-corrects), dense inverse on the coarsest
-//     level (<= 384 dofs).
+//     level (<= 160 dofs).
 // The cycle is a fixed symmetric positive definite operator, so it is a valid CG preconditioner.
 // Plain (unsmoothed) aggregation is used in this round; smoothing the prolongator is the next step.
 #include <stdlib.h>
@@ -39,7 +40,7 @@ struct AmgLevel {
   double* vals = nullptr;    // block values (level 0: the caller's matrix, not owned)
   double* dinv = nullptr;    // omega / diag per dof
   uint8_t* iso = nullptr;    // 1 = decoupled dof (row has no off-diagonal entries)
-  double* xy = nullptr;      // node coordinates (n,2) (level 0 aliases ctx->X)
+  double* xy = nullptr;      // node coordinates (n,dim) (level 0 aliases ctx->X)
   bool owns_xy = false;
   // transfer to the next level
   int64_t nc = 0;            // number of aggregates
@@ -53,6 +54,8 @@ struct AmgLevel {
 
 struct pf_amg {
   int nlevels = 0;
+  int dim = 2;                  // stride of the coordinate arrays; 3 only for 3-D elasticity (scalar problems never
+                                // read coordinates, so they run the dim = 2 code on any mesh)
   AmgLevel L[AMG_MAX_LEVELS];
   double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
   int64_t dense_m = 0;
@@ -167,45 +170,55 @@ __global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ lam2, dou
   if (i < n) d[i] = (iso[i] ? 1.0 : omega) / d[i];  // decoupled dofs are solved exactly
 }
 
-// tentative prolongator row block P_n (DR x DC) for node n of an aggregate with centroid (cx, cy)
-template <int DR, int DC>
-__device__ __forceinline__ void amg_P(double dx, double dy, const uint8_t* iso_n, double Pn[DR][DC]) {
+// tentative prolongator row block P_n (DR x DC) for node n at offset r from its aggregate's centroid
+template <int DIM, int DR, int DC>
+__device__ __forceinline__ void amg_P(const double* __restrict__ xn, const double* __restrict__ xc, const uint8_t* iso_n,
+                                      double Pn[DR][DC]) {
   if constexpr (DR == 1) {
     Pn[0][0] = iso_n[0] ? 0.0 : 1.0;
-  } else if constexpr (DR == 2) {  // [I2 | rotation about the centroid]
+  } else if constexpr (DIM == 2) {
+    const double dx = xn[0] - xc[0], dy = xn[1] - xc[1];
+    // DR == 2: [I2 | rotation about the centroid];  DR == 3: rigid-body modes of a (ux, uy, theta) node
     Pn[0][0] = 1.0; Pn[0][1] = 0.0; Pn[0][2] = -dy;
     Pn[1][0] = 0.0; Pn[1][1] = 1.0; Pn[1][2] = dx;
+    if constexpr (DR == 3) { Pn[2][0] = 0.0; Pn[2][1] = 0.0; Pn[2][2] = 1.0; }
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < DR; ++k)
       if (iso_n[k]) { Pn[k][0] = Pn[k][1] = Pn[k][2] = 0.0; }
-  } else {  // rigid-body modes of a 3-dof node (ux, uy, theta)
-    Pn[0][0] = 1.0; Pn[0][1] = 0.0; Pn[0][2] = -dy;
-    Pn[1][0] = 0.0; Pn[1][1] = 1.0; Pn[1][2] = dx;
-    Pn[2][0] = 0.0; Pn[2][1] = 0.0; Pn[2][2] = 1.0;
+  } else {
+    // 3-D: u = t + w x r.  DR == 3: [I3 | R(r)];  DR == 6 (t, w nodes): [[I3, R(r)], [0, I3]]
+    const double rx = xn[0] - xc[0], ry = xn[1] - xc[1], rz = xn[2] - xc[2];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (iso_n[k]) { Pn[k][0] = Pn[k][1] = Pn[k][2] = 0.0; }
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) Pn[r][c] = (r == c) ? 1.0 : 0.0;
+    Pn[0][4] = rz;  Pn[0][5] = -ry;
+    Pn[1][3] = -rz; Pn[1][5] = rx;
+    Pn[2][3] = ry;  Pn[2][4] = -rx;
+#pragma unroll
+    for (int k = 0; k < DR; ++k)
+      if (iso_n[k]) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) Pn[k][c] = 0.0;
+      }
   }
 }
 
 // coarse coordinates = centroid of the members
-__global__ void k_amg_centroids(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
+__global__ void k_amg_centroids(int64_t nc, int dim, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
                                 const double* __restrict__ xy, double* __restrict__ cxy) {
   const int64_t a = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (a >= nc) return;
-  double sx = 0.0, sy = 0.0;
+  double s[3] = {0.0, 0.0, 0.0};
   const int32_t b = aptr[a], e = aptr[a + 1];
-  for (int32_t k = b; k < e; ++k) {
-    sx += xy[2 * (int64_t)amem[k]];
-    sy += xy[2 * (int64_t)amem[k] + 1];
-  }
+  for (int32_t k = b; k < e; ++k)
+    for (int c = 0; c < dim; ++c) s[c] += xy[dim * (int64_t)amem[k] + c];
   const double inv = 1.0 / (double)max(e - b, 1);
-  cxy[2 * a] = sx * inv;
-  cxy[2 * a + 1] = sy * inv;
+  for (int c = 0; c < dim; ++c) cxy[dim * a + c] = s[c] * inv;
 }
 
 // Galerkin product, one lane per coarse row I:  C[I,J] = sum_{n in I} sum_{m in J} P_n^T A[n,m] P_m
-template <int DR, int DC>
+template <int DIM, int DR, int DC>
 __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
                                const int32_t* __restrict__ agg, const int32_t* __restrict__ ptr,
                                const int32_t* __restrict__ idx, const double* __restrict__ vals,
@@ -216,16 +229,15 @@ __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, con
   if (I >= nc) return;
   const int32_t cb = cptr[I], ce = cptr[I + 1];
   for (int64_t q = (int64_t)cb * DC * DC; q < (int64_t)ce * DC * DC; ++q) cvals[q] = 0.0;
-  const double cxI = cxy[2 * I], cyI = cxy[2 * I + 1];
   for (int32_t k = aptr[I]; k < aptr[I + 1]; ++k) {
     const int64_t n = amem[k];
     double Pn[DR][DC];
-    amg_P<DR, DC>(xy[2 * n] - cxI, xy[2 * n + 1] - cyI, iso + DR * n, Pn);
+    amg_P<DIM, DR, DC>(xy + DIM * n, cxy + DIM * I, iso + DR * n, Pn);
     for (int32_t g = ptr[n]; g < ptr[n + 1]; ++g) {
       const int64_t m = idx[g];
       const int32_t J = agg[m];
       double Pm[DR][DC];
-      amg_P<DR, DC>(xy[2 * m] - cxy[2 * (int64_t)J], xy[2 * m + 1] - cxy[2 * (int64_t)J + 1], iso + DR * m, Pm);
+      amg_P<DIM, DR, DC>(xy + DIM * m, cxy + DIM * (int64_t)J, iso + DR * m, Pm);
       const double* a = vals + (int64_t)g * DR * DR;
       double AP[DR][DC];  // A[n,m] P_m
 #pragma unroll
@@ -319,7 +331,7 @@ __global__ void k_amg_jacobi0(int64_t n, const double* __restrict__ dinv, const 
     x[i] = dinv[i] * b[i];
 }
 // coarse rhs: bc_I = sum_{n in I} P_n^T res_n
-template <int DR, int DC>
+template <int DIM, int DR, int DC>
 __global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, const int32_t* __restrict__ amem,
                                const uint8_t* __restrict__ iso, const double* __restrict__ xy,
                                const double* __restrict__ cxy, const double* __restrict__ resid,
@@ -329,11 +341,10 @@ __global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, con
   double s[DC];
 #pragma unroll
   for (int c = 0; c < DC; ++c) s[c] = 0.0;
-  const double cx = cxy[2 * I], cy = cxy[2 * I + 1];
   for (int32_t k = aptr[I]; k < aptr[I + 1]; ++k) {
     const int64_t n = amem[k];
     double Pn[DR][DC];
-    amg_P<DR, DC>(xy[2 * n] - cx, xy[2 * n + 1] - cy, iso + DR * n, Pn);
+    amg_P<DIM, DR, DC>(xy + DIM * n, cxy + DIM * I, iso + DR * n, Pn);
 #pragma unroll
     for (int r = 0; r < DR; ++r) {
       const double res = resid[DR * n + r];
@@ -346,7 +357,7 @@ __global__ void k_amg_restrict(int64_t nc, const int32_t* __restrict__ aptr, con
 }
 
 // x_n += P_n e_{agg[n]}
-template <int DR, int DC>
+template <int DIM, int DR, int DC>
 __global__ void k_amg_prolong(int64_t n, const int32_t* __restrict__ agg, const uint8_t* __restrict__ iso,
                               const double* __restrict__ xy, const double* __restrict__ cxy,
                               const double* __restrict__ ec, double* __restrict__ x, double over) {
@@ -354,7 +365,7 @@ __global__ void k_amg_prolong(int64_t n, const int32_t* __restrict__ agg, const 
   if (i >= n) return;
   const int64_t I = agg[i];
   double Pn[DR][DC];
-  amg_P<DR, DC>(xy[2 * i] - cxy[2 * I], xy[2 * i + 1] - cxy[2 * I + 1], iso + DR * i, Pn);
+  amg_P<DIM, DR, DC>(xy + DIM * i, cxy + DIM * I, iso + DR * i, Pn);
 #pragma unroll
   for (int r = 0; r < DR; ++r) {
     double s = 0.0;
@@ -451,7 +462,9 @@ static int to_device(pf_ctx* ctx, const std::vector<T>& h, T*& d) {
 static int amg_build_hierarchy(pf_ctx* ctx) {
   pf_amg* H = new pf_amg();
   ctx->amg = H;
-  const int d0 = ctx->d, dc = (d0 == 2) ? 3 : 1;
+  const int d0 = ctx->d;
+  H->dim = (ctx->ndims == 3 && d0 == 3) ? 3 : 2;
+  const int dc = (d0 == 1) ? 1 : (H->dim == 3) ? 6 : 3;
   std::vector<int32_t> ptr(ctx->nnodes + 1), idx(ctx->nblocks);
   PF_HIP(hipMemcpyAsync(ptr.data(), ctx->nptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipMemcpyAsync(idx.data(), ctx->nidx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -487,8 +500,8 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     if (rc == PF_OK) rc = to_device(ctx, cptr, Nx.ptr);
     if (rc == PF_OK) rc = to_device(ctx, cidx, Nx.idx);
     if (rc) return rc;
-    PF_HIP(hipMalloc(&Nx.xy, sizeof(double) * 2 * nc));
-    k_amg_centroids<<<(unsigned)cdiv(nc, 256), 256, 0, ctx->stream>>>(nc, Lv.aptr, Lv.amem, Lv.xy, Nx.xy);
+    PF_HIP(hipMalloc(&Nx.xy, sizeof(double) * H->dim * nc));
+    k_amg_centroids<<<(unsigned)cdiv(nc, 256), 256, 0, ctx->stream>>>(nc, H->dim, Lv.aptr, Lv.amem, Lv.xy, Nx.xy);
     PF_LAUNCH_CHECK();
     PF_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
     ptr.swap(cptr);
@@ -517,7 +530,7 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
   }
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
 #define PF_AS(D_, M_) k_amg_spmv<D_, M_><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, Lv.dinv, b)
-#define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else PF_AS(3, M_); } while (0)
+#define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
   if (mode == AMG_AX) PF_ASD(AMG_AX);
   else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
   else if (mode == AMG_RESID) PF_ASD(AMG_RESID);
@@ -569,7 +582,6 @@ static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, dou
 // the previous call is kept if it was made for the same value array (the caller asserts the values are
 // unchanged, e.g. the constant Helmholtz filter matrix).
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
-  if (ctx->d == 3) return PF_E_UNSUPPORTED;  // 3-D elasticity needs six rigid-body modes per aggregate: Jacobi for now
   if (!ctx->amg) {
     int rc = amg_build_hierarchy(ctx);
     if (rc) { pf_amg_free(ctx); return rc; }
@@ -588,17 +600,20 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     const unsigned gr = (unsigned)cdiv(Lv.n, 256);
     if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
     else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
+    else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
     else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
     PF_LAUNCH_CHECK();
     if (l + 1 == H->nlevels) break;
     AmgLevel& Nx = H->L[l + 1];
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
-#define PF_GAL(DR_, DC_)                                                                                      \
-    k_amg_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
-                                                         Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
-    if (Lv.dr == 1) PF_GAL(1, 1);
-    else if (Lv.dr == 2) PF_GAL(2, 3);
-    else PF_GAL(3, 3);
+#define PF_GAL(DIM_, DR_, DC_)                                                                                \
+    k_amg_galerkin<DIM_, DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
+                                                               Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
+    if (Lv.dr == 1) PF_GAL(2, 1, 1);
+    else if (H->dim == 3 && Lv.dr == 3) PF_GAL(3, 3, 6);
+    else if (H->dim == 3) PF_GAL(3, 6, 6);
+    else if (Lv.dr == 2) PF_GAL(2, 2, 3);
+    else PF_GAL(2, 3, 3);
 #undef PF_GAL
     PF_LAUNCH_CHECK();
   }
@@ -616,6 +631,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     PF_HIP(hipMemsetAsync(H->dense_inv, 0, sizeof(double) * H->dense_m * H->dense_m, ctx->stream));
     const unsigned g = (unsigned)cdiv(C.n, 128);
     if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    else if (C.dr == 6) k_amg_to_dense<6><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
     else k_amg_to_dense<3><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
     k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
     PF_LAUNCH_CHECK();
@@ -669,9 +685,11 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     }
     if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
-    if (Lv.dr == 1) k_amg_restrict<1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else if (Lv.dr == 2) k_amg_restrict<2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else k_amg_restrict<3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    if (Lv.dr == 1) k_amg_restrict<2, 1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else if (H->dim == 3 && Lv.dr == 3) k_amg_restrict<3, 3, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else if (H->dim == 3) k_amg_restrict<3, 6, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else if (Lv.dr == 2) k_amg_restrict<2, 2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    else k_amg_restrict<2, 3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
     PF_LAUNCH_CHECK();
     cur[l] = c;
     oth[l] = o;
@@ -703,9 +721,11 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     double* c = cur[l];
     double* o = oth[l];
     const unsigned g = (unsigned)cdiv(Lv.n, 256);
-    if (Lv.dr == 1) k_amg_prolong<1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else if (Lv.dr == 2) k_amg_prolong<2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else k_amg_prolong<3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    if (Lv.dr == 1) k_amg_prolong<2, 1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else if (H->dim == 3 && Lv.dr == 3) k_amg_prolong<3, 3, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    else k_amg_prolong<2, 3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
     for (int s = 0; s < H->nsmooth; ++s) {
       if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
       std::swap(c, o);

@@ -26,6 +26,17 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 96, 128]:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     _, it, _ = h.cg(K.vals, rhs, rtol=0.0, maxiter=200, check_every=200, allow_maxiter=True)
     torch.cuda.synchronize(); t_cg = time.perf_counter() - t0
+    solve = {}
+    for name, pc in (("amg", _lib.PF_PRECOND_AMG), ("jacobi", _lib.PF_PRECOND_JACOBI)):
+        if name == "jacobi" and n > 96:
+            continue
+        h.cg(K.vals, rhs, rtol=1e-1, precond=pc)  # hierarchy / kernels warm
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, its, rr = h.cg(K.vals, rhs, rtol=1e-8, precond=pc)
+        torch.cuda.synchronize()
+        solve[name] = {"iters": its, "s": time.perf_counter() - t0}
+    if "amg" in solve:
+        solve["amg_levels"] = h.amg_info()
     b_asm = 4 * 8 * h.nelems + 24 * h.nnodes + 8 * h.nnz
     b_spmv = 8 * h.nnz + 4 * h.nblocks + 52 * h.nnodes
     print(json.dumps({"n": n, "nelems": h.nelems, "ndof": h.nrows, "nnz": h.nnz, "setup_s": t_setup,
@@ -33,6 +44,6 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 96, 128]:
                       "assemble_GBps_algorithmic": b_asm / ms_asm / 1e6, "assemble_rho_ms": ms_asm_rho,
                       "fp64_TFLOPs_useful": h.nelems * 8 * 2 * 2000 / ms_asm / 1e9,
                       "spmv_ms": ms_spmv, "spmv_GBps_algorithmic": b_spmv / ms_spmv / 1e6,
-                      "cg_iter_per_s": it / t_cg}), flush=True)
+                      "cg_iter_per_s": it / t_cg, "solve_rtol1e-8": solve}), flush=True)
     del m, K, h
     torch.cuda.empty_cache()
