@@ -31,11 +31,32 @@ import numpy as np
 # ------------------------------------------------------------------------------------------
 # partition
 # ------------------------------------------------------------------------------------------
-class ElementBlockPartition:
-    """Element-block partition of (conn, nnodes) for `world` ranks, seen from `rank`."""
+def centroid_element_order(X, conn):
+    """Permutation that sorts elements along a Morton (Z-order) curve of their centroids.  Element-index blocks
+    are compact strips on ProblemCreator meshes; on unstructured or renumbered meshes (arm.inp, C4) contiguous
+    index ranges can be scattered all over the domain, and sorting by centroid first restores compact
+    blocks with short interfaces.  Stable, so a mesh that is already ordered keeps its order inside a cell."""
+    X = np.asarray(X, dtype=float)
+    c = X[np.asarray(conn)].mean(axis=1)
+    lo, hi = c.min(axis=0), c.max(axis=0)
+    q = ((c - lo) / np.where(hi > lo, hi - lo, 1.0) * 1023.0).astype(np.uint64)  # 10 bits per axis
+    code = np.zeros(c.shape[0], dtype=np.uint64)
+    nd = c.shape[1]
+    for bit in range(10):
+        for ax in range(nd):
+            code |= ((q[:, ax] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(bit * nd + ax)
+    return np.argsort(code, kind="stable")
 
-    def __init__(self, conn, nnodes, world, rank, ndof_per_node):
+
+class ElementBlockPartition:
+    """Element-block partition of (conn, nnodes) for `world` ranks, seen from `rank`.
+    elem_perm: optional element permutation applied before cutting the blocks (centroid_element_order)."""
+
+    def __init__(self, conn, nnodes, world, rank, ndof_per_node, elem_perm=None):
         conn = np.asarray(conn)
+        if elem_perm is not None:
+            conn = conn[np.asarray(elem_perm)]
+        self.elem_perm = elem_perm
         E = conn.shape[0]
         if E < world:
             raise ValueError("fewer elements than ranks")
@@ -223,7 +244,7 @@ class PartitionedElasticity:
     returns the local solution and `gather_global` assembles the global vector on every rank."""
 
     def __init__(self, X, conn, dof_fixed, dof_fixed_vals, nodal_force, quadrature, basis, E=10.0, nu=0.3, p=0.0,
-                 group=None, rank=None, world=None, device=None):
+                 group=None, rank=None, world=None, device=None, elem_order="index"):
         import torch.distributed as dist
 
         from . import pyfem
@@ -234,7 +255,10 @@ class PartitionedElasticity:
         self.group, self.rank, self.world = group, rank, world
         X = np.asarray(X, dtype=float)
         self.nnodes_global = X.shape[0]
-        self.part = ElementBlockPartition(conn, X.shape[0], world, rank, 2)
+        if elem_order not in ("index", "centroid"):
+            raise ValueError("elem_order must be 'index' (contiguous element-index blocks) or 'centroid'")
+        perm = centroid_element_order(X, conn) if elem_order == "centroid" else None
+        self.part = ElementBlockPartition(conn, X.shape[0], world, rank, 2, elem_perm=perm)
         pt = self.part
         fixed_local, present = pt.local_dofs_of(dof_fixed)
         vals_local = None if dof_fixed_vals is None else np.asarray(dof_fixed_vals, dtype=float)[present]

@@ -129,3 +129,29 @@ def test_partition_single_rank_is_identity():
     part = ElementBlockPartition(conn, X.shape[0], 1, 0, 2)
     assert part.n_iface_dofs == 0 and np.array_equal(part.conn_local, conn)
     assert np.array_equal(part.nodes, np.arange(X.shape[0])) and part.own_weight.min() == 1.0
+
+
+def test_centroid_order_shortens_interfaces_of_shuffled_meshes():
+    """sort elements by centroid before cutting blocks when element ids carry no locality."""
+    from oracle import pyfem_oracle as orc
+    from pyfem_gpu_testflight_amd.dist import ElementBlockPartition, centroid_element_order
+
+    conn, X = orc.structured_mesh(41, 33, "tri")
+    rng = np.random.RandomState(5)
+    conn = conn[rng.permutation(conn.shape[0])]
+    perm = centroid_element_order(X, conn)
+    assert np.array_equal(np.sort(perm), np.arange(conn.shape[0]))
+    world = 4
+    g_index = ElementBlockPartition(conn, X.shape[0], world, 0, 2).n_iface_dofs
+    parts = [ElementBlockPartition(conn, X.shape[0], world, r, 2, elem_perm=perm) for r in range(world)]
+    g_centroid = parts[0].n_iface_dofs
+    assert g_centroid * 5 < g_index, (g_centroid, g_index)
+    # still a partition: every element exactly once, local meshes consistent with the global one
+    seen = np.concatenate([perm[p.elem_range[0]:p.elem_range[1]] for p in parts])
+    assert np.array_equal(np.sort(seen), np.arange(conn.shape[0]))
+    for p in parts:
+        assert np.array_equal(p.nodes[p.conn_local], conn[perm][p.elem_range[0]:p.elem_range[1]])
+    # a structured mesh keeps strip-like blocks under either order (no regression for ProblemCreator meshes)
+    conn2, X2 = orc.structured_mesh(33, 33, "quad")
+    assert ElementBlockPartition(conn2, X2.shape[0], 4, 1, 2, elem_perm=centroid_element_order(X2, conn2)).n_iface_dofs \
+        <= 3 * ElementBlockPartition(conn2, X2.shape[0], 4, 1, 2).n_iface_dofs
