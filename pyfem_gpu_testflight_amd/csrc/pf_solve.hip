@@ -207,17 +207,21 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // d = 3 (3-D elasticity): 3x3 blocks, 72 B of values + 4 B of index per block.  One persistent wave per
-// 64-node tile; lanes stream the tile's contiguous block range (block g: nine coalesced doubles per lane
-// are 72-byte strided, so the nine loads of a wave cover the same 4.6 KB -- every line is used fully),
-// park the 3-vector product in an LDS strip, then lane-per-node sums its row.  Same epilogues as k_spmv.
+// 64-node tile.  The tile's contiguous block range is streamed 64 blocks at a time: the 4.6 KB of values
+// are copied to an LDS staging strip with nine fully coalesced 512-byte wave loads (a lane reading "its"
+// block directly would make every load instruction touch 36 different lines), each lane then reads its
+// block back at a stride of 9 doubles (odd: conflict-free), multiplies by the gathered x and parks the
+// 3-vector product in the strip; lane-per-node sums its row.  One wave per block: LDS operations execute in
+// program order, so the staging needs no barrier.  Same epilogues as k_spmv.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __restrict__ nptr,
                                               const int32_t* __restrict__ nidx, const double* __restrict__ vals,
                                               const double* __restrict__ x, double* __restrict__ y,
                                               double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
                                               const double* __restrict__ sm_b) {
-  constexpr int CH = 512;
+  constexpr int CH = 384, U = 3;
   __shared__ double prod[3 * CH];
+  __shared__ double stage[64 * 9];
   const int lane = threadIdx.x;
   double dacc = 0.0;
   const int64_t ntiles = (nnodes + 63) / 64;
@@ -230,21 +234,47 @@ __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __r
     double acc[3] = {0.0, 0.0, 0.0};
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
-      for (int32_t g = c0 + lane; g < c1; g += 64) {
-        const int64_t m = nidx[g];
-        const double* a = vals + 9 * (int64_t)g;
-        const double x0 = x[3 * m], x1 = x[3 * m + 1], x2 = x[3 * m + 2];
-        prod[(g - c0)] = a[0] * x0 + a[1] * x1 + a[2] * x2;           // plane layout: conflict-free strips
-        prod[CH + (g - c0)] = a[3] * x0 + a[4] * x1 + a[5] * x2;
-        prod[2 * CH + (g - c0)] = a[6] * x0 + a[7] * x1 + a[8] * x2;
+      for (int32_t g0 = c0; g0 < c1; g0 += 64 * U) {
+        // U groups of 64 blocks in flight per trip; a group past the end is clamped onto the last block of the
+        // chunk (loads stay in range, nothing is stored for it)
+        int32_t nb[U], g[U];
+        int64_t m[U];
+        double v[U][9], xv[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int32_t gu = min(g0 + 64 * u, c1 - 1);
+          nb[u] = (g0 + 64 * u < c1) ? min(64, c1 - gu) : 0;  // wave-uniform
+          g[u] = min(gu + lane, c1 - 1);
+          m[u] = nidx[g[u]];
+          const double* src = vals + 9 * (int64_t)gu;
+          const int32_t last = max(nb[u], 1) * 9 - 1;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[u][k] = src[min(k * 64 + lane, last)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          xv[u][0] = x[3 * m[u]]; xv[u][1] = x[3 * m[u] + 1]; xv[u][2] = x[3 * m[u] + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) stage[k * 64 + lane] = v[u][k];
+          const double* a = stage + 9 * min(lane, max(nb[u], 1) - 1);
+          const double p0 = a[0] * xv[u][0] + a[1] * xv[u][1] + a[2] * xv[u][2];
+          const double p1 = a[3] * xv[u][0] + a[4] * xv[u][1] + a[5] * xv[u][2];
+          const double p2 = a[6] * xv[u][0] + a[7] * xv[u][1] + a[8] * xv[u][2];
+          if (lane < nb[u]) {
+            prod[g[u] - c0] = p0;  // plane layout: conflict-free strips
+            prod[CH + g[u] - c0] = p1;
+            prod[2 * CH + g[u] - c0] = p2;
+          }
+        }
       }
-      __syncthreads();
       for (int32_t g = max(rb, c0); g < min(re, c1); ++g) {
         acc[0] += prod[g - c0];
         acc[1] += prod[CH + g - c0];
         acc[2] += prod[2 * CH + g - c0];
       }
-      __syncthreads();
     }
     if (valid) {
 #pragma unroll
