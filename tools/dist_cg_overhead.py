@@ -1,3 +1,4 @@
+"""dist_cg (world 1) against the native pf_cg on a 1/8 strip of the 4M-quad mesh: host overhead of the distributed driver."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

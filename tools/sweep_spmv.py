@@ -1,3 +1,4 @@
+"""SpMV shape sweep (build with PF_SPMV_SWEEP=1; PF_SPMV_SHAPE selects a candidate) on the 4M-quad matrices."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
