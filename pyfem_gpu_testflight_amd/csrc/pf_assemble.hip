@@ -975,7 +975,9 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     const int abl = ab ? atoi(ab) : 0;
     auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;
     const bool both = (Phys::V == 4) || (out0 && (out1 || Phys::V == 1));
-    if (per_lane <= 5 && both) {
+    if (per_lane <= 3 && both) {
+      k3 = k_assemble_v3<P, Phys, RHO, 3, 0>;
+    } else if (per_lane <= 5 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 5, 0>;
       if constexpr (P == 4 && Phys::V == 4 && !RHO) {
         if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 5, 1>;

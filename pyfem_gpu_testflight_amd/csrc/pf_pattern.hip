@@ -425,9 +425,16 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     return rc;
   }
   PF_REQUIRE((int64_t)d * d * ctx->nblocks < ((int64_t)1 << 31), "pf_pattern_build: nnz exceeds int32 (scipy CSR index type)");
-  // nodes per assembly tile: a tile's incident pairs must fit one wave (64 lanes)
-  ctx->npt = ctx->max_valence <= 4 ? 16 : ctx->max_valence <= 8 ? 8 : ctx->max_valence <= 16 ? 4
-           : ctx->max_valence <= 32 ? 2 : ctx->max_valence <= 64 ? 1 : 0;
+  // Max nodes per assembly tile.  A tile's incident pairs must fit one wave (64 lanes): the greedy pass below stops
+  // a tile at 64 pairs, so the cap only has to cover the typical valence (npt * max_valence <= 128: triangles with
+  // valence 6-8 get up to 10 nodes = 60 lanes instead of 8 nodes = 48) and keep the LDS image of the tile's rows
+  // (npt * max_row_blocks blocks of d*d doubles, two planes for the scalar K+R pair) within ~20 KB per wave.
+  ctx->npt = 0;
+  if (ctx->max_valence <= 64) {
+    const int64_t row_bytes = (int64_t)ctx->max_row_blocks * d * d * 8 * (d == 1 ? 2 : 1);
+    for (int c = 16; c >= 1; c >>= 1)
+      if ((c * ctx->max_valence <= 128 && c * row_bytes <= 20 * 1024) || c == 1) { ctx->npt = c; break; }
+  }
   if (ctx->npt) {
     // Tiles: runs of <= npt consecutive nodes.  A tile's rows are one contiguous segment of the value array,
     // copied out by one wave; neighbouring segments are written by different CUs, and a cache line shared by
@@ -447,7 +454,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     const bool fixed = getenv("PF_TILE_FIXED") != nullptr;  // ablation: npt nodes per tile, no alignment search
     for (int64_t n0 = 0; n0 < nn;) {
       int64_t emax = std::min<int64_t>(n0 + ctx->npt, nn);
-      while (hv[emax] - hv[n0] > 64) --emax;  // cannot happen with npt from max_valence; kept as a guard
+      while (emax > n0 + 1 && hv[emax] - hv[n0] > 64) --emax;  // at most 64 incident pairs per tile
       int64_t e = emax;
       if (emax < nn && !fixed) {
         int best = -1;
