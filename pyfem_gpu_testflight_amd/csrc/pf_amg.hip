@@ -47,6 +47,17 @@ struct AmgLevel {
   int32_t* agg = nullptr;    // (n) aggregate of each node
   int32_t* aptr = nullptr;   // (nc+1) aggregate -> members
   int32_t* amem = nullptr;   // (n)
+  // smoothed prolongator P = (I - w D^-1 A) P_tent, stored: row n couples to the aggregates of n's neighbours
+  int32_t* pptr = nullptr;   // (n+1)
+  int32_t* pidx = nullptr;   // (np) aggregate ids, ascending per row
+  double* pvals = nullptr;   // (np) blocks of dr x dc(next level), row-major
+  int32_t* tptr = nullptr;   // (nc+1) transpose pattern: entries of each coarse column, ascending node
+  int32_t* tnode = nullptr;  // (np) fine node of the entry
+  int32_t* tslot = nullptr;  // (np) its index into pidx / pvals
+  double* ptvals = nullptr;  // (np) the same blocks in transpose order (streamed by the restriction)
+  int64_t np = 0;
+  int32_t max_crow = 0;      // longest row of the next level's graph
+  bool sa = false;           // this level's transfer uses the stored smoothed P (else the tentative P on the fly)
   // work vectors
   double *x = nullptr, *b = nullptr, *t = nullptr;
   double omega = 0.6;
@@ -62,10 +73,15 @@ struct pf_amg {
   double* gersh = nullptr;      // scratch vector for the power iteration
   double* lam = nullptr;        // device: per-level |D^-1 A v|^2 + the not-SPD flag (AMG_MAX_LEVELS + 1 doubles)
   bool numeric_ok = false;      // the numeric setup below matches L[0].vals
+  int sa_mode = 1;              // PF_AMG_SA: 0 tentative P on the fly everywhere (plain aggregation), 2 smoothed
+                                // aggregation (stored P) on every level, 1 (default) smoothed except on the finest
+                                // level of 3-D elasticity, where the triple product with 125-node columns of 3x6
+                                // blocks costs more than the iterations it saves (96^3: 61 ms against 45 ms of solve)
   int nsmooth = 2;              // damped-Jacobi sweeps before and after the coarse correction
   double over = 2.0;            // scaling of the coarse-grid correction: plain aggregation under-corrects.
                                 // 2048^2 plane stress, rtol 1e-8 (tools/amg_sweep.py): V(1,1)/1.0 180 its 572 ms,
                                 // V(2,2)/2.0 60 its 231 ms, Jacobi-PCG 16 380 its 7.3 s.  Any value > 0 keeps M SPD.
+  double over_sa = 1.0;         // the same for levels with a smoothed prolongator: no over-correction needed
   double omega_scale = 1.0;
 };
 
@@ -126,6 +142,61 @@ static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const 
     row.erase(std::unique(row.begin(), row.end()), row.end());
     cidx.insert(cidx.end(), row.begin(), row.end());
     cptr[a + 1] = (int32_t)cidx.size();
+  }
+}
+
+// Pattern of the smoothed prolongator and of the Galerkin product built with it (graph only, host):
+//   row n of P couples to the aggregates of n and of its neighbours;  P^T A P couples I and J when some n in a
+//   column of I has a neighbour m whose row of P contains J.
+static void sa_pattern_host(int64_t n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx,
+                            const std::vector<int32_t>& agg, int64_t nc, std::vector<int32_t>& pptr,
+                            std::vector<int32_t>& pidx, std::vector<int32_t>& tptr, std::vector<int32_t>& tnode,
+                            std::vector<int32_t>& tslot, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx) {
+  pptr.assign(n + 1, 0);
+  pidx.clear();
+  pidx.reserve(3 * n);
+  std::vector<int32_t> row;
+  for (int64_t i = 0; i < n; ++i) {
+    row.clear();
+    row.push_back(agg[i]);
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) row.push_back(agg[idx[g]]);
+    std::sort(row.begin(), row.end());
+    row.erase(std::unique(row.begin(), row.end()), row.end());
+    pidx.insert(pidx.end(), row.begin(), row.end());
+    pptr[i + 1] = (int32_t)pidx.size();
+  }
+  const int64_t np = (int64_t)pidx.size();
+  tptr.assign(nc + 1, 0);
+  for (int64_t s = 0; s < np; ++s) tptr[pidx[s] + 1]++;
+  for (int64_t I = 0; I < nc; ++I) tptr[I + 1] += tptr[I];
+  tnode.resize(np);
+  tslot.resize(np);
+  std::vector<int32_t> cur(tptr.begin(), tptr.end() - 1);
+  for (int64_t i = 0; i < n; ++i)
+    for (int32_t s = pptr[i]; s < pptr[i + 1]; ++s) {
+      const int32_t at = cur[pidx[s]]++;
+      tnode[at] = (int32_t)i;
+      tslot[at] = s;
+    }
+  cptr.assign(nc + 1, 0);
+  cidx.clear();
+  std::vector<int32_t> mark(nc, -1);
+  for (int64_t I = 0; I < nc; ++I) {
+    row.clear();
+    for (int32_t e = tptr[I]; e < tptr[I + 1]; ++e) {
+      const int32_t i = tnode[e];
+      for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+        const int32_t m = idx[g];
+        for (int32_t s = pptr[m]; s < pptr[m + 1]; ++s) {
+          const int32_t J = pidx[s];
+          if (mark[J] != (int32_t)I) { mark[J] = (int32_t)I; row.push_back(J); }
+        }
+      }
+    }
+    if (mark[I] != (int32_t)I) row.push_back((int32_t)I);
+    std::sort(row.begin(), row.end());
+    cidx.insert(cidx.end(), row.begin(), row.end());
+    cptr[I + 1] = (int32_t)cidx.size();
   }
 }
 
@@ -375,6 +446,266 @@ __global__ void k_amg_prolong(int64_t n, const int32_t* __restrict__ agg, const 
   }
 }
 
+// ---- smoothed aggregation: stored prolongator ------------------------------------------------------------
+// P = (I - w D^-1 A) P_tent, w = 4 / (3 * 1.1 * lambda_max(D^-1 A)); one lane per fine node owns its row of P.
+// diag holds the raw diagonal, lam2 the squared estimate of lambda_max from the power iteration.
+template <int DIM, int DR, int DC>
+__global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                              const double* __restrict__ vals, const int32_t* __restrict__ agg,
+                              const uint8_t* __restrict__ iso, const double* __restrict__ xy,
+                              const double* __restrict__ cxy, const double* __restrict__ diag,
+                              const double* __restrict__ lam2, const int32_t* __restrict__ pptr,
+                              const int32_t* __restrict__ pidx, double* __restrict__ pvals) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double w = 4.0 / (3.3 * sqrt(lam2[0]));
+  const int32_t pb = pptr[i], pe = pptr[i + 1];
+  for (int64_t q = (int64_t)pb * DR * DC; q < (int64_t)pe * DR * DC; ++q) pvals[q] = 0.0;
+  double wr[DR];
+#pragma unroll
+  for (int r = 0; r < DR; ++r) wr[r] = iso[DR * i + r] ? 0.0 : w / diag[DR * i + r];
+  {
+    const int32_t I = agg[i];
+    double Pn[DR][DC];
+    amg_P<DIM, DR, DC>(xy + DIM * i, cxy + DIM * (int64_t)I, iso + DR * i, Pn);
+    int32_t s = pb;
+    while (pidx[s] != I) ++s;
+    double* dst = pvals + (int64_t)s * DR * DC;
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) dst[r * DC + c] = Pn[r][c];
+  }
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+    const int64_t m = idx[g];
+    const int32_t J = agg[m];
+    double Pm[DR][DC];
+    amg_P<DIM, DR, DC>(xy + DIM * m, cxy + DIM * (int64_t)J, iso + DR * m, Pm);
+    const double* a = vals + (int64_t)g * DR * DR;
+    int32_t s = pb;
+    while (pidx[s] != J) ++s;
+    double* dst = pvals + (int64_t)s * DR * DC;
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < DR; ++t) acc += a[r * DR + t] * Pm[t][c];
+        dst[r * DC + c] -= wr[r] * acc;
+      }
+  }
+}
+
+// Galerkin product with the stored P, one lane per coarse row I:
+//   C[I,J] = sum_{n in col I} sum_{m in N(n)} P[n,I]^T A[n,m] P[m,J]
+template <int DR, int DC>
+__global__ void k_sa_galerkin(int64_t nc, const int32_t* __restrict__ tptr, const int32_t* __restrict__ tnode,
+                              const int32_t* __restrict__ tslot, const int32_t* __restrict__ ptr,
+                              const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                              const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                              const double* __restrict__ pvals, const int32_t* __restrict__ cptr,
+                              const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  const int32_t cb = cptr[I], ce = cptr[I + 1];
+  for (int64_t q = (int64_t)cb * DC * DC; q < (int64_t)ce * DC * DC; ++q) cvals[q] = 0.0;
+  for (int32_t e = tptr[I]; e < tptr[I + 1]; ++e) {
+    const int64_t n = tnode[e];
+    const double* Pn = pvals + (int64_t)tslot[e] * DR * DC;
+    double pn[DR][DC];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) pn[r][c] = Pn[r * DC + c];
+    for (int32_t g = ptr[n]; g < ptr[n + 1]; ++g) {
+      const int64_t m = idx[g];
+      const double* a = vals + (int64_t)g * DR * DR;
+      double T[DC][DR];  // P[n,I]^T A[n,m]
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int t = 0; t < DR; ++t) {
+          double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < DR; ++r) s += pn[r][c] * a[r * DR + t];
+          T[c][t] = s;
+        }
+      int32_t pos = cb;
+      for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
+        const int32_t J = pidx[s2];  // ascending per row, like cidx: the search resumes where it stopped
+        while (cidx[pos] != J) ++pos;
+        const double* Pm = pvals + (int64_t)s2 * DR * DC;
+        double* dst = cvals + (int64_t)pos * DC * DC;
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+#pragma unroll
+          for (int c2 = 0; c2 < DC; ++c2) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < DR; ++t) s += T[c][t] * Pm[t * DC + c2];
+            dst[c * DC + c2] += s;
+          }
+      }
+    }
+  }
+}
+
+// The same product with one WAVE per coarse row (rows of at most 64 couplings): lanes split the (n, m) pairs --
+// four entries of the column of I times sixteen neighbour slots per pass -- and add their DC x DC contributions
+// into an LDS image of the row with LDS atomics; the row is then written out once.  The lane-per-row kernel above
+// takes 15 ms for the 233 k coarse rows of the 2048x1024 plane-stress matrix; this one well under one.
+template <int DR, int DC>
+__global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32_t* __restrict__ tptr,
+                                                         const int32_t* __restrict__ tnode,
+                                                         const int32_t* __restrict__ tslot,
+                                                         const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                         const double* __restrict__ vals,
+                                                         const int32_t* __restrict__ pptr,
+                                                         const int32_t* __restrict__ pidx,
+                                                         const double* __restrict__ pvals,
+                                                         const int32_t* __restrict__ cptr,
+                                                         const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
+  __shared__ int32_t crow[64];
+  __shared__ double cacc[64 * DC * DC];
+  const int lane = threadIdx.x;
+  for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
+    const int32_t cb = cptr[I], clen = cptr[I + 1] - cb;
+    if (lane < clen) crow[lane] = cidx[cb + lane];
+    for (int q = lane; q < clen * DC * DC; q += 64) cacc[q] = 0.0;
+    const int32_t tb = tptr[I], te = tptr[I + 1];
+    for (int32_t e0 = tb; e0 < te; e0 += 4) {
+      const int32_t e = e0 + (lane >> 4);
+      const bool eok = e < te;
+      const int64_t n = eok ? tnode[e] : 0;
+      const int32_t rb = eok ? ptr[n] : 0, rl = eok ? ptr[n + 1] - rb : 0;
+      double pn[DR][DC];
+      if (eok) {
+        const double* Pn = pvals + (int64_t)tslot[e] * DR * DC;
+#pragma unroll
+        for (int r = 0; r < DR; ++r)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) pn[r][c] = Pn[r * DC + c];
+      }
+      const int32_t rlmax = max(max(__shfl(rl, 0), __shfl(rl, 16)), max(__shfl(rl, 32), __shfl(rl, 48)));
+      for (int32_t g0 = 0; g0 < rlmax; g0 += 16) {
+        const int32_t go = g0 + (lane & 15);
+        if (eok && go < rl) {
+          const int32_t g = rb + go;
+          const int64_t m = idx[g];
+          const double* av = vals + (int64_t)g * DR * DR;
+          double T[DC][DR];
+#pragma unroll
+          for (int c = 0; c < DC; ++c)
+#pragma unroll
+            for (int t = 0; t < DR; ++t) {
+              double s = 0.0;
+#pragma unroll
+              for (int r = 0; r < DR; ++r) s += pn[r][c] * av[r * DR + t];
+              T[c][t] = s;
+            }
+          int pos = 0;
+          for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
+            const int32_t J = pidx[s2];
+            while (crow[pos] != J) ++pos;
+            const double* Pm = pvals + (int64_t)s2 * DR * DC;
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+#pragma unroll
+              for (int c2 = 0; c2 < DC; ++c2) {
+                double s = 0.0;
+#pragma unroll
+                for (int t = 0; t < DR; ++t) s += T[c][t] * Pm[t * DC + c2];
+                __hip_atomic_fetch_add(cacc + (pos * DC + c) * DC + c2, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+          }
+        }
+      }
+    }
+    double* dst = cvals + (int64_t)cb * DC * DC;
+    for (int q = lane; q < clen * DC * DC; q += 64) dst[q] = cacc[q];
+  }
+}
+
+// ptvals[e] = pvals[tslot[e]]: P in transpose order, so that the restriction streams it
+__global__ void k_sa_transpose_vals(int64_t np, int bs, const int32_t* __restrict__ tslot,
+                                    const double* __restrict__ pvals, double* __restrict__ ptvals) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= np * bs) return;
+  const int64_t e = q / bs;
+  ptvals[q] = pvals[(int64_t)tslot[e] * bs + (q - e * bs)];
+}
+
+// restriction as a streamed block product with P^T (same scheme as k_amg_spmv: 64 coarse rows per wave tile,
+// lanes stream the tile's contiguous entries, products parked in LDS, lane-per-row sums)
+template <int DR, int DC>
+__global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int32_t* __restrict__ tptr,
+                                                           const int32_t* __restrict__ tnode,
+                                                           const double* __restrict__ ptvals,
+                                                           const double* __restrict__ resid, double* __restrict__ bc) {
+  constexpr int CH = 512;
+  __shared__ double prod[CH * DC];
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (nc + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t I = tile * 64 + lane;
+    const bool valid = I < nc;
+    const int32_t rb = valid ? tptr[I] : 0, re = valid ? tptr[I + 1] : 0;
+    const int32_t base = __shfl(rb, 0);
+    const int32_t end = tptr[min(nc, (tile + 1) * 64)];
+    double acc[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) acc[c] = 0.0;
+    for (int32_t c0 = base; c0 < end; c0 += CH) {
+      const int32_t c1 = min(end, c0 + CH);
+      for (int32_t e = c0 + lane; e < c1; e += 64) {
+        const int64_t n = tnode[e];
+        const double* Pn = ptvals + (int64_t)e * DR * DC;
+        double rv[DR];
+#pragma unroll
+        for (int r = 0; r < DR; ++r) rv[r] = resid[DR * n + r];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < DR; ++r) s += Pn[r * DC + c] * rv[r];
+          prod[c * CH + (e - c0)] = s;
+        }
+      }
+      __syncthreads();
+      for (int32_t e = max(rb, c0); e < min(re, c1); ++e)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) acc[c] += prod[c * CH + (e - c0)];
+      __syncthreads();
+    }
+    if (valid)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
+  }
+}
+
+// x_n += over * sum_J P[n,J] e_J
+template <int DR, int DC>
+__global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                             const double* __restrict__ pvals, const double* __restrict__ ec, double* __restrict__ x,
+                             double over) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s[DR];
+#pragma unroll
+  for (int r = 0; r < DR; ++r) s[r] = 0.0;
+  for (int32_t q = pptr[i]; q < pptr[i + 1]; ++q) {
+    const double* Pn = pvals + (int64_t)q * DR * DC;
+    const double* e = ec + DC * (int64_t)pidx[q];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+  }
+#pragma unroll
+  for (int r = 0; r < DR; ++r) x[DR * i + r] += over * s[r];
+}
+
 // coarsest level: scatter the block matrix into a dense m x m array, invert it in place (Gauss-Jordan,
 // SPD so no pivoting) with one workgroup, then x = Ainv b per cycle
 template <int D>
@@ -442,6 +773,8 @@ void pf_amg_free(pf_ctx* ctx) {
     if (l > 0) pf_free(Lv.vals);
     if (Lv.owns_xy) pf_free(Lv.xy);
     pf_free(Lv.dinv); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
+    pf_free(Lv.pptr); pf_free(Lv.pidx); pf_free(Lv.pvals); pf_free(Lv.tptr); pf_free(Lv.tnode); pf_free(Lv.tslot);
+    pf_free(Lv.ptvals);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
   }
   pf_free(H->dense_inv);
@@ -465,6 +798,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   const int d0 = ctx->d;
   H->dim = (ctx->ndims == 3 && d0 == 3) ? 3 : 2;
   const int dc = (d0 == 1) ? 1 : (H->dim == 3) ? 6 : 3;
+  if (const char* e = getenv("PF_AMG_SA")) H->sa_mode = atoi(e);
   std::vector<int32_t> ptr(ctx->nnodes + 1), idx(ctx->nblocks);
   PF_HIP(hipMemcpyAsync(ptr.data(), ctx->nptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipMemcpyAsync(idx.data(), ctx->nidx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -492,7 +826,25 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     if (nc >= n || nc == 0) break;  // no coarsening possible
     coarse_graph_host(n, ptr, idx, agg, nc, aptr, amem, cptr, cidx);
     Lv.nc = nc;
-    int rc = to_device(ctx, agg, Lv.agg);
+    int rc = PF_OK;
+    Lv.sa = H->sa_mode == 2 || (H->sa_mode == 1 && !(H->dim == 3 && l == 0));
+    if (Lv.sa) {  // the coarse graph is that of P^T A P with the smoothed P
+      std::vector<int32_t> pptr, pidx, tptr, tnode, tslot;
+      sa_pattern_host(n, ptr, idx, agg, nc, pptr, pidx, tptr, tnode, tslot, cptr, cidx);
+      Lv.np = (int64_t)pidx.size();
+      rc = to_device(ctx, pptr, Lv.pptr);
+      if (rc == PF_OK) rc = to_device(ctx, pidx, Lv.pidx);
+      if (rc == PF_OK) rc = to_device(ctx, tptr, Lv.tptr);
+      if (rc == PF_OK) rc = to_device(ctx, tnode, Lv.tnode);
+      if (rc == PF_OK) rc = to_device(ctx, tslot, Lv.tslot);
+      if (rc) return rc;
+      PF_HIP(hipMalloc(&Lv.pvals, sizeof(double) * Lv.np * Lv.dr * dc));
+      PF_HIP(hipMalloc(&Lv.ptvals, sizeof(double) * Lv.np * Lv.dr * dc));
+      Lv.max_crow = 0;
+      for (int64_t I = 0; I < nc; ++I) Lv.max_crow = std::max(Lv.max_crow, cptr[I + 1] - cptr[I]);
+      PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
+    }
+    if (rc == PF_OK) rc = to_device(ctx, agg, Lv.agg);
     if (rc == PF_OK) rc = to_device(ctx, aptr, Lv.aptr);
     if (rc == PF_OK) rc = to_device(ctx, amem, Lv.amem);
     AmgLevel& Nx = H->L[l + 1];
@@ -592,6 +944,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   H->L[0].vals = const_cast<double*>(vals);
   if (const char* e = getenv("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
   if (const char* e = getenv("PF_AMG_OVER")) H->over = atof(e);
+  if (const char* e = getenv("PF_AMG_OVER_SA")) H->over_sa = atof(e);
   if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
   double* bad = H->lam + AMG_MAX_LEVELS;
   PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 1), ctx->stream));
@@ -603,26 +956,50 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
     else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
     PF_LAUNCH_CHECK();
-    if (l + 1 == H->nlevels) break;
-    AmgLevel& Nx = H->L[l + 1];
-    const unsigned g = (unsigned)cdiv(Lv.nc, 128);
-#define PF_GAL(DIM_, DR_, DC_)                                                                                \
-    k_amg_galerkin<DIM_, DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
-                                                               Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
-    if (Lv.dr == 1) PF_GAL(2, 1, 1);
-    else if (H->dim == 3 && Lv.dr == 3) PF_GAL(3, 3, 6);
-    else if (H->dim == 3) PF_GAL(3, 6, 6);
-    else if (Lv.dr == 2) PF_GAL(2, 2, 3);
-    else PF_GAL(2, 3, 3);
-#undef PF_GAL
-    PF_LAUNCH_CHECK();
-  }
-  // damping per level from lambda_max(D^-1 A) (power iteration under-estimates slightly, hence the 1.1)
-  for (int l = 0; l < H->nlevels; ++l) {
-    AmgLevel& Lv = H->L[l];
+    // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
+    // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
     const int64_t ndof = Lv.n * Lv.dr;
     int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l);
     if (rc) return rc;
+    if (l + 1 < H->nlevels) {
+      AmgLevel& Nx = H->L[l + 1];
+      const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+      if (Lv.sa) {
+        const unsigned gn = (unsigned)cdiv(Lv.n, 128);
+#define PF_SAP(DIM_, DR_, DC_)                                                                                   \
+        k_sa_smooth_P<DIM_, DR_, DC_><<<gn, 128, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.agg, Lv.iso, Lv.xy, \
+                                                                   Nx.xy, Lv.dinv, H->lam + l, Lv.pptr, Lv.pidx, Lv.pvals)
+#define PF_SAG(DR_, DC_)                                                                                         \
+        do {                                                                                                     \
+          if (Lv.max_crow <= 64)                                                                                 \
+            k_sa_galerkin_wave<DR_, DC_><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>(     \
+                Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+          else                                                                                                   \
+            k_sa_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, \
+                                                                Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+          const int bs_ = DR_ * DC_;                                                                             \
+          k_sa_transpose_vals<<<(unsigned)cdiv(Lv.np * bs_, 256), 256, 0, ctx->stream>>>(Lv.np, bs_, Lv.tslot, Lv.pvals, Lv.ptvals); \
+        } while (0)
+        if (Lv.dr == 1) { PF_SAP(2, 1, 1); PF_SAG(1, 1); }
+        else if (H->dim == 3 && Lv.dr == 3) { PF_SAP(3, 3, 6); PF_SAG(3, 6); }
+        else if (H->dim == 3) { PF_SAP(3, 6, 6); PF_SAG(6, 6); }
+        else if (Lv.dr == 2) { PF_SAP(2, 2, 3); PF_SAG(2, 3); }
+        else { PF_SAP(2, 3, 3); PF_SAG(3, 3); }
+#undef PF_SAP
+#undef PF_SAG
+      } else {
+#define PF_GAL(DIM_, DR_, DC_)                                                                                \
+        k_amg_galerkin<DIM_, DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
+                                                                   Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
+        if (Lv.dr == 1) PF_GAL(2, 1, 1);
+        else if (H->dim == 3 && Lv.dr == 3) PF_GAL(3, 3, 6);
+        else if (H->dim == 3) PF_GAL(3, 6, 6);
+        else if (Lv.dr == 2) PF_GAL(2, 2, 3);
+        else PF_GAL(2, 3, 3);
+#undef PF_GAL
+      }
+      PF_LAUNCH_CHECK();
+    }
     k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, H->lam + l, H->omega_scale, Lv.dinv, Lv.iso);
     PF_LAUNCH_CHECK();
   }
@@ -685,6 +1062,17 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     }
     if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+    if (Lv.sa) {
+#define PF_SAR(DR_, DC_)                                                                                    \
+  k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, \
+                                                                                                   Lv.ptvals, o, Nx.b)
+      if (Lv.dr == 1) PF_SAR(1, 1);
+      else if (H->dim == 3 && Lv.dr == 3) PF_SAR(3, 6);
+      else if (H->dim == 3) PF_SAR(6, 6);
+      else if (Lv.dr == 2) PF_SAR(2, 3);
+      else PF_SAR(3, 3);
+#undef PF_SAR
+    } else
     if (Lv.dr == 1) k_amg_restrict<2, 1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
     else if (H->dim == 3 && Lv.dr == 3) k_amg_restrict<3, 3, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
     else if (H->dim == 3) k_amg_restrict<3, 6, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
@@ -721,11 +1109,21 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     double* c = cur[l];
     double* o = oth[l];
     const unsigned g = (unsigned)cdiv(Lv.n, 256);
-    if (Lv.dr == 1) k_amg_prolong<2, 1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else if (H->dim == 3 && Lv.dr == 3) k_amg_prolong<3, 3, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
-    else k_amg_prolong<2, 3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, H->over);
+    const double over = Lv.sa ? H->over_sa : H->over;
+    if (Lv.sa) {
+#define PF_SAO(DR_, DC_) k_sa_prolong<DR_, DC_><<<g, 256, 0, st>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, Nx.x, c, over)
+      if (Lv.dr == 1) PF_SAO(1, 1);
+      else if (H->dim == 3 && Lv.dr == 3) PF_SAO(3, 6);
+      else if (H->dim == 3) PF_SAO(6, 6);
+      else if (Lv.dr == 2) PF_SAO(2, 3);
+      else PF_SAO(3, 3);
+#undef PF_SAO
+    } else
+    if (Lv.dr == 1) k_amg_prolong<2, 1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
+    else if (H->dim == 3 && Lv.dr == 3) k_amg_prolong<3, 3, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
+    else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
+    else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
+    else k_amg_prolong<2, 3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
     for (int s = 0; s < H->nsmooth; ++s) {
       if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
       std::swap(c, o);
