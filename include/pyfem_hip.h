@@ -161,7 +161,7 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * (the reference's `cg(K, rhs, tol=1e-8, atol=0.0)`, pyfem.py:2418).  x holds the initial
  * guess on entry.  Returns PF_E_NOCONV when maxiter is hit (iters/relres still written).
  * iters, relres: HOST out pointers.  check_every: residual is read back to the host every
- * that many iterations (<=0: default, 50 for Jacobi / 5 for AMG); iteration count is exact to that granularity. */
+ * that many iterations (<=0: default, 50 for Jacobi / 1 for AMG); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
 /* PF_PRECOND_AMG: aggregation-AMG V(2,2) cycle -- the device counterpart of the reference's

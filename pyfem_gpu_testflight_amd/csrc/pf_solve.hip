@@ -699,7 +699,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);  // scipy's default
-  if (check_every <= 0) check_every = (precond == PF_PRECOND_AMG) ? 5 : 50;  // an AMG iteration costs ~8 Jacobi ones
+  if (check_every <= 0) check_every = (precond == PF_PRECOND_AMG) ? 1 : 50;  // AMG: 10-30 iterations of ~1 ms; a read-back is ~20 us
   if (ctx->cgw_cap < 5 * n) {
     pf_free(ctx->cgw);
     PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * 5 * n));
