@@ -164,7 +164,7 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * that many iterations (<=0: default, 50 for Jacobi / 1 for AMG); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
-/* PF_PRECOND_AMG: aggregation-AMG V(2,2) cycle -- the device counterpart of the reference's
+/* PF_PRECOND_AMG: smoothed-aggregation AMG V(2,2) cycle -- the device counterpart of the reference's
  * pyamg.smoothed_aggregation_solver(K).aspreconditioner() (pyfem.py:2393-2400) and of
  * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,
  * the coarse operators per call.  If the matrix has a non-positive diagonal entry (not SPD) pf_cg

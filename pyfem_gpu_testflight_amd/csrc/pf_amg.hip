@@ -6,20 +6,19 @@
 // the rest of the path (node graph + dense d x d blocks), not a port:
 //   * aggregates depend on the node GRAPH only, so they are built once per mesh on the host (greedy
 //     root/neighbourhood aggregation, O(nnz) serial C++) together with the coarse node graphs;
-//   * per matrix, on the device: Galerkin coarse operators A_c = P^T A P by an owner-computes gather
-//     (one lane per coarse row, no atomics), with the tentative prolongator built from the near-null
-//     space: the constant for scalar problems, the three rigid-body modes (two translations and the
-//     in-plane rotation about the aggregate centroid) for plane elasticity -> 3 x 3 coarse blocks, the six
-//     rigid-body modes (translations + rotations about the centroid) for 3-D elasticity -> 6 x 6 blocks;
-//     dofs whose row is decoupled (Dirichlet rows after apply_dirichlet_bcs) are kept out of P and are
-//     solved exactly by the smoother;
+//   * per matrix, on the device: the prolongator P = (I - w D^-1 A) P_tent (smoothed aggregation), where the
+//     tentative prolongator carries the near-null space: the constant for scalar problems, the three
+//     rigid-body modes (two translations and the in-plane rotation about the aggregate centroid) for plane
+//     elasticity -> 3 x 3 coarse blocks, the six rigid-body modes for 3-D elasticity -> 6 x 6 blocks; dofs whose
+//     row is decoupled (Dirichlet rows after apply_dirichlet_bcs) are kept out of P and are solved exactly by
+//     the smoother; Galerkin coarse operators A_c = P^T A P (one wave per coarse row, no global atomics);
 //   * V(2,2) cycle with damped Jacobi, omega = 4/(3*1.1*lambda_max(D^-1 A)) with lambda_max from ten
 //     device power iterations per level (invariant under the scaling of individual dofs, unlike a
-//     Gershgorin row sum: translations and rotations have different units on the coarse levels), the
-//     coarse correction scaled by 2 (plain aggregation under-corrects), dense inverse on the coarsest
-//     level (<= 160 dofs).
+//     Gershgorin row sum: translations and rotations have different units on the coarse levels), dense
+//     inverse on the coarsest level (<= 160 dofs).
 // The cycle is a fixed symmetric positive definite operator, so it is a valid CG preconditioner.
-// Plain (unsmoothed) aggregation is used in this round; smoothing the prolongator is the next step.
+// PF_AMG_SA=0 selects plain aggregation (tentative P formed on the fly from the coordinates, coarse correction
+// scaled by 2 because plain aggregation under-corrects): kept as the cheap-setup variant and for comparison.
 #include <stdlib.h>
 
 #include <algorithm>
