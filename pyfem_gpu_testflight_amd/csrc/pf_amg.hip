@@ -320,7 +320,7 @@ __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, con
           AP[r][c] = s;
         }
       int32_t pos = cb;
-      while (cidx[pos] != J) ++pos;
+      while (pos < ce - 1 && cidx[pos] != J) ++pos;  // J is in the row by construction; bounded anyway
       double* dst = cvals + (int64_t)pos * DC * DC;
 #pragma unroll
       for (int r = 0; r < DC; ++r)
@@ -468,7 +468,7 @@ __global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const 
     double Pn[DR][DC];
     amg_P<DIM, DR, DC>(xy + DIM * i, cxy + DIM * (int64_t)I, iso + DR * i, Pn);
     int32_t s = pb;
-    while (pidx[s] != I) ++s;
+    while (s < pe - 1 && pidx[s] != I) ++s;
     double* dst = pvals + (int64_t)s * DR * DC;
 #pragma unroll
     for (int r = 0; r < DR; ++r)
@@ -482,7 +482,7 @@ __global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const 
     amg_P<DIM, DR, DC>(xy + DIM * m, cxy + DIM * (int64_t)J, iso + DR * m, Pm);
     const double* a = vals + (int64_t)g * DR * DR;
     int32_t s = pb;
-    while (pidx[s] != J) ++s;
+    while (s < pe - 1 && pidx[s] != J) ++s;
     double* dst = pvals + (int64_t)s * DR * DC;
 #pragma unroll
     for (int r = 0; r < DR; ++r)
@@ -533,7 +533,7 @@ __global__ void k_sa_galerkin(int64_t nc, const int32_t* __restrict__ tptr, cons
       int32_t pos = cb;
       for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
         const int32_t J = pidx[s2];  // ascending per row, like cidx: the search resumes where it stopped
-        while (cidx[pos] != J) ++pos;
+        while (pos < ce - 1 && cidx[pos] != J) ++pos;
         const double* Pm = pvals + (int64_t)s2 * DR * DC;
         double* dst = cvals + (int64_t)pos * DC * DC;
 #pragma unroll
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32
           int pos = 0;
           for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
             const int32_t J = pidx[s2];
-            while (crow[pos] != J) ++pos;
+            while (pos < clen - 1 && crow[pos] != J) ++pos;
             const double* Pm = pvals + (int64_t)s2 * DR * DC;
 #pragma unroll
             for (int c = 0; c < DC; ++c)
