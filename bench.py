@@ -81,8 +81,8 @@ def cpu_baseline(n=512, reps=2, cg_iters=40):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nx", type=int, default=2048, help="quads per side (2048 -> the 4M-quad metric mesh)")
     ap.add_argument("--cg-iters", type=int, default=200)
     ap.add_argument("--spmv-reps", type=int, default=50)

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 20 --warmup 3 --cg-iters 100 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --cg-iters 100 --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
