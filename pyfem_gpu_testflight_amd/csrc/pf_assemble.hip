@@ -33,7 +33,7 @@ static constexpr int LDS_STRIDE = 65;             // doubles between consecutive
 // ------------------------------------------------------------------------------------------
 // element geometry at one quadrature point: det J, grad N (global), N
 //
-// Instruction diet (r02 counters: the assembly kernel is VALU-bound, ~520 VALU instructions per
+// Instruction diet (first GPU profile of this round: the v1 kernel was VALU-bound, ~520 VALU instructions per
 // incident element, fp64 issuing at a quarter of the fp32 rate):
 //   * J from the four edge differences of the quad (2 ops per entry instead of 4),
 //   * 1/det and the RAMP quotient by v_rcp_f64 + two Newton steps (5 ops) instead of the IEEE
@@ -426,7 +426,7 @@ __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __re
 // integrate tile Tcur from Cuse into the LDS image and copy the finished segment out.
 // Image layout: V planes of `plane` doubles, value k of the tile's block B at img[k*plane + B].  With the
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
-// 8 of the 32 banks (r03 counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
+// 8 of the 32 banks (PMC counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
 // touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
 template <int P, class Phys, bool RHO, int NOUT, int ABL>
 __device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V3Tile& Tcur,
@@ -997,7 +997,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     if (lds3 > 48 * 1024)
       PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     const int64_t nt = ctx->ntiles;
-    int wpc = 24;  // persistent waves per CU (r03 sweep: 24-32 best)
+    int wpc = 24;  // persistent waves per CU (tools/abl_v3.py sweep: 24-32 best)
     const char* g3 = getenv("PF_GATHER_WAVES_PER_CU");
     if (g3 && atoi(g3) > 0) wpc = atoi(g3);
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);

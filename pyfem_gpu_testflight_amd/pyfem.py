@@ -529,7 +529,7 @@ class Assembler:
         """ref: pyfem.py:2403-2423.
         "direct": scipy spsolve on the exported matrix -- the reference's own third-party call, kept
                   for small meshes / parity checks (not an accelerated leg).
-        "cg" and "gmres": device PCG with the aggregation-AMG V-cycle (self.precond = "amg", default) or
+        "cg" and "gmres": device PCG with the smoothed-aggregation AMG V-cycle (self.precond = "amg", default) or
                   Jacobi.  K is SPD after symmetric BC elimination, so CG reaches the same solution GMRES
                   does."""
         if method == "direct":
