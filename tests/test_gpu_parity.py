@@ -636,3 +636,22 @@ def test_refined_arm_mesh_matches_oracle(pf, orc):
         u = pf.Assembler(model).solve(method="cg")
         uo, *_ = orc.solve_elasticity(Xr, cr, "tri", dof_fixed, force)
         assert relmax(u, uo) < U_TOL
+
+
+@pytest.mark.parametrize("argv", [["--element_type", "quad", "--nx", "96", "--ny", "48", "--iters", "6", "--r0", "0.04"],
+                                  ["--element_type", "block", "--nx", "16", "--ny", "8", "--nz", "8", "--iters", "4",
+                                   "--r0", "0.1"]])
+def test_topology_loop_example(argv):
+    """examples/topo_oc.py: the reference's topology-optimisation callbacks (topo.py:50-75) around the GPU path
+    with an optimality-criteria update; compliance must fall while the volume constraint is kept."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "topo_oc.py")
+    spec = importlib.util.spec_from_file_location("topo_oc", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(argv)
+    obj = [h[0] for h in hist]
+    assert all(np.isfinite(obj)) and obj[-1] < 0.8 * obj[0]
+    assert abs(hist[-1][1]) < 0.03  # volume fraction within 3 % of the target
