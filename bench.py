@@ -42,12 +42,24 @@ def cpu_baseline(n=512, reps=2, cg_iters=40):
     sample -- an n x n quad mesh of the same plane-stress workload."""
     from oracle import pyfem_oracle as orc  # checker/baseline only
 
+    # BLAS threads = the CPUs this process may really use (affinity mask and cgroup quota), not the host's logical
+    # CPU count: on a quota'd box one OpenBLAS thread per logical CPU only burns the quota and gets the process
+    # throttled, which would understate the baseline.
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
     except Exception:
-        threads = os.cpu_count()
+        pass
+    threads = usable
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=usable)
+    except Exception:
+        threads = os.cpu_count() or 1
     conn, X = orc.structured_mesh(n + 1, n + 1, "quad")
     dof_fixed, force = orc.elasticity_problem(n + 1, n + 1)
     conn_dof = orc.create_conn_dof(conn, 2)
@@ -70,10 +82,13 @@ def cpu_baseline(n=512, reps=2, cg_iters=40):
     except RuntimeError:
         pass
     t_cg = (time.perf_counter() - t0) / cg_iters
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {
         "value": conn.shape[0] / t_asm, "unit": "elements/s", "cores": int(threads), "kind": "port",
         "sample": f"{n}x{n}-quad plane-stress mesh ({conn.shape[0]} elements), oracle einsum Ke + coo->csr, "
-                  f"median of {reps} warm passes; host has {os.cpu_count()} logical cpus",
+                  f"median of {reps} warm passes; BLAS threads limited to the {threads} usable cpus of "
+                  f"{os.cpu_count()} logical ones",
         "cg_iter_per_sec": 1.0 / t_cg, "spmv_GBps": algorithmic_bytes_spmv(Kbc.nnz, Kbc.shape[0]) / t_spmv / 1e9,
     }
 

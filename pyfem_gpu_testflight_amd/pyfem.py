@@ -34,6 +34,13 @@ DEFAULT_RTOL = 1e-10
 # pyamg preconditioners, pyfem.py:2393-2400 and :2098; falls back to Jacobi on matrices that are not
 # positive definite) or "jacobi"
 DEFAULT_PRECOND = "amg"
+
+
+def _vdot(a, b):
+    """rhs . u of the compliance functionals (pyfem.py:1068, 1832) without BLAS: a multi-threaded ddot wakes one
+    thread per logical CPU, and on a CPU-quota'd GPU box those spinning threads get the whole process throttled for
+    tens of milliseconds -- longer than the solve the number belongs to."""
+    return float(np.add.reduce(np.multiply(a, b)))
 _PRECOND = {"none": _lib.PF_PRECOND_NONE, "jacobi": _lib.PF_PRECOND_JACOBI, "amg": _lib.PF_PRECOND_AMG}
 
 
@@ -290,7 +297,7 @@ class LinearPoisson(ModelBase):
         rhs = self.compute_rhs()
         K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
         u = Assembler(self)._solve_linear_system(K, rhs, solver)
-        c = rhs.dot(u) if weighted else np.sum(u) / len(u)
+        c = _vdot(rhs, u) if weighted else np.sum(u) / len(u)
         return c, u
 
     @time_this
@@ -396,8 +403,10 @@ class LinearElasticity(ModelBase):
         K = self.compute_jacobian(rho)
         rhs = self.compute_rhs()
         K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
-        u = Assembler(self)._solve_linear_system(K, rhs, solver)
-        return rhs.dot(u), u
+        asm = Assembler(self)
+        u = asm._solve_linear_system(K, rhs, solver)
+        self.last_iters = asm.last_iters  # PCG iterations of this solve (None for "direct")
+        return _vdot(rhs, u), u
 
     def volume(self, rho):
         """ref: pyfem.py:1851-1859."""
