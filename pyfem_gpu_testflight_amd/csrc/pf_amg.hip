@@ -22,6 +22,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "pf_common.h"
@@ -120,13 +122,15 @@ static void aggregate_host(int64_t n, const std::vector<int32_t>& ptr, const std
 
 static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx,
                               const std::vector<int32_t>& agg, int64_t nc, std::vector<int32_t>& aptr,
-                              std::vector<int32_t>& amem, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx) {
+                              std::vector<int32_t>& amem, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx,
+                              bool members_only) {
   aptr.assign(nc + 1, 0);
   for (int64_t i = 0; i < n; ++i) aptr[agg[i] + 1]++;
   for (int64_t a = 0; a < nc; ++a) aptr[a + 1] += aptr[a];
   amem.resize(n);
   std::vector<int32_t> cur(aptr.begin(), aptr.end() - 1);
   for (int64_t i = 0; i < n; ++i) amem[cur[agg[i]]++] = (int32_t)i;
+  if (members_only) return;  // the caller builds the graph of P^T A P with the smoothed P instead
   cptr.assign(nc + 1, 0);
   cidx.clear();
   std::vector<int32_t> row;
@@ -147,22 +151,61 @@ static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const 
 // Pattern of the smoothed prolongator and of the Galerkin product built with it (graph only, host):
 //   row n of P couples to the aggregates of n and of its neighbours;  P^T A P couples I and J when some n in a
 //   column of I has a neighbour m whose row of P contains J.
+static int host_threads() {
+  if (const char* e = getenv("PF_HOST_THREADS")) return std::max(1, atoi(e));
+  return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));  // GPU boxes grant ~16 CPUs per GPU
+}
+
+// run fn(chunk, begin, end) over [0, n) in contiguous chunks on host threads
+template <class F>
+static void parallel_chunks(int64_t n, F fn) {
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 4096));
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+  for (auto& x : th) x.join();
+}
+static int parallel_chunk_count(int64_t n) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(host_threads(), n / 4096));
+}
+
+// concatenate per-chunk row lists into (ptr, idx); rowlen[c] holds the row lengths of chunk c in order
+static void concat_rows(int64_t nrows, const std::vector<std::vector<int32_t>>& rowlen,
+                        const std::vector<std::vector<int32_t>>& part, std::vector<int32_t>& ptr,
+                        std::vector<int32_t>& idx) {
+  ptr.assign(nrows + 1, 0);
+  int64_t r = 0;
+  size_t total = 0;
+  for (const auto& p : part) total += p.size();
+  idx.clear();
+  idx.reserve(total);
+  for (size_t c = 0; c < part.size(); ++c) {
+    for (int32_t len : rowlen[c]) { ptr[r + 1] = ptr[r] + len; ++r; }
+    idx.insert(idx.end(), part[c].begin(), part[c].end());
+  }
+}
+
 static void sa_pattern_host(int64_t n, const std::vector<int32_t>& ptr, const std::vector<int32_t>& idx,
                             const std::vector<int32_t>& agg, int64_t nc, std::vector<int32_t>& pptr,
                             std::vector<int32_t>& pidx, std::vector<int32_t>& tptr, std::vector<int32_t>& tnode,
                             std::vector<int32_t>& tslot, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx) {
-  pptr.assign(n + 1, 0);
-  pidx.clear();
-  pidx.reserve(3 * n);
-  std::vector<int32_t> row;
-  for (int64_t i = 0; i < n; ++i) {
-    row.clear();
-    row.push_back(agg[i]);
-    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) row.push_back(agg[idx[g]]);
-    std::sort(row.begin(), row.end());
-    row.erase(std::unique(row.begin(), row.end()), row.end());
-    pidx.insert(pidx.end(), row.begin(), row.end());
-    pptr[i + 1] = (int32_t)pidx.size();
+  {  // rows of P: the aggregates of i and of its neighbours, ascending
+    const int C = parallel_chunk_count(n);
+    std::vector<std::vector<int32_t>> part(C), rowlen(C);
+    parallel_chunks(n, [&](int c, int64_t b, int64_t e) {
+      std::vector<int32_t> row;
+      part[c].reserve(3 * (e - b));
+      rowlen[c].reserve(e - b);
+      for (int64_t i = b; i < e; ++i) {
+        row.clear();
+        row.push_back(agg[i]);
+        for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) row.push_back(agg[idx[g]]);
+        std::sort(row.begin(), row.end());
+        row.erase(std::unique(row.begin(), row.end()), row.end());
+        part[c].insert(part[c].end(), row.begin(), row.end());
+        rowlen[c].push_back((int32_t)row.size());
+      }
+    });
+    concat_rows(n, rowlen, part, pptr, pidx);
   }
   const int64_t np = (int64_t)pidx.size();
   tptr.assign(nc + 1, 0);
@@ -177,25 +220,31 @@ static void sa_pattern_host(int64_t n, const std::vector<int32_t>& ptr, const st
       tnode[at] = (int32_t)i;
       tslot[at] = s;
     }
-  cptr.assign(nc + 1, 0);
-  cidx.clear();
-  std::vector<int32_t> mark(nc, -1);
-  for (int64_t I = 0; I < nc; ++I) {
-    row.clear();
-    for (int32_t e = tptr[I]; e < tptr[I + 1]; ++e) {
-      const int32_t i = tnode[e];
-      for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
-        const int32_t m = idx[g];
-        for (int32_t s = pptr[m]; s < pptr[m + 1]; ++s) {
-          const int32_t J = pidx[s];
-          if (mark[J] != (int32_t)I) { mark[J] = (int32_t)I; row.push_back(J); }
+  {  // rows of P^T A P
+    const int C = parallel_chunk_count(nc);
+    std::vector<std::vector<int32_t>> part(C), rowlen(C);
+    parallel_chunks(nc, [&](int c, int64_t b, int64_t e) {
+      std::vector<int32_t> mark(nc, -1), row;
+      rowlen[c].reserve(e - b);
+      for (int64_t I = b; I < e; ++I) {
+        row.clear();
+        for (int32_t q = tptr[I]; q < tptr[I + 1]; ++q) {
+          const int32_t i = tnode[q];
+          for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+            const int32_t m = idx[g];
+            for (int32_t s = pptr[m]; s < pptr[m + 1]; ++s) {
+              const int32_t J = pidx[s];
+              if (mark[J] != (int32_t)I) { mark[J] = (int32_t)I; row.push_back(J); }
+            }
+          }
         }
+        if (mark[I] != (int32_t)I) row.push_back((int32_t)I);
+        std::sort(row.begin(), row.end());
+        part[c].insert(part[c].end(), row.begin(), row.end());
+        rowlen[c].push_back((int32_t)row.size());
       }
-    }
-    if (mark[I] != (int32_t)I) row.push_back((int32_t)I);
-    std::sort(row.begin(), row.end());
-    cidx.insert(cidx.end(), row.begin(), row.end());
-    cptr[I + 1] = (int32_t)cidx.size();
+    });
+    concat_rows(nc, rowlen, part, cptr, cidx);
   }
 }
 
@@ -821,15 +870,23 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     if (last) break;
     std::vector<int32_t> agg, aptr, amem, cptr, cidx;
     int64_t nc = 0;
+    const bool verbose = getenv("PF_AMG_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     aggregate_host(n, ptr, idx, agg, nc);
     if (nc >= n || nc == 0) break;  // no coarsening possible
-    coarse_graph_host(n, ptr, idx, agg, nc, aptr, amem, cptr, cidx);
+    const double t_b = now();
+    const bool sa_level = H->sa_mode == 2 || (H->sa_mode == 1 && !(H->dim == 3 && l == 0));
+    coarse_graph_host(n, ptr, idx, agg, nc, aptr, amem, cptr, cidx, sa_level);
+    if (verbose) fprintf(stderr, "[pf_amg] level %d: %lld nodes, aggregate %.3f s, tentative graph %.3f s\n", l, (long long)n, t_b - t_a, now() - t_b);
     Lv.nc = nc;
     int rc = PF_OK;
-    Lv.sa = H->sa_mode == 2 || (H->sa_mode == 1 && !(H->dim == 3 && l == 0));
+    Lv.sa = sa_level;
     if (Lv.sa) {  // the coarse graph is that of P^T A P with the smoothed P
       std::vector<int32_t> pptr, pidx, tptr, tnode, tslot;
+      const double t_c = now();
       sa_pattern_host(n, ptr, idx, agg, nc, pptr, pidx, tptr, tnode, tslot, cptr, cidx);
+      if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s\n", l, now() - t_c);
       Lv.np = (int64_t)pidx.size();
       rc = to_device(ctx, pptr, Lv.pptr);
       if (rc == PF_OK) rc = to_device(ctx, pidx, Lv.pidx);
