@@ -1,4 +1,5 @@
-"""AMG parameter sweep (PF_AMG_NSMOOTH / PF_AMG_OVER) against Jacobi-PCG on an NX x NY plane-stress mesh."""
+"""AMG parameter sweep (PF_AMG_NSMOOTH / PF_AMG_OVER_SA for the smoothed levels; PF_AMG_SA=0 + PF_AMG_OVER for plain
+aggregation) against Jacobi-PCG on an NX x NY plane-stress mesh."""
 import os, sys, time, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,15 +17,16 @@ for label, rho in (("uniform", 1.0), ("random", 0.05 + 0.95 * rng.rand(X.shape[0
     K, rhs = m.apply_dirichlet_bcs(K, rhs, True)
     def run(pre, **env):
         for k, v in env.items(): os.environ[k] = str(v)
-        h.cg(K.vals, rhs, rtol=1e-8, precond=pre, check_every=10, maxiter=20, allow_maxiter=True)  # warm (hierarchy)
+        h.cg(K.vals, rhs, rtol=1e-8, precond=pre, check_every=1, maxiter=3, allow_maxiter=True)  # warm (hierarchy)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        x, it, rr = h.cg(K.vals, rhs, rtol=1e-8, precond=pre, check_every=10)
+        x, it, rr = h.cg(K.vals, rhs, rtol=1e-8, precond=pre, check_every=(1 if pre == _lib.PF_PRECOND_AMG else 10))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         return it, dt
     if not os.environ.get("SKIP_JACOBI"):
         it, dt = run(_lib.PF_PRECOND_JACOBI)
         print(f"{label}: jacobi iters={it} {dt*1e3:.1f} ms", flush=True)
-    for ns, over in itertools.product([1, 2, 3], [1.5, 1.8, 2.0, 2.5]):
-        it, dt = run(_lib.PF_PRECOND_AMG, PF_AMG_NSMOOTH=ns, PF_AMG_OVER=over)
+    sa = os.environ.get("PF_AMG_SA", "1") != "0"
+    for ns, over in itertools.product([1, 2, 3], [0.8, 1.0, 1.2, 1.5] if sa else [1.5, 1.8, 2.0, 2.5]):
+        it, dt = run(_lib.PF_PRECOND_AMG, PF_AMG_NSMOOTH=ns, **({"PF_AMG_OVER_SA": over} if sa else {"PF_AMG_OVER": over}))
         print(f"{label}: amg nsmooth={ns} over={over}: iters={it} {dt*1e3:.1f} ms", flush=True)
 print("levels", h.amg_info())
