@@ -655,3 +655,35 @@ def test_topology_loop_example(argv):
     obj = [h[0] for h in hist]
     assert all(np.isfinite(obj)) and obj[-1] < 0.8 * obj[0]
     assert abs(hist[-1][1]) < 0.03  # volume fraction within 3 % of the target
+
+
+def _fan_mesh(k):
+    """k triangles around node 0 (a closed fan): valence k at the hub, row of k+1 blocks."""
+    ang = 2 * np.pi * np.arange(k) / k
+    X = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1) * (1.0 + 0.1 * np.cos(3 * ang))[:, None]])
+    conn = np.stack([np.zeros(k, dtype=np.int64), 1 + np.arange(k), 1 + (np.arange(k) + 1) % k], axis=1)
+    return X, conn
+
+
+@pytest.mark.parametrize("k", [9, 30, 63])
+def test_high_valence_hub_matches_oracle(pf, orc, k):
+    """Tiles are cut at 64 incident pairs: a hub of valence 63 fills a wave on its own; positions up to 63."""
+    X, conn = _fan_mesh(k)
+    rho = 0.3 + 0.7 * np.random.RandomState(k).rand(X.shape[0])
+    q, b = _qb(pf, "tri")
+    model = pf.LinearElasticity(X, conn, [2, 3, 4, 5], None, {0: [0.0, -1.0]}, q, b, p=2.0)
+    Ks = model.compute_jacobian(rho).to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X, conn, "tri", rho=rho, p=2.0), orc.create_conn_dof(conn, 2))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    u = pf.Assembler(model).solve(method="cg")  # Assembler.solve assembles with rho = 1 (pyfem.py:2308)
+    uo, *_ = orc.solve_elasticity(X, conn, "tri", np.array([2, 3, 4, 5]), {0: [0.0, -1.0]})
+    assert relmax(u, uo) < U_TOL
+
+
+def test_too_many_neighbours_is_refused(pf):
+    """More than 64 neighbours per node is outside the pattern's 1-byte/6-bit position encoding: a clean error."""
+    X, conn = _fan_mesh(70)
+    q, b = _qb(pf, "tri")
+    with pytest.raises((RuntimeError, NotImplementedError, ValueError), match="64 neighbours"):
+        pf.LinearElasticity(X, conn, [2, 3], None, {0: [0.0, -1.0]}, q, b)
