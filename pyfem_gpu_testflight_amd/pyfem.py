@@ -285,9 +285,23 @@ class LinearPoisson(ModelBase):
             return out
         return DeviceCSR(self.hctx, vals)
 
+    @time_this
+    def _einsum_element_jacobian(self):
+        """Element matrices (nelems, P, P) on the device for the last density; the name (and its profiler key,
+        read by examples/SciTech2023/performance/performance_test.py:103-113) is the reference's, pyfem.py:1176.
+        Synchronises, so that the recorded time is the kernel's."""
+        Ke = self.hctx.element_matrices_poisson(self.p, self._last_rho)
+        self.hctx.torch.cuda.synchronize()
+        return Ke
+
+    @time_this
+    def _compute_element_jacobian(self, Ke):
+        """ref: pyfem.py:1189-1217 -- fills the caller's array in place (performance_test.py:52)."""
+        Ke[...] = self._einsum_element_jacobian().cpu().numpy()
+
     @property
     def Ke_mat(self):
-        return self.hctx.element_matrices_poisson(self.p, self._last_rho).cpu().numpy()
+        return self._einsum_element_jacobian().cpu().numpy()
 
     @time_this
     def compliance(self, rho, solver="cg", weighted=True):
@@ -391,10 +405,24 @@ class LinearElasticity(ModelBase):
             return out
         return DeviceCSR(self.hctx, vals)
 
+    @time_this
+    def _einsum_element_jacobian(self):
+        """Element matrices (nelems, D, D) on the device for the last density; the name (and its profiler key,
+        read by examples/SciTech2023/performance/performance_test.py:103-113) is the reference's, pyfem.py:2016.
+        Synchronises, so that the recorded time is the kernel's."""
+        Ke = self.hctx.element_matrices_elasticity(self.E, self.nu, self.p, self._last_rho)
+        self.hctx.torch.cuda.synchronize()
+        return Ke
+
+    @time_this
+    def _compute_element_jacobian(self, Ke):
+        """ref: pyfem.py:2030-2068 -- fills the caller's array in place (performance_test.py:52)."""
+        Ke[...] = self._einsum_element_jacobian().cpu().numpy()
+
     @property
     def Ke_mat(self):
-        """(nelems, 8|6, 8|6) element matrices for the last density (ref attribute: pyfem.py:717-723)."""
-        return self.hctx.element_matrices_elasticity(self.E, self.nu, self.p, self._last_rho).cpu().numpy()
+        """(nelems, D, D) element matrices for the last density (ref attribute: pyfem.py:717-723)."""
+        return self._einsum_element_jacobian().cpu().numpy()
 
     @time_this
     def compliance(self, rho, solver="cg"):
@@ -490,13 +518,27 @@ class Helmholtz(ModelBase):
     def compute_jacobian(self):
         return self.K
 
+    @time_this
+    def _einsum_element_jacobian(self):
+        """(Ke, Re) on the device, each (nelems, P, P); reference names pyfem.py:2127 / :2134 (one kernel here)."""
+        KR = self.hctx.element_matrices_helmholtz(self.r0)
+        self.hctx.torch.cuda.synchronize()
+        return KR
+
+    @time_this
+    def _compute_element_jacobian_and_rhs(self, Ke, Re):
+        """ref: pyfem.py:2139-2177 -- fills the caller's arrays in place."""
+        Kd, Rd = self._einsum_element_jacobian()
+        Ke[...] = Kd.cpu().numpy()
+        Re[...] = Rd.cpu().numpy()
+
     @property
     def Ke_mat(self):
-        return self.hctx.element_matrices_helmholtz(self.r0)[0].cpu().numpy()
+        return self._einsum_element_jacobian()[0].cpu().numpy()
 
     @property
     def Re(self):
-        return self.hctx.element_matrices_helmholtz(self.r0)[1].cpu().numpy()
+        return self._einsum_element_jacobian()[1].cpu().numpy()
 
 
 def _not_on_path(name, where):

@@ -687,3 +687,35 @@ def test_too_many_neighbours_is_refused(pf):
     q, b = _qb(pf, "tri")
     with pytest.raises((RuntimeError, NotImplementedError, ValueError), match="64 neighbours"):
         pf.LinearElasticity(X, conn, [2, 3], None, {0: [0.0, -1.0]}, q, b)
+
+
+def test_reference_profiler_keys_and_in_place_element_matrices(pf, orc):
+    """SciTech2023/performance/performance_test.py:52, 103-113: `model._compute_element_jacobian(model.Ke_mat)`
+    fills the array in place and `MyProfiler.saved_times["<Class>._einsum_element_jacobian"]` holds the times."""
+    from pyfem_gpu_testflight_amd import utils
+
+    utils.timer_on()
+    try:
+        c = pf.ProblemCreator(4, 3, 3, element_type="block")
+        q, b = _qb(pf, "block")
+        conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+        model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b, E=10.0, nu=0.3)
+        Ke = np.zeros((conn.shape[0], 24, 24))
+        model._compute_element_jacobian(Ke)
+        Ko = orc.elasticity_Ke(X, conn.astype(np.int64), "block")
+        assert np.abs(Ke - Ko).max() <= K_TOL * np.abs(Ko).max()
+        conn, X, fixed = c.create_poisson_problem()
+        pm = pf.LinearPoisson(X, conn, fixed, None, q, b, lambda x: 1.0, 1.0)
+        Kp = np.zeros((conn.shape[0], 8, 8))
+        pm._compute_element_jacobian(Kp)
+        assert np.abs(Kp - orc.poisson_Ke(X, conn.astype(np.int64), "block")).max() <= K_TOL * np.abs(Kp).max()
+        hm = pf.Helmholtz(0.05, X, conn, q, b)
+        Kh, Rh = np.zeros_like(Kp), np.zeros_like(Kp)
+        hm._compute_element_jacobian_and_rhs(Kh, Rh)
+        Ko, Ro = orc.helmholtz_Ke_Re(X, conn.astype(np.int64), "block", 0.05)
+        assert np.abs(Kh - Ko).max() <= K_TOL * np.abs(Ko).max() and np.abs(Rh - Ro).max() <= K_TOL * np.abs(Ro).max()
+        for key in ("LinearElasticity._einsum_element_jacobian", "LinearPoisson._einsum_element_jacobian",
+                    "Helmholtz._einsum_element_jacobian"):
+            assert len(utils.MyProfiler.saved_times[key]) >= 1
+    finally:
+        utils.timer_off()
