@@ -1,0 +1,46 @@
+"""Host-side utilities of the mirror module that need no GPU."""
+import numpy as np
+
+from oracle import pyfem_oracle as orc
+from pyfem_gpu_testflight_amd import utils
+
+
+def test_to_vtk_writes_a_readable_legacy_file(tmp_path):
+    conn, X = orc.structured_mesh3d(3, 3, 2)
+    u = np.arange(X.shape[0], dtype=float)
+    path = tmp_path / "block.vtk"
+    utils.to_vtk(conn, X, {"ux": u, "uy": 2 * u}, vtk_name=str(path))
+    lines = path.read_text().splitlines()
+    assert lines[3] == "DATASET UNSTRUCTURED_GRID" and lines[4] == f"POINTS {X.shape[0]} double"
+    pts = np.array([[float(v) for v in ln.split()] for ln in lines[5:5 + X.shape[0]]])
+    assert np.allclose(pts, X)
+    k = 5 + X.shape[0]
+    assert lines[k] == f"CELLS {conn.shape[0]} {conn.shape[0] * 9}"
+    cells = np.array([[int(v) for v in ln.split()] for ln in lines[k + 1:k + 1 + conn.shape[0]]])
+    assert np.all(cells[:, 0] == 8) and np.array_equal(cells[:, 1:], conn)
+    k += 1 + conn.shape[0]
+    assert lines[k] == f"CELL_TYPES {conn.shape[0]}" and set(lines[k + 1:k + 1 + conn.shape[0]]) == {"12"}
+    assert f"POINT_DATA {X.shape[0]}" in lines and "SCALARS ux float 1" in lines and "SCALARS uy float 1" in lines
+    # 2-D meshes get a zero z column; mixed meshes come as a dict
+    c2, X2 = orc.structured_mesh(3, 3, "quad")
+    c3, _ = orc.structured_mesh(3, 3, "tri")
+    utils.to_vtk({"quad": c2, "tri": c3[:2]}, X2, vtk_name=str(tmp_path / "mixed.vtk"))
+    txt = (tmp_path / "mixed.vtk").read_text().splitlines()
+    assert f"CELLS {c2.shape[0] + 2} {c2.shape[0] * 5 + 2 * 4}" in txt
+    assert txt[5].split()[2] in ("0", "0.0")
+
+
+def test_profiler_records_by_qualname():
+    class A:
+        @utils.time_this
+        def work(self):
+            return 7
+
+    utils.timer_off()
+    assert A().work() == 7 and "test_profiler_records_by_qualname.<locals>.A.work" not in utils.MyProfiler.saved_times
+    utils.timer_on()
+    try:
+        assert A().work() == 7
+        assert len(utils.MyProfiler.saved_times["test_profiler_records_by_qualname.<locals>.A.work"]) == 1
+    finally:
+        utils.timer_off()
