@@ -601,6 +601,21 @@ class Assembler:
     def solve_nonlinear(self, *a, **k):
         raise NotImplementedError("Newton solve (pyfem.py:2320-2355) is outside the accelerated hot path")
 
+    def plot(self, u, ax, **kwargs):
+        """Filled contours of a nodal scalar on a 2-D mesh (ref: pyfem.py:2358-2390; the examples end with it).
+        Quads are drawn as the two triangles (0,1,2) and (0,2,3)."""
+        import matplotlib.tri as tri
+
+        conn, X = self.model.conn, self.model.X
+        if self.model.nnodes_per_elem == 4:
+            triangles = np.concatenate([conn[:, [0, 1, 2]], conn[:, [0, 2, 3]]], axis=0)
+        elif self.model.nnodes_per_elem == 3:
+            triangles = conn
+        else:
+            raise ValueError("unsupported element type")
+        ax.set_aspect("equal")
+        ax.tricontourf(tri.Triangulation(X[:, 0], X[:, 1], triangles), np.asarray(u), **kwargs)
+
 
 # ------------------------------------------------------------------------------------------
 class ProblemCreator:

@@ -719,3 +719,23 @@ def test_reference_profiler_keys_and_in_place_element_matrices(pf, orc):
             assert len(utils.MyProfiler.saved_times[key]) >= 1
     finally:
         utils.timer_off()
+
+
+def test_assembler_plot_draws_quads_and_triangles(pf):
+    """examples/helmholtz/helmholtz_filter.py and examples/torque_arm/arm.py end with assembler.plot(u, ax)."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    for etype in ("quad", "tri"):
+        c = pf.ProblemCreator(nnodes_x=12, nnodes_y=9, element_type=etype)
+        conn, X, x = c.create_helmhotz_problem()
+        q, b = _qb(pf, etype)
+        model = pf.Helmholtz(0.1, X, conn, q, b)
+        u = model.apply(x)
+        fig, ax = plt.subplots()
+        pf.Assembler(model).plot(u, ax, levels=10)
+        assert len(ax.collections) > 0 or len(ax.get_children()) > 10
+        plt.close(fig)
+        assert abs(u.sum() / x.sum() - 1) < 0.2  # the filter roughly preserves the integral (helmholtz_filter.py:30-32)

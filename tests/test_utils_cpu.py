@@ -44,3 +44,61 @@ def test_profiler_records_by_qualname():
         assert len(utils.MyProfiler.saved_times["test_profiler_records_by_qualname.<locals>.A.work"]) == 1
     finally:
         utils.timer_off()
+
+
+_INP = """*Heading
+ synthetic
+*NODE
+3, 1.0, 1.0, 0
+1, 0.0, 0.0, 0
+2, 1.0, 0.0, 0
+4, 0.0, 1.0, 0
+** a comment line
+*ELEMENT, type=T3D2, ELSET=Line1
+1, 1, 2
+*ELEMENT, type=CPS3, ELSET=Surface1
+3, 3, 4, 1
+2, 1, 2, 3
+*ELSET,ELSET=load
+2,
+*NSET,NSET=load
+3, 4,
+*NSET,NSET=fixed
+1,
+2
+"""
+
+
+def test_inp_parser_conventions(tmp_path):
+    from pyfem_gpu_testflight_amd.parse_inp import InpParser
+
+    path = tmp_path / "mesh.inp"
+    path.write_text(_INP)
+    conn, X, groups = InpParser(str(path)).parse()
+    assert list(conn) == ["CPS3"] and np.array_equal(conn["CPS3"], [[0, 1, 2], [2, 3, 0]])  # sorted by element id
+    assert np.array_equal(X, [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])  # sorted by node id, 3 coordinates
+    assert np.array_equal(groups["load"], [2, 3]) and np.array_equal(groups["fixed"], [0, 1])
+    p = InpParser(str(path))
+    p.to_vtk({"t": np.arange(4.0)})
+    assert (tmp_path / "mesh.vtk").read_text().count("SCALARS t float 1") == 1
+
+
+def test_inp_parser_reads_the_reference_arm_mesh_like_the_reference():
+    """When the reference checkout is present (build container only): arm.inp through this parser gives the mesh
+    and groups the reference's own parser produced for the committed fixture (oracle/gen_golden.py)."""
+    import os
+
+    import pytest
+
+    from pyfem_gpu_testflight_amd.parse_inp import InpParser
+    from tests._golden import load
+
+    path = "/root/reference/examples/torque_arm/arm.inp"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    conn, X, groups = InpParser(path).parse()
+    g = load("arm_tri")
+    assert np.array_equal(conn["CPS3"], g["conn"]) and np.array_equal(X[:, :2], g["X"])
+    fixed = np.concatenate((2 * groups["fixed"], 2 * groups["fixed"] + 1))
+    assert np.array_equal(np.sort(fixed), np.sort(g["dof_fixed"]))
+    assert np.array_equal(np.sort(groups["load"]), np.sort(g["force_nodes"]))
