@@ -171,6 +171,15 @@ int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rt
  * silently uses Jacobi instead.  pf_amg_info reports the hierarchy of the last AMG solve (HOST outputs,
  * arrays of length cap). */
 int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);
+/* The same V-cycle as a stand-alone operator for drivers with their own Krylov loop (dist.py: one local AMG per
+ * rank in an additive Schwarz preconditioner).  prepare: numeric setup for vals (reuse as in PF_PRECOND_AMG_REUSE;
+ * PF_E_UNSUPPORTED if not positive definite).  vcycle: z = M^-1 r (device vectors of length nrows, z != r),
+ * asynchronous on the ctx stream. */
+int pf_amg_prepare(pf_ctx* ctx, const double* vals, int reuse);
+/* vals[diagonal entry of dof q] += add[q] (add: nrows doubles): the Schwarz driver completes the interface
+ * diagonals of a rank's block so that its local problem is definite */
+int pf_add_to_diag(pf_ctx* ctx, double* vals, const double* add);
+int pf_amg_vcycle(pf_ctx* ctx, const double* r, double* z);
 
 /* Building blocks for the one-process-per-GPU driver (pyfem_gpu_testflight_amd/dist.py): the
  * single-reduction (Chronopoulos-Gear) Jacobi-PCG.  ONE all-reduce per iteration carries the

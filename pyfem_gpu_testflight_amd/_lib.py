@@ -56,6 +56,9 @@ SIGNATURES = {
     "pf_cg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.c_int, C.POINTER(_i32),
                         C.POINTER(_f64)]),
     "pf_amg_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_f64), C.c_int]),
+    "pf_amg_prepare": (C.c_int, [_vp, _vp, C.c_int]),
+    "pf_amg_vcycle": (C.c_int, [_vp, _vp, _vp]),
+    "pf_add_to_diag": (C.c_int, [_vp, _vp, _vp]),
     "pf_dot": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_copy_indexed": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "pf_spmv_dot": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -72,7 +72,7 @@ struct pf_amg {
   double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
   int64_t dense_m = 0;
   double* gersh = nullptr;      // scratch vector for the power iteration
-  double* lam = nullptr;        // device: per-level |D^-1 A v|^2 + the not-SPD flag (AMG_MAX_LEVELS + 1 doubles)
+  double* lam = nullptr;        // device: per-level |D^-1 A v|^2, the not-SPD flag, the finest diagonal scale
   bool numeric_ok = false;      // the numeric setup below matches L[0].vals
   int sa_mode = 1;              // PF_AMG_SA: 0 tentative P on the fly everywhere (plain aggregation), 2 smoothed
                                 // aggregation (stored P) on every level, 1 (default) smoothed except on the finest
@@ -255,7 +255,8 @@ static void sa_pattern_host(int64_t n, const std::vector<int32_t>& ptr, const st
 template <int D>
 __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                            const double* __restrict__ vals, uint8_t* __restrict__ iso,
-                           double* __restrict__ diag, double* __restrict__ bad) {
+                           double* __restrict__ diag, double* __restrict__ bad, double* __restrict__ scale,
+                           int finest) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   double off[D], dg[D];
@@ -272,13 +273,23 @@ __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int
         else off[k] += fabs(a[k * D + l]);
       }
   }
+  double rmax = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) rmax = fmax(rmax, fabs(dg[k]) + off[k]);
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    iso[D * i + k] = (off[k] == 0.0) ? 1 : 0;
-    if (dg[k] == 0.0) dg[k] = 1.0;  // empty / decoupled coarse dof: identity
+    // An empty coarse dof -- e.g. the rotation of a one-node aggregate, whose column of P is zero -- comes out of the
+    // triple product as rounding noise of either sign: treat a row that is negligible against its node's other rows
+    // as decoupled (identity), not as evidence of an indefinite matrix.
+    const bool empty = fabs(dg[k]) + off[k] <= 1e-12 * (finest ? rmax : fmax(rmax, scale[0]));
+    iso[D * i + k] = (off[k] == 0.0 || empty) ? 1 : 0;
+    if (dg[k] == 0.0 || empty) dg[k] = 1.0;
     if (!(dg[k] > 0.0)) bad[0] = 1.0;  // benign race: every writer stores the same value
     diag[D * i + k] = dg[k];
   }
+  // the finest level leaves the size of its largest diagonal entry for the coarse levels' emptiness test
+  // (positive doubles order like their bit patterns)
+  if (finest && rmax > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scale), (unsigned long long)__double_as_longlong(rmax));
 }
 
 // lam2[0] = |D^-1 A v|^2 of the last power iteration; omega = scale * 4 / (3 * 1.1 * lambda_max)
@@ -925,7 +936,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   int64_t maxdof = 1;
   for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
   PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
-  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 1)));
+  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 2)));  // + not-SPD flag + diagonal scale
   return PF_OK;
 }
 
@@ -1003,14 +1014,14 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (const char* e = getenv("PF_AMG_OVER_SA")) H->over_sa = atof(e);
   if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
   double* bad = H->lam + AMG_MAX_LEVELS;
-  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 1), ctx->stream));
+  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 2), ctx->stream));
   for (int l = 0; l < H->nlevels; ++l) {
     AmgLevel& Lv = H->L[l];
     const unsigned gr = (unsigned)cdiv(Lv.n, 256);
-    if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
-    else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
-    else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
-    else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad);
+    if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
+    else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
+    else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
+    else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
     PF_LAUNCH_CHECK();
     // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
     // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
@@ -1072,6 +1083,11 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   double h[AMG_MAX_LEVELS + 1];
   PF_HIP(hipMemcpyAsync(h, H->lam, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipStreamSynchronize(ctx->stream));
+  if (getenv("PF_AMG_VERBOSE")) {
+    fprintf(stderr, "[pf_amg] numeric setup: not-SPD flag %g, lambda_max^2 per level:", h[AMG_MAX_LEVELS]);
+    for (int l = 0; l < H->nlevels; ++l) fprintf(stderr, " %g", h[l]);
+    fprintf(stderr, "\n");
+  }
   if (h[AMG_MAX_LEVELS] != 0.0) return PF_E_UNSUPPORTED;  // not positive definite
   for (int l = 0; l < H->nlevels; ++l) {
     const double lam = 1.1 * sqrt(h[l]);
@@ -1207,4 +1223,23 @@ extern "C" int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(nlevels && nodes && dofs_per_node && omega && cap > 0, "pf_amg_info: NULL argument");
   return pf_amg_describe(ctx, nlevels, nodes, dofs_per_node, omega, cap);
+}
+
+// The V-cycle as a stand-alone operator, for drivers that run their own Krylov loop (dist.py: one local AMG per
+// rank inside an additive Schwarz preconditioner).  pf_amg_prepare = numeric setup for `vals` (PF_E_UNSUPPORTED if
+// the matrix has a non-positive diagonal entry); pf_amg_vcycle: z = M^-1 r, both of length nrows, z != r.
+extern "C" int pf_amg_prepare(pf_ctx* ctx, const double* vals, int reuse) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && vals, "pf_amg_prepare: no pattern / NULL argument");
+  PF_HIP(hipSetDevice(ctx->device));
+  const int rc = pf_amg_setup(ctx, vals, reuse);
+  if (rc == PF_E_UNSUPPORTED) return pf_fail(ctx, rc, "pf_amg_prepare: the matrix has a non-positive diagonal entry");
+  return rc;
+}
+
+extern "C" int pf_amg_vcycle(pf_ctx* ctx, const double* r, double* z) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(r && z && r != z, "pf_amg_vcycle: NULL argument or z aliases r");
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok, "pf_amg_vcycle: call pf_amg_prepare first");
+  return pf_amg_apply(ctx, r, z);
 }

@@ -309,6 +309,17 @@ __global__ void k_extract_diag(int64_t nnodes, const int32_t* __restrict__ nptr,
   }
 }
 
+// vals[diagonal of dof q] += add[q]
+template <int D>
+__global__ void k_add_to_diag(int64_t nnodes, const int32_t* __restrict__ nptr, const uint8_t* __restrict__ diagpos,
+                              double* __restrict__ vals, const double* __restrict__ add) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  const int64_t b = ((int64_t)nptr[n] + diagpos[n]) * D * D;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vals[b + k * D + k] += add[D * n + k];
+}
+
 // apply_dirichlet_bcs (pyfem.py:781-835); one lane owns the d rows of one node
 template <int D>
 __global__ void k_apply_dirichlet(int64_t nnodes, const int32_t* __restrict__ nptr, const int32_t* __restrict__ nidx,
@@ -597,6 +608,17 @@ extern "C" int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag) {
   if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
   else if (ctx->d == 3) k_extract_diag<3><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
   else k_extract_diag<2><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, diag, 0);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_add_to_diag(pf_ctx* ctx, double* vals, const double* add) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && vals && add, "pf_add_to_diag: no pattern / NULL argument");
+  const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
+  if (ctx->d == 1) k_add_to_diag<1><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, add);
+  else if (ctx->d == 3) k_add_to_diag<3><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, add);
+  else k_add_to_diag<2><<<g, 256, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, add);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -49,6 +49,9 @@ def test_partitioned_single_rank():
     u_ref = _reference_u("quad", conn, X, dof_fixed, force, rho, 3.0)
     assert np.abs(u - u_ref).max() < 1e-8 * np.abs(u_ref).max()
     assert pm.last_iters > 10
+    x = pm.solve(rho=rho, rtol=1e-12, precond="amg")  # one rank: plain AMG-PCG through the distributed driver
+    assert np.abs(pm.gather_global(x).cpu().numpy() - u_ref).max() < 1e-8 * np.abs(u_ref).max()
+    assert pm.last_iters < 40
 
 
 def _worker(rank, world, port, etype):
@@ -74,6 +77,19 @@ def _worker(rank, world, port, etype):
         u_ref = _reference_u(etype, conn, X, dof_fixed, force, rho, 3.0)
         err = np.abs(u - u_ref).max() / np.abs(u_ref).max()
         assert err < 1e-8, err
+        it_jacobi = pm.last_iters
+        # additive Schwarz with one local AMG V-cycle per rank: same solution on any partition ...
+        x = pm.solve(rho=rho, rtol=1e-12, precond="amg")
+        u = pm.gather_global(x).cpu().numpy()
+        err = np.abs(u - u_ref).max() / np.abs(u_ref).max()
+        assert err < 1e-8, err
+        # ... and far fewer iterations once the blocks are compact (scattered element ids: sort by centroid first)
+        pc = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0, elem_order="centroid")
+        x = pc.solve(rho=rho, rtol=1e-12, precond="amg")
+        u = pc.gather_global(x).cpu().numpy()
+        assert np.abs(u - u_ref).max() / np.abs(u_ref).max() < 1e-8
+        assert pc.iface.G < pm.iface.G or etype == "quad"
+        assert pc.last_iters * 3 < it_jacobi, (pc.last_iters, it_jacobi)
     finally:
         dist.destroy_process_group()
 
