@@ -739,3 +739,55 @@ def test_assembler_plot_draws_quads_and_triangles(pf):
         assert len(ax.collections) > 0 or len(ax.get_children()) > 10
         plt.close(fig)
         assert abs(u.sum() / x.sum() - 1) < 0.2  # the filter roughly preserves the integral (helmholtz_filter.py:30-32)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_problems_match_oracle(pf, orc, seed):
+    """Seeded random problems: element type, mesh size, distortion, nodal density, RAMP penalty, the set of fixed dofs
+    with prescribed values and the loads are all drawn at random; K entry by entry, the BC'd operator and the
+    solution are held to the oracle at the product bars."""
+    rng = np.random.RandomState(1000 + seed)
+    etype = ["quad", "tri", "block"][seed % 3]
+    if etype == "block":
+        shape = tuple(rng.randint(2, 8, size=3))
+        conn, X = orc.structured_mesh3d(*shape)
+    else:
+        shape = tuple(rng.randint(2, 24, size=2))
+        conn, X = orc.structured_mesh(shape[0], shape[1], etype)
+    nd = X.shape[1]
+    X = X + (0.25 / max(shape)) * (rng.rand(*X.shape) - 0.5)
+    if rng.rand() < 0.5:  # random renumbering of nodes and elements
+        perm = rng.permutation(X.shape[0])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(X.shape[0])
+        X, conn = X[perm], inv[conn][rng.permutation(conn.shape[0])]
+    rho = 0.05 + 0.95 * rng.rand(X.shape[0])
+    p = float(rng.choice([0.0, 1.0, 5.0]))
+    ndof = nd * X.shape[0]
+    # fix all dofs of a few nodes (enough to remove the rigid-body modes) plus a random handful of single dofs
+    nodes = rng.choice(X.shape[0], size=min(X.shape[0] - 1, 4), replace=False)
+    fixed = np.unique(np.concatenate([(nd * nodes[:, None] + np.arange(nd)).ravel(), rng.choice(ndof, size=3)]))
+    vals = 0.01 * (rng.rand(fixed.size) - 0.5) if rng.rand() < 0.5 else None
+    load_nodes = rng.choice(np.setdiff1d(np.arange(X.shape[0]), nodes), size=2, replace=False)
+    force = {int(n): list(rng.rand(nd) - 0.5) for n in load_nodes}
+    q, b = _qb(pf, etype)
+    model = pf.LinearElasticity(X, conn, fixed, vals, force, q, b, p=p)
+    K = model.compute_jacobian(rho)
+    Ks = K.to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X, conn.astype(np.int64), etype, rho=rho, p=p),
+                          orc.create_conn_dof(conn.astype(np.int64), nd))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    rhs = model.compute_rhs()
+    assert np.array_equal(rhs, orc.elasticity_rhs(ndof, force))
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+    Kb, rb = orc.apply_dirichlet_bcs(Ko, orc.elasticity_rhs(ndof, force), fixed, vals, True)
+    v = rng.rand(ndof)
+    assert relmax(K.dot(v), Kb.dot(v)) < K_TOL and np.abs(rhs - rb).max() <= 1e-12 * max(1.0, np.abs(rb).max())
+    from scipy.sparse.linalg import spsolve
+
+    u_ref = spsolve(Kb.tocsc(), rb)
+    asm = pf.Assembler(model)
+    for method in ("cg", "direct"):
+        u = asm._solve_linear_system(K, rhs, method)
+        assert relmax(u, u_ref) < U_TOL, (etype, shape, method)
