@@ -248,6 +248,8 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_amg_free(ctx);
   pf_free(ctx->nptr);
   pf_free(ctx->nidx);
+  pf_free(ctx->nidx16);
+  ctx->nidx16_state = 0;
   pf_free(ctx->n2e_ptr);
   pf_free(ctx->n2e);
   pf_free(ctx->n2e_pos);

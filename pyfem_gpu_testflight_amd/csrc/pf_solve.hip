@@ -90,7 +90,7 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 //   d=1 moves a third of the bytes of d=2 per node, so it takes R=2 / U=6 to amortise the per-tile
 //   overhead (r01: 50 % of peak at R=1/U=3).
 // ------------------------------------------------------------------------------------------
-template <int D, int R, int U, int CH>
+template <int D, int R, int U, int CH, bool IDX16 = false>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
@@ -127,7 +127,10 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           g[u] = min(g0 + 64 * u, c1 - 1);  // clamped: loads stay in range, result discarded
-          m[u] = nidx[g[u]];
+          if constexpr (IDX16)  // 2-byte offsets from the tile's first node: 10 instead of 12 bytes per nonzero
+            m[u] = (int32_t)(tile * TILE) + reinterpret_cast<const int16_t*>(nidx)[g[u]];
+          else
+            m[u] = nidx[g[u]];
         }
         if constexpr (D == 1) {
           double kv[U], xv[U];
@@ -567,6 +570,40 @@ static inline unsigned spmv_grid_d(int64_t nnodes, int d) {
 }
 static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
 
+// 16-bit column offsets for the scalar SpMV (bytes per nonzero 12 -> 10): neighbour id minus the first node of the
+// row's tile.  Fits whenever the numbering keeps neighbours within +-32 k node ids (any mesh with a sensible
+// ordering); otherwise flag[0] is raised and the 32-bit indices stay in use.
+__global__ void k_build_idx16(int64_t nnodes, int tile_nodes, const int32_t* __restrict__ nptr,
+                              const int32_t* __restrict__ nidx, int16_t* __restrict__ out, int32_t* __restrict__ flag) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  const int64_t base = (n / tile_nodes) * tile_nodes;
+  for (int32_t g = nptr[n]; g < nptr[n + 1]; ++g) {
+    const int64_t rel = (int64_t)nidx[g] - base;
+    if (rel < -32768 || rel > 32767) { flag[0] = 1; return; }
+    out[g] = (int16_t)rel;
+  }
+}
+
+static int ensure_idx16(pf_ctx* ctx) {
+  if (ctx->nidx16_state) return PF_OK;
+  const char* e = getenv("PF_SPMV_IDX16");
+  if (e && atoi(e) == 0) { ctx->nidx16_state = -1; return PF_OK; }
+  int32_t* flag = nullptr;
+  PF_HIP(hipMalloc(&ctx->nidx16, sizeof(int16_t) * (size_t)std::max<int64_t>(1, ctx->nblocks)));
+  PF_HIP(hipMalloc(&flag, sizeof(int32_t)));
+  PF_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx->stream));
+  k_build_idx16<<<(unsigned)cdiv(ctx->nnodes, 256), 256, 0, ctx->stream>>>(ctx->nnodes, SPMV_TILE1, ctx->nptr, ctx->nidx,
+                                                                          ctx->nidx16, flag);
+  int32_t f = 0;
+  PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(flag);
+  ctx->nidx16_state = f ? -1 : 1;
+  if (f) { pf_free(ctx->nidx16); }
+  return PF_OK;
+}
+
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
                    const double* sm_dinv, const double* sm_b) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
@@ -586,8 +623,14 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
 #endif
   if (ctx->d == 3)
     k_spmv3<<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
-  else if (ctx->d == 1)
-    k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+  else if (ctx->d == 1) {
+    if (int rc16 = ensure_idx16(ctx)) return rc16;
+    if (ctx->nidx16_state == 1)
+      k_spmv<PF_SPMV1, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
+                                                          vals, x, y, dot_part, sm_dinv, sm_b);
+    else
+      k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+  }
   else
     k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   PF_LAUNCH_CHECK();
