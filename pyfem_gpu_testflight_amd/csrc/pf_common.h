@@ -32,8 +32,8 @@ struct pf_ctx {
   int32_t max_valence = 0;     // max elements around a node
   int32_t* nptr = nullptr;   // (nnodes+1) node-graph row pointer
   int32_t* nidx = nullptr;   // (nblocks)  neighbour node ids, ascending per row
-  int16_t* nidx16 = nullptr; // (nblocks)  scalar SpMV only: neighbour id minus the first node of the row's 128-row
-  int nidx16_state = 0;      //            SpMV tile; state 0 not tried, 1 usable, -1 some offset does not fit 16 bits
+  int16_t* nidx16 = nullptr; // (nblocks)  d = 1, 2: neighbour id minus the first node of the row's SpMV tile (128 / 64
+  int nidx16_state = 0;      //            rows); state 0 not tried, 1 usable, -1 some offset does not fit 16 bits
   int32_t* n2e_ptr = nullptr;  // (nnodes+1) node -> incident (element, local index) list
   int32_t* n2e = nullptr;      // (nelems*P) entries e*P + a, ascending per node
   uint8_t* n2e_pos = nullptr;  // (nelems*P*PS) PS = 4 (8 for blocks) bytes per incident pair j; byte b (< P):

@@ -570,7 +570,8 @@ static inline unsigned spmv_grid_d(int64_t nnodes, int d) {
 }
 static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
 
-// 16-bit column offsets for the scalar SpMV (bytes per nonzero 12 -> 10): neighbour id minus the first node of the
+// 16-bit column offsets for the d = 1 and d = 2 products (12 -> 10 bytes per scalar nonzero, 36 -> 34 per 2x2 block):
+// neighbour id minus the first node of the
 // row's tile.  Fits whenever the numbering keeps neighbours within +-32 k node ids (any mesh with a sensible
 // ordering); otherwise flag[0] is raised and the 32-bit indices stay in use.
 __global__ void k_build_idx16(int64_t nnodes, int tile_nodes, const int32_t* __restrict__ nptr,
@@ -593,8 +594,8 @@ static int ensure_idx16(pf_ctx* ctx) {
   PF_HIP(hipMalloc(&ctx->nidx16, sizeof(int16_t) * (size_t)std::max<int64_t>(1, ctx->nblocks)));
   PF_HIP(hipMalloc(&flag, sizeof(int32_t)));
   PF_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), ctx->stream));
-  k_build_idx16<<<(unsigned)cdiv(ctx->nnodes, 256), 256, 0, ctx->stream>>>(ctx->nnodes, SPMV_TILE1, ctx->nptr, ctx->nidx,
-                                                                          ctx->nidx16, flag);
+  k_build_idx16<<<(unsigned)cdiv(ctx->nnodes, 256), 256, 0, ctx->stream>>>(ctx->nnodes, ctx->d == 1 ? SPMV_TILE1 : SPMV_TILE2,
+                                                                          ctx->nptr, ctx->nidx, ctx->nidx16, flag);
   int32_t f = 0;
   PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipStreamSynchronize(ctx->stream));
@@ -631,8 +632,14 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
     else
       k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   }
-  else
-    k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+  else {
+    if (int rc16 = ensure_idx16(ctx)) return rc16;
+    if (ctx->nidx16_state == 1)
+      k_spmv<PF_SPMV2, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
+                                                          vals, x, y, dot_part, sm_dinv, sm_b);
+    else
+      k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+  }
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
