@@ -2,7 +2,7 @@
    python tools/bench3d.py [n ...]      prints one JSON object per size"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from pyfem_gpu_testflight_amd import pyfem, _lib
 
 for n in [int(a) for a in sys.argv[1:]] or [64, 96, 128]:

@@ -1,7 +1,7 @@
 """dist_cg (world 1) against the native pf_cg on a 1/8 strip of the 4M-quad mesh: host overhead of the distributed driver."""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import torch
 from pyfem_gpu_testflight_amd import pyfem
 from pyfem_gpu_testflight_amd.dist import PartitionedElasticity, dist_cg
 for nx, ny in ((2048, 2048), (2048, 256)):

@@ -1,6 +1,6 @@
 """What this box's HBM gives a plain kernel: fill (write-only), copy (read+write), sum (read-only) of the
 K value array size (1.208 GB).  Context for the assembly roofline (its traffic is 78 % writes)."""
-import torch, time
+import torch
 n = 151044100
 a = torch.empty(n, dtype=torch.float64, device="cuda")
 b = torch.empty(n, dtype=torch.float64, device="cuda")

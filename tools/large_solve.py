@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PF_AMG_VERBOSE", "1")
-import numpy as np, torch
+import torch
 from pyfem_gpu_testflight_amd import pyfem, _lib
 nx = int(os.environ.get("NX", 5120))
 t0 = time.perf_counter()
