@@ -90,6 +90,11 @@ def _worker(rank, world, port, etype):
         assert np.abs(u - u_ref).max() / np.abs(u_ref).max() < 1e-8
         assert pc.iface.G < pm.iface.G or etype == "quad"
         assert pc.last_iters * 3 < it_jacobi, (pc.last_iters, it_jacobi)
+        it_one = pc.last_iters
+        x = pc.solve(rho=rho, rtol=1e-12, precond="amg2")  # + global rigid-body coarse space on a grid of bins
+        u = pc.gather_global(x).cpu().numpy()
+        assert np.abs(u - u_ref).max() / np.abs(u_ref).max() < 1e-8
+        assert pc.last_iters <= it_one, (pc.last_iters, it_one)
     finally:
         dist.destroy_process_group()
 

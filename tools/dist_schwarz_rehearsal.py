@@ -19,9 +19,9 @@ def worker(rank, world, port, nx, ny):
     rho = 0.3 + 0.7 * np.random.RandomState(1).rand(X.shape[0])
     pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
     out = {}
-    for pc in ("amg", "jacobi"):
+    for pc in ("amg2", "amg", "jacobi"):
         torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
-        x = pm.solve(rho=rho, rtol=1e-8, precond=pc, check_every=(1 if pc == "amg" else 100))
+        x = pm.solve(rho=rho, rtol=1e-8, precond=pc, check_every=(100 if pc == "jacobi" else 1))
         torch.cuda.synchronize(); dist.barrier()
         out[pc] = (pm.last_iters, time.perf_counter() - t0)
     if rank == 0:
