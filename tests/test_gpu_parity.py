@@ -791,3 +791,36 @@ def test_randomised_problems_match_oracle(pf, orc, seed):
     for method in ("cg", "direct"):
         u = asm._solve_linear_system(K, rhs, method)
         assert relmax(u, u_ref) < U_TOL, (etype, shape, method)
+
+
+@pytest.mark.parametrize("kind", ["elasticity3d", "poisson3d", "poisson2d"])
+def test_sensitivity_is_the_derivative_of_the_assembled_operator(pf, kind):
+    """The reference checks _compute_K_dv_sens against a complex-step derivative of compute_jacobian
+    (tests/test_elements.py:21-56, tests/test_elasticity.py:68-104).  The kernels are fp64-real, so the same identity
+    is checked with a central difference:  p . d(phi^T K(rho) psi)/d rho  =  d/dh phi^T K(rho + h p) psi."""
+    rng = np.random.RandomState(3)
+    if kind == "poisson2d":
+        c = pf.ProblemCreator(9, 7)
+        q, b = _qb(pf, "quad")
+        conn, X, fixed = c.create_poisson_problem()
+        model = pf.LinearPoisson(X, conn, fixed, None, q, b, lambda x: 1.0 + 0 * x[..., 0], p=5.0)
+        nd = 1
+    else:
+        c = pf.ProblemCreator(5, 4, 4, element_type="block")
+        q, b = _qb(pf, "block")
+        if kind == "poisson3d":
+            conn, X, fixed = c.create_poisson_problem()
+            model = pf.LinearPoisson(X, conn, fixed, None, q, b, lambda x: 1.0 + 0 * x[..., 0], p=5.0)
+            nd = 1
+        else:
+            conn, X, fixed, force = c.create_linear_elasticity_problem()
+            model = pf.LinearElasticity(X, conn, fixed, None, force, q, b, p=5.0)
+            nd = 3
+    n = X.shape[0]
+    phi, psi = rng.rand(nd * n), rng.rand(nd * n)
+    rho, dv = 0.2 + 0.7 * rng.rand(n), rng.rand(n)
+    dfdrho = dv.dot(model._compute_K_dv_sens(rho, phi, psi))
+    h = 1e-6
+    f = lambda r: phi.dot(model.compute_jacobian(r).dot(psi))  # noqa: E731
+    fd = (f(rho + h * dv) - f(rho - h * dv)) / (2 * h)
+    assert abs(dfdrho - fd) <= 1e-7 * abs(fd), (dfdrho, fd)
