@@ -666,6 +666,7 @@ __global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32
           int pos = 0;
           for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
             const int32_t J = pidx[s2];
+            if (J < (int32_t)I) continue;  // A_c is symmetric: the lower triangle is mirrored by k_sa_mirror_lower
             while (pos < clen - 1 && crow[pos] != J) ++pos;
             const double* Pm = pvals + (int64_t)s2 * DR * DC;
 #pragma unroll
@@ -683,6 +684,27 @@ __global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32
     }
     double* dst = cvals + (int64_t)cb * DC * DC;
     for (int q = lane; q < clen * DC * DC; q += 64) dst[q] = cacc[q];
+  }
+}
+
+// C[I,J] = C[J,I]^T for J < I, after k_sa_galerkin_wave has filled the upper triangle (halves its LDS adds)
+template <int DC>
+__global__ void k_sa_mirror_lower(int64_t nc, const int32_t* __restrict__ cptr, const int32_t* __restrict__ cidx,
+                                  double* __restrict__ cvals) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  for (int32_t pos = cptr[I]; pos < cptr[I + 1]; ++pos) {
+    const int32_t J = cidx[pos];
+    if (J >= (int32_t)I) break;  // ascending columns: the rest is the upper triangle
+    int32_t q = cptr[J];
+    const int32_t qe = cptr[J + 1];
+    while (q < qe - 1 && cidx[q] != (int32_t)I) ++q;
+    const double* src = cvals + (int64_t)q * DC * DC;
+    double* dst = cvals + (int64_t)pos * DC * DC;
+#pragma unroll
+    for (int c = 0; c < DC; ++c)
+#pragma unroll
+      for (int c2 = 0; c2 < DC; ++c2) dst[c * DC + c2] = src[c2 * DC + c];
   }
 }
 
@@ -1038,10 +1060,11 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
                                                                    Nx.xy, Lv.dinv, H->lam + l, Lv.pptr, Lv.pidx, Lv.pvals)
 #define PF_SAG(DR_, DC_)                                                                                         \
         do {                                                                                                     \
-          if (Lv.max_crow <= 64)                                                                                 \
+          if (Lv.max_crow <= 64) {                                                                               \
             k_sa_galerkin_wave<DR_, DC_><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>(     \
                 Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
-          else                                                                                                   \
+            k_sa_mirror_lower<DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Nx.ptr, Nx.idx, Nx.vals);                  \
+          } else                                                                                                   \
             k_sa_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, \
                                                                 Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
           const int bs_ = DR_ * DC_;                                                                             \
