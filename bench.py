@@ -218,15 +218,16 @@ def main():
 
     # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command
     # (profiles/r01_pmc_summary.json: WRITE_SIZE + FETCH_SIZE in KB, separate passes; FETCH_SIZE of the
-    # 16-B/lane SpMV stream doubled as MI355X_MICROARCH.md prescribes, the assembly's mixed-width reads
-    # left raw = a lower bound).  null when the summary is missing or the mesh is not the profiled one.
+    # 16-B/lane SpMV stream doubled as MI355X_MICROARCH.md prescribes; of the assembly's reads only the visit-record
+    # stream is a 16-B/lane coalesced read, so the half of its 16 B x (4 nelems) that the counter misses is added back,
+    # the gathers are left as counted).  null when the summary is missing or the mesh is not the profiled one.
     traffic_asm = traffic_spmv = None
     try:
         if nx == 2048 and world == 1:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             for k, v in pm.items():
                 if "k_assemble_v3" in k:
-                    traffic_asm = 1024.0 * (v["WRITE_SIZE"] + v["FETCH_SIZE"])
+                    traffic_asm = 1024.0 * (v["WRITE_SIZE"] + v["FETCH_SIZE"]) + 0.5 * 16.0 * 4 * h.nelems
                 if "k_spmv" in k:
                     traffic_spmv = 1024.0 * (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"])
     except Exception:
