@@ -39,7 +39,8 @@ struct AmgLevel {
   bool owns_graph = false;
   int64_t nblk = 0;
   double* vals = nullptr;    // block values (level 0: the caller's matrix, not owned)
-  double* dinv = nullptr;    // omega / diag per dof
+  double* dinv = nullptr;    // omega_1 / diag per dof (raw diagonal during the numeric setup)
+  double* dinv2 = nullptr;   // omega_2 / diag: second factor of the two-step smoother
   uint8_t* iso = nullptr;    // 1 = decoupled dof (row has no off-diagonal entries)
   double* xy = nullptr;      // node coordinates (n,dim) (level 0 aliases ctx->X)
   bool owns_xy = false;
@@ -82,6 +83,7 @@ struct pf_amg {
   double over = 2.0;            // scaling of the coarse-grid correction: plain aggregation under-corrects.
                                 // 2048^2 plane stress, rtol 1e-8 (tools/amg_sweep.py): V(1,1)/1.0 180 its 572 ms,
                                 // V(2,2)/2.0 60 its 231 ms, Jacobi-PCG 16 380 its 7.3 s.  Any value > 0 keeps M SPD.
+  double cheb = 4.4;            // PF_AMG_CHEB: the two sweeps target [lambda_max / cheb, lambda_max]; <= 1: equal factors
   double over_sa = 1.0;         // the same for levels with a smoothed prolongator: no over-correction needed
   double omega_scale = 1.0;
 };
@@ -292,12 +294,26 @@ __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int
   if (finest && rmax > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(scale), (unsigned long long)__double_as_longlong(rmax));
 }
 
-// lam2[0] = |D^-1 A v|^2 of the last power iteration; omega = scale * 4 / (3 * 1.1 * lambda_max)
-__global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ lam2, double scale, double* __restrict__ d,
-                                 const uint8_t* __restrict__ iso) {
+// Damping factors of the smoother from lam2[0] = |D^-1 A v|^2 of the last power iteration (b = 1.1 lambda_max):
+//   cheb == 0: plain damped Jacobi, both factors 4 / (3 b);
+//   cheb > 1:  the two sweeps of a V(2,2) side are the degree-2 Chebyshev polynomial on [b / cheb, b]: factors
+//              1 / (c +- h cos(pi/4)), c = (a + b)/2, h = (b - a)/2.  Same cost as two equal sweeps; the worst
+//              damping on that interval is 1/T_2((b+a)/(b-a)) (0.25 for cheb = 4.4) instead of 0.49.
+__global__ void k_amg_scale_dinv(int64_t n, const double* __restrict__ lam2, double scale, double cheb,
+                                 double* __restrict__ d, double* __restrict__ d2, const uint8_t* __restrict__ iso) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const double omega = scale * 4.0 / (3.3 * sqrt(lam2[0]));
-  if (i < n) d[i] = (iso[i] ? 1.0 : omega) / d[i];  // decoupled dofs are solved exactly
+  const double bb = 1.1 * sqrt(lam2[0]);
+  double w1 = scale * 4.0 / (3.0 * bb), w2 = w1;
+  if (cheb > 1.0) {
+    const double aa = bb / cheb, c = 0.5 * (aa + bb), h = 0.5 * (bb - aa) * 0.70710678118654752;
+    w1 = scale / (c + h);
+    w2 = scale / (c - h);
+  }
+  if (i < n) {  // decoupled dofs are solved exactly
+    const double dg = d[i];
+    d[i] = (iso[i] ? 1.0 : w1) / dg;
+    d2[i] = (iso[i] ? 1.0 : w2) / dg;
+  }
 }
 
 // tentative prolongator row block P_n (DR x DC) for node n at offset r from its aggregate's centroid
@@ -399,13 +415,14 @@ __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, con
 // MODE fuses the smoother into the product (the coarse levels are launch-bound, every fused pass counts):
 //   AMG_AX   y = A x                         AMG_RESID  y = b - A x
 //   AMG_SMOOTH y = x + dinv .* (b - A x)     (one damped-Jacobi sweep, y != x)
-//   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv .* (b - A x1)
+//   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv2 .* (b - A x1)
 enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
 template <int D, int MODE>
 __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
                                                  const int32_t* __restrict__ idx, const double* __restrict__ vals,
                                                  const double* __restrict__ x, double* __restrict__ y,
-                                                 const double* __restrict__ dinv, const double* __restrict__ b) {
+                                                 const double* __restrict__ dinv, const double* __restrict__ dinv2,
+                                                 const double* __restrict__ b) {
   constexpr int CH = 448;
   __shared__ double prod[CH * D];
   const int lane = threadIdx.x;
@@ -448,7 +465,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
         double out = acc[k];
         if constexpr (MODE == AMG_RESID) out = b[q] - out;
         if constexpr (MODE == AMG_SMOOTH) out = x[q] + dinv[q] * (b[q] - out);
-        if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * (2.0 * b[q] - out);
+        if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * b[q] + dinv2[q] * (b[q] - out);  // x1 + D2 (b - A x1)
         y[q] = out;
       }
   }
@@ -853,7 +870,7 @@ void pf_amg_free(pf_ctx* ctx) {
     if (Lv.owns_graph) { pf_free(Lv.ptr); pf_free(Lv.idx); }
     if (l > 0) pf_free(Lv.vals);
     if (Lv.owns_xy) pf_free(Lv.xy);
-    pf_free(Lv.dinv); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
+    pf_free(Lv.dinv); pf_free(Lv.dinv2); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
     pf_free(Lv.pptr); pf_free(Lv.pidx); pf_free(Lv.pvals); pf_free(Lv.tptr); pf_free(Lv.tnode); pf_free(Lv.tslot);
     pf_free(Lv.ptvals);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
@@ -892,6 +909,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     AmgLevel& Lv = H->L[l];
     const int64_t ndof = Lv.n * Lv.dr;
     PF_HIP(hipMalloc(&Lv.dinv, sizeof(double) * ndof));
+    PF_HIP(hipMalloc(&Lv.dinv2, sizeof(double) * ndof));
     PF_HIP(hipMalloc(&Lv.iso, (size_t)ndof));
     PF_HIP(hipMalloc(&Lv.t, sizeof(double) * ndof));
     if (l > 0) {
@@ -962,15 +980,16 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   return PF_OK;
 }
 
+// which: 0 -> first factor (dinv), 1 -> second (dinv2); AMG_SMOOTH0 uses dinv for its first sweep and dinv2 for the second
 static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y, int mode = AMG_AX,
-                    const double* b = nullptr) {
+                    const double* b = nullptr, int which = 0) {
+  const double* dv = which ? Lv.dinv2 : Lv.dinv;
   if (level == 0) {
     if (mode == AMG_SMOOTH0) return pf_fail(ctx, PF_E_INVALID, "amg_spmv: AMG_SMOOTH0 is a coarse-level mode");
-    return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr, mode == AMG_SMOOTH ? Lv.dinv : nullptr,
-                          mode == AMG_AX ? nullptr : b);
+    return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b);
   }
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
-#define PF_AS(D_, M_) k_amg_spmv<D_, M_><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, Lv.dinv, b)
+#define PF_AS(D_, M_) k_amg_spmv<D_, M_><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b)
 #define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
   if (mode == AMG_AX) PF_ASD(AMG_AX);
   else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
@@ -1034,6 +1053,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (const char* e = getenv("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
   if (const char* e = getenv("PF_AMG_OVER")) H->over = atof(e);
   if (const char* e = getenv("PF_AMG_OVER_SA")) H->over_sa = atof(e);
+  if (const char* e = getenv("PF_AMG_CHEB")) H->cheb = atof(e);
   if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
   double* bad = H->lam + AMG_MAX_LEVELS;
   PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 2), ctx->stream));
@@ -1090,7 +1110,8 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
       }
       PF_LAUNCH_CHECK();
     }
-    k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, H->lam + l, H->omega_scale, Lv.dinv, Lv.iso);
+    k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, H->lam + l, H->omega_scale,
+                                                                         H->nsmooth == 2 ? H->cheb : 0.0, Lv.dinv, Lv.dinv2, Lv.iso);
     PF_LAUNCH_CHECK();
   }
   if (H->dense_inv) {
@@ -1151,8 +1172,8 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
       k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, c);
       done = 1;
     }
-    for (; done < H->nsmooth; ++done) {
-      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
+    for (; done < H->nsmooth; ++done) {  // sweep s uses factor s & 1 on the way down ...
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, done & 1))) return rc;
       std::swap(c, o);
     }
     if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
@@ -1219,8 +1240,8 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
     else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
     else k_amg_prolong<2, 3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
-    for (int s = 0; s < H->nsmooth; ++s) {
-      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b))) return rc;
+    for (int s = H->nsmooth - 1; s >= 0; --s) {  // ... and the reverse order on the way up: the cycle stays symmetric
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1))) return rc;
       std::swap(c, o);
     }
     PF_LAUNCH_CHECK();
