@@ -102,3 +102,33 @@ def test_inp_parser_reads_the_reference_arm_mesh_like_the_reference():
     fixed = np.concatenate((2 * groups["fixed"], 2 * groups["fixed"] + 1))
     assert np.array_equal(np.sort(fixed), np.sort(g["dof_fixed"]))
     assert np.array_equal(np.sort(groups["load"]), np.sort(g["force_nodes"]))
+
+
+def test_compat_modules_shadow_the_reference_names():
+    """compat/ on sys.path makes `import pyfem, utils` / `from parse_inp import InpParser` resolve to this package
+    (how the reference's own examples and tests are pointed at the MI355X path)."""
+    import importlib
+    import os
+    import sys
+
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat")
+    saved = {k: sys.modules.pop(k) for k in ("pyfem", "utils", "parse_inp") if k in sys.modules}
+    sys.path.insert(0, compat)
+    try:
+        pyfem = importlib.import_module("pyfem")
+        utils_mod = importlib.import_module("utils")
+        parse_inp = importlib.import_module("parse_inp")
+        from pyfem_gpu_testflight_amd import pyfem as ours
+
+        assert pyfem.LinearElasticity is ours.LinearElasticity and pyfem.ProblemCreator is ours.ProblemCreator
+        assert pyfem.QuadratureBlock3D is ours.QuadratureBlock3D and pyfem.Assembler is ours.Assembler
+        assert callable(utils_mod.time_this) and callable(utils_mod.to_vtk) and callable(utils_mod.timer_on)
+        assert parse_inp.InpParser.__module__ == "pyfem_gpu_testflight_amd.parse_inp"
+        # the mesh generator needs no GPU: the reference's scripts start with it
+        conn, X, dof_fixed, force = pyfem.ProblemCreator(4, 3).create_linear_elasticity_problem()
+        assert conn.shape == (6, 4) and X.shape == (12, 2) and len(dof_fixed) == 6 and list(force) == [3]
+    finally:
+        sys.path.remove(compat)
+        for k in ("pyfem", "utils", "parse_inp"):
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
