@@ -19,6 +19,7 @@
 // The cycle is a fixed symmetric positive definite operator, so it is a valid CG preconditioner.
 // PF_AMG_SA=0 selects plain aggregation (tentative P formed on the fly from the coordinates, coarse correction
 // scaled by 2 because plain aggregation under-corrects): kept as the cheap-setup variant and for comparison.
+#include <hipcub/hipcub.hpp>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -860,6 +861,182 @@ __global__ void k_amg_dense_apply(int m, const double* __restrict__ Ainv, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// The same patterns on the device (sa_pattern_host is the fallback when a row exceeds the local-array caps):
+// rows of P, its transpose (entries of each coarse column, ascending node) and the rows of P^T A P, each as a
+// count pass, a scan and a fill pass with per-thread sorted-unique arrays.  Everything is sorted, so the result is
+// identical to the host version.
+// ------------------------------------------------------------------------------------------
+static constexpr int SA_PCAP = 32;    // aggregates one row of P may touch
+static constexpr int SA_CCAP = 160;   // couplings of one coarse row
+
+__device__ __forceinline__ bool sa_insert(int32_t* arr, int& cnt, int cap, int32_t v) {
+  int k = 0;
+  while (k < cnt && arr[k] < v) ++k;
+  if (k < cnt && arr[k] == v) return true;
+  if (cnt == cap) return false;
+  for (int t = cnt; t > k; --t) arr[t] = arr[t - 1];
+  arr[k] = v;
+  ++cnt;
+  return true;
+}
+
+__global__ void k_sa_prow(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                          const int32_t* __restrict__ agg, int32_t* __restrict__ count,
+                          const int32_t* __restrict__ pptr, int32_t* __restrict__ pidx, int32_t* __restrict__ flag) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t arr[SA_PCAP];
+  int cnt = 0;
+  bool ok = sa_insert(arr, cnt, SA_PCAP, agg[i]);
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) ok = sa_insert(arr, cnt, SA_PCAP, agg[idx[g]]) && ok;
+  if (!ok) flag[0] = 1;
+  if (count) count[i] = cnt;
+  else
+    for (int k = 0; k < cnt; ++k) pidx[pptr[i] + k] = arr[k];
+}
+
+__global__ void k_sa_tcount(int64_t n, const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                            int32_t* __restrict__ tcount) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int32_t s = pptr[i]; s < pptr[i + 1]; ++s) atomicAdd(&tcount[pidx[s]], 1);
+}
+
+__global__ void k_sa_tfill(int64_t n, const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                           const int32_t* __restrict__ tptr, int32_t* __restrict__ cursor,
+                           int32_t* __restrict__ tnode, int32_t* __restrict__ tslot) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int32_t s = pptr[i]; s < pptr[i + 1]; ++s) {
+    const int32_t J = pidx[s];
+    const int32_t at = tptr[J] + atomicAdd(&cursor[J], 1);
+    tnode[at] = (int32_t)i;
+    tslot[at] = s;
+  }
+}
+
+// order each coarse column by node (the atomics above fill it in arrival order)
+__global__ void k_sa_tsort(int64_t nc, const int32_t* __restrict__ tptr, int32_t* __restrict__ tnode,
+                           int32_t* __restrict__ tslot) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  const int32_t b = tptr[I], e = tptr[I + 1];
+  for (int32_t q = b + 1; q < e; ++q) {
+    const int32_t vn = tnode[q], vs = tslot[q];
+    int32_t j = q - 1;
+    while (j >= b && tnode[j] > vn) {
+      tnode[j + 1] = tnode[j];
+      tslot[j + 1] = tslot[j];
+      --j;
+    }
+    tnode[j + 1] = vn;
+    tslot[j + 1] = vs;
+  }
+}
+
+__global__ void k_sa_crow(int64_t nc, const int32_t* __restrict__ tptr, const int32_t* __restrict__ tnode,
+                          const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                          const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                          int32_t* __restrict__ count, const int32_t* __restrict__ cptr, int32_t* __restrict__ cidx,
+                          int32_t* __restrict__ flag) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  int32_t arr[SA_CCAP];
+  int cnt = 0;
+  bool ok = sa_insert(arr, cnt, SA_CCAP, (int32_t)I);
+  for (int32_t q = tptr[I]; q < tptr[I + 1]; ++q) {
+    const int32_t i = tnode[q];
+    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+      const int32_t m = idx[g];
+      for (int32_t s = pptr[m]; s < pptr[m + 1]; ++s) ok = sa_insert(arr, cnt, SA_CCAP, pidx[s]) && ok;
+    }
+  }
+  if (!ok) flag[0] = 1;
+  if (count) count[I] = cnt;
+  else
+    for (int k = 0; k < cnt; ++k) cidx[cptr[I] + k] = arr[k];
+}
+
+static int sa_scan(pf_ctx* ctx, int32_t* in, int32_t* out, int64_t n) {
+  size_t need = 0;
+  PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, ctx->stream));
+  if (need > ctx->scan_tmp_cap) {
+    if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
+    ctx->scan_tmp = nullptr;
+    PF_HIP(hipMalloc(&ctx->scan_tmp, need));
+    ctx->scan_tmp_cap = need;
+  }
+  PF_HIP(hipcub::DeviceScan::ExclusiveSum(ctx->scan_tmp, need, in, out, (int)n, ctx->stream));
+  return PF_OK;
+}
+
+// Builds Lv.pptr/pidx/tptr/tnode/tslot and the next level's graph (dptr_c/didx_c, also copied to the host vectors for
+// the next aggregation).  d_ptr/d_idx: this level's graph on the device, Lv.agg already uploaded.
+// Returns PF_E_UNSUPPORTED (nothing allocated) when a row exceeds the caps: the caller then uses sa_pattern_host.
+static int sa_pattern_device(pf_ctx* ctx, AmgLevel& Lv, int64_t n, const int32_t* d_ptr, const int32_t* d_idx, int64_t nc,
+                             int32_t*& dptr_c, int32_t*& didx_c, std::vector<int32_t>& cptr, std::vector<int32_t>& cidx) {
+  hipStream_t st = ctx->stream;
+  int32_t *cnt = nullptr, *flag = nullptr, *cur = nullptr;
+  const int64_t nmax = std::max(n, nc) + 1;
+  PF_HIP(hipMalloc(&cnt, sizeof(int32_t) * nmax));
+  PF_HIP(hipMalloc(&cur, sizeof(int32_t) * (nc + 1)));
+  PF_HIP(hipMalloc(&flag, sizeof(int32_t)));
+  PF_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+  PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nmax, st));
+  int32_t *pptr = nullptr, *pidx = nullptr, *tptr = nullptr, *tnode = nullptr, *tslot = nullptr;
+  int rc = PF_OK;
+  int32_t total = 0, f = 0;
+  auto fail = [&](int code) {
+    pf_free(pptr); pf_free(pidx); pf_free(tptr); pf_free(tnode); pf_free(tslot); pf_free(dptr_c); pf_free(didx_c);
+    (void)hipFree(cnt); (void)hipFree(cur); (void)hipFree(flag);
+    return code;
+  };
+  const unsigned gn = (unsigned)cdiv(n, 128), gc = (unsigned)cdiv(nc, 128);
+  // rows of P
+  PF_HIP(hipMalloc(&pptr, sizeof(int32_t) * (n + 1)));
+  k_sa_prow<<<gn, 128, 0, st>>>(n, d_ptr, d_idx, Lv.agg, cnt, nullptr, nullptr, flag);
+  if ((rc = sa_scan(ctx, cnt, pptr, n + 1))) return fail(rc);
+  PF_HIP(hipMemcpyAsync(&total, pptr + n, sizeof(total), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipStreamSynchronize(st));
+  if (f) return fail(PF_E_UNSUPPORTED);
+  const int64_t np = total;
+  PF_HIP(hipMalloc(&pidx, sizeof(int32_t) * std::max<int64_t>(1, np)));
+  k_sa_prow<<<gn, 128, 0, st>>>(n, d_ptr, d_idx, Lv.agg, nullptr, pptr, pidx, flag);
+  // transpose
+  PF_HIP(hipMalloc(&tptr, sizeof(int32_t) * (nc + 1)));
+  PF_HIP(hipMalloc(&tnode, sizeof(int32_t) * std::max<int64_t>(1, np)));
+  PF_HIP(hipMalloc(&tslot, sizeof(int32_t) * std::max<int64_t>(1, np)));
+  PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nmax, st));
+  PF_HIP(hipMemsetAsync(cur, 0, sizeof(int32_t) * (nc + 1), st));
+  k_sa_tcount<<<gn, 128, 0, st>>>(n, pptr, pidx, cnt);
+  if ((rc = sa_scan(ctx, cnt, tptr, nc + 1))) return fail(rc);
+  k_sa_tfill<<<gn, 128, 0, st>>>(n, pptr, pidx, tptr, cur, tnode, tslot);
+  k_sa_tsort<<<gc, 128, 0, st>>>(nc, tptr, tnode, tslot);
+  // rows of P^T A P
+  PF_HIP(hipMalloc(&dptr_c, sizeof(int32_t) * (nc + 1)));
+  PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nmax, st));
+  k_sa_crow<<<gc, 128, 0, st>>>(nc, tptr, tnode, d_ptr, d_idx, pptr, pidx, cnt, nullptr, nullptr, flag);
+  if ((rc = sa_scan(ctx, cnt, dptr_c, nc + 1))) return fail(rc);
+  PF_HIP(hipMemcpyAsync(&total, dptr_c + nc, sizeof(total), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipStreamSynchronize(st));
+  if (f) return fail(PF_E_UNSUPPORTED);
+  PF_HIP(hipMalloc(&didx_c, sizeof(int32_t) * std::max<int32_t>(1, total)));
+  k_sa_crow<<<gc, 128, 0, st>>>(nc, tptr, tnode, d_ptr, d_idx, pptr, pidx, nullptr, dptr_c, didx_c, flag);
+  PF_HIP(hipGetLastError());
+  cptr.resize(nc + 1);
+  cidx.resize(total);
+  PF_HIP(hipMemcpyAsync(cptr.data(), dptr_c, sizeof(int32_t) * (nc + 1), hipMemcpyDeviceToHost, st));
+  if (total) PF_HIP(hipMemcpyAsync(cidx.data(), didx_c, sizeof(int32_t) * total, hipMemcpyDeviceToHost, st));
+  PF_HIP(hipStreamSynchronize(st));
+  (void)hipFree(cnt); (void)hipFree(cur); (void)hipFree(flag);
+  Lv.pptr = pptr; Lv.pidx = pidx; Lv.tptr = tptr; Lv.tnode = tnode; Lv.tslot = tslot;
+  Lv.np = np;
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // hierarchy management
 // ------------------------------------------------------------------------------------------
 void pf_amg_free(pf_ctx* ctx) {
@@ -933,31 +1110,41 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     Lv.nc = nc;
     int rc = PF_OK;
     Lv.sa = sa_level;
+    int32_t *dptr_c = nullptr, *didx_c = nullptr;  // the next level's graph when it was built on the device
     if (Lv.sa) {  // the coarse graph is that of P^T A P with the smoothed P
-      std::vector<int32_t> pptr, pidx, tptr, tnode, tslot;
       const double t_c = now();
-      sa_pattern_host(n, ptr, idx, agg, nc, pptr, pidx, tptr, tnode, tslot, cptr, cidx);
-      if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s\n", l, now() - t_c);
-      Lv.np = (int64_t)pidx.size();
-      rc = to_device(ctx, pptr, Lv.pptr);
-      if (rc == PF_OK) rc = to_device(ctx, pidx, Lv.pidx);
-      if (rc == PF_OK) rc = to_device(ctx, tptr, Lv.tptr);
-      if (rc == PF_OK) rc = to_device(ctx, tnode, Lv.tnode);
-      if (rc == PF_OK) rc = to_device(ctx, tslot, Lv.tslot);
+      rc = to_device(ctx, agg, Lv.agg);
       if (rc) return rc;
+      rc = getenv("PF_AMG_HOST_PATTERNS") ? PF_E_UNSUPPORTED
+                                          : sa_pattern_device(ctx, Lv, n, Lv.ptr, Lv.idx, nc, dptr_c, didx_c, cptr, cidx);
+      if (rc == PF_E_UNSUPPORTED) {  // a row beyond the device kernels' local arrays: same patterns on host threads
+        std::vector<int32_t> pptr, pidx, tptr, tnode, tslot;
+        sa_pattern_host(n, ptr, idx, agg, nc, pptr, pidx, tptr, tnode, tslot, cptr, cidx);
+        Lv.np = (int64_t)pidx.size();
+        rc = to_device(ctx, pptr, Lv.pptr);
+        if (rc == PF_OK) rc = to_device(ctx, pidx, Lv.pidx);
+        if (rc == PF_OK) rc = to_device(ctx, tptr, Lv.tptr);
+        if (rc == PF_OK) rc = to_device(ctx, tnode, Lv.tnode);
+        if (rc == PF_OK) rc = to_device(ctx, tslot, Lv.tslot);
+      }
+      if (rc) return rc;
+      if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s (%s)\n", l, now() - t_c, dptr_c ? "device" : "host");
       PF_HIP(hipMalloc(&Lv.pvals, sizeof(double) * Lv.np * Lv.dr * dc));
       PF_HIP(hipMalloc(&Lv.ptvals, sizeof(double) * Lv.np * Lv.dr * dc));
       Lv.max_crow = 0;
       for (int64_t I = 0; I < nc; ++I) Lv.max_crow = std::max(Lv.max_crow, cptr[I + 1] - cptr[I]);
       PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
     }
-    if (rc == PF_OK) rc = to_device(ctx, agg, Lv.agg);
+    if (rc == PF_OK && !Lv.agg) rc = to_device(ctx, agg, Lv.agg);
     if (rc == PF_OK) rc = to_device(ctx, aptr, Lv.aptr);
     if (rc == PF_OK) rc = to_device(ctx, amem, Lv.amem);
     AmgLevel& Nx = H->L[l + 1];
     Nx.n = nc; Nx.dr = dc; Nx.nblk = (int64_t)cidx.size(); Nx.owns_graph = true; Nx.owns_xy = true;
-    if (rc == PF_OK) rc = to_device(ctx, cptr, Nx.ptr);
-    if (rc == PF_OK) rc = to_device(ctx, cidx, Nx.idx);
+    if (dptr_c) { Nx.ptr = dptr_c; Nx.idx = didx_c; }
+    else {
+      if (rc == PF_OK) rc = to_device(ctx, cptr, Nx.ptr);
+      if (rc == PF_OK) rc = to_device(ctx, cidx, Nx.idx);
+    }
     if (rc) return rc;
     PF_HIP(hipMalloc(&Nx.xy, sizeof(double) * H->dim * nc));
     k_amg_centroids<<<(unsigned)cdiv(nc, 256), 256, 0, ctx->stream>>>(nc, H->dim, Lv.aptr, Lv.amem, Lv.xy, Nx.xy);
