@@ -4,8 +4,9 @@
 // (pyfem.py:2393-2400) and `pyamg.ruge_stuben_solver(K)` (pyfem.py:2098) -- SURVEY.md 8f row f1.
 // pyamg is a host library; this is a from-scratch device implementation on the same data layout as
 // the rest of the path (node graph + dense d x d blocks), not a port:
-//   * aggregates depend on the node GRAPH only, so they are built once per mesh on the host (greedy
-//     root/neighbourhood aggregation, O(nnz) serial C++) together with the coarse node graphs;
+//   * aggregates depend on the node GRAPH only, so they are built once per mesh: the greedy root/neighbourhood
+//     aggregation on the host (serial O(nnz), a few ms per million nodes), the patterns of the smoothed
+//     prolongator, of its transpose and of the coarse operators on the device;
 //   * per matrix, on the device: the prolongator P = (I - w D^-1 A) P_tent (smoothed aggregation), where the
 //     tentative prolongator carries the near-null space: the constant for scalar problems, the three
 //     rigid-body modes (two translations and the in-plane rotation about the aggregate centroid) for plane
