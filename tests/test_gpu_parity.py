@@ -824,3 +824,38 @@ def test_sensitivity_is_the_derivative_of_the_assembled_operator(pf, kind):
     f = lambda r: phi.dot(model.compute_jacobian(r).dot(psi))  # noqa: E731
     fd = (f(rho + h * dv) - f(rho - h * dv)) / (2 * h)
     assert abs(dfdrho - fd) <= 1e-7 * abs(fd), (dfdrho, fd)
+
+
+def test_contexts_release_their_device_memory(pf):
+    """Every pf_ctx owns a mesh copy, the pattern, visit records, AMG hierarchies (stored prolongators, coarse
+    operators): building, solving and dropping models in a loop must not leak device memory."""
+    import gc
+
+    import torch
+
+    def one(k):
+        c = pf.ProblemCreator(120 + k, 90)
+        conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+        q, b = _qb(pf, "quad")
+        m = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+        u = pf.Assembler(m).solve(method="cg")
+        f = pf.Helmholtz(0.05, X, conn, q, b)
+        f.apply(np.ones(X.shape[0]))
+        c3 = pf.ProblemCreator(10, 9, 8 + k % 2, element_type="block")
+        conn3, X3, fix3, force3 = c3.create_linear_elasticity_problem()
+        q3, b3 = _qb(pf, "block")
+        pf.Assembler(pf.LinearElasticity(X3, conn3, fix3, None, force3, q3, b3)).solve(method="cg")
+        return float(np.abs(u).max())
+
+    one(0)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(1, 25):
+        one(k)
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 2**20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 24 model lifetimes"
