@@ -97,7 +97,7 @@ int pf_assemble_helmholtz2d(pf_ctx* ctx, double r0, double* Kvals, double* Rvals
 /* Sensitivity of phi^T K(rho) psi w.r.t. the nodal density: LinearElasticity._compute_K_dv_sens
  * (pyfem.py:1873-1920) with _update_material_property_deriv (:1948-1973), fused -- the (E,D,D,P)
  * tensor Ke_deriv is never formed.  rho float64[nnodes] (required), phi/psi float64[2*nnodes],
- * out float64[nnodes].  compliance_grad (pyfem.py:1837-1848) is -pf_sens(rho, u, u).           */
+ * out float64[nnodes].  compliance_grad (pyfem.py:1837-1848) is minus this with phi = psi = u.           */
 int pf_sens_elasticity2d(pf_ctx* ctx, double E, double nu, double p, const double* rho,
                          const double* phi, const double* psi, double* out);
 
