@@ -385,13 +385,15 @@ __device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t 
 
 template <int P, bool RHO, int ABL = 0>
 __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __restrict__ X,
-                                              const double* __restrict__ rho, V3Visit<P, RHO>& C) {
+                                              const double* __restrict__ rho, V3Visit<P, RHO>& C, int32_t nlast) {
   const uint32_t w = (uint32_t)B.rec.w;
   const int a = (int)((w >> 24) & 3), ln = (int)((w >> 26) & 15);
   C.w = w;
   C.active = B.active;
   C.roff = __shfl(B.rp, ln) - __shfl(B.rp, 0);
-  const int32_t n = B.n0 + ln;  // the lane's own node
+  // the lane's own node; clamped, because a lane past the tile's last pair carries the slot of another tile's record
+  // and n0 + slot can then lie beyond the last node (its gathers are unconditional, their values unused)
+  const int32_t n = min(B.n0 + ln, nlast);
   int32_t nd[4];
   nd[0] = (a == 0) ? n : B.rec.x;
   nd[1] = (a == 1) ? n : ((a < 1) ? B.rec.x : B.rec.y);
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int64_t ntil
   V3Rec Ba = v3_load_rec<ABL>(T0, lane, nvis, nnodes, vis_rec, nptr);
   V3Rec Bb = v3_load_rec<ABL>(T1, lane, nvis, nnodes, vis_rec, nptr);
   V3Visit<P, RHO> Ca, Cb;
-  v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca);
+  v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca, (int32_t)nnodes - 1);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "five stores are younger than it" (back edge: vmcnt(5) is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -547,12 +549,12 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int64_t ntil
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
     const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, tile_desc);
-    v3_load_visit<P, RHO, ABL>(Bb, X, pr.rho, Cb);
+    v3_load_visit<P, RHO, ABL>(Bb, X, pr.rho, Cb, (int32_t)nnodes - 1);
     Ba = v3_load_rec<ABL>(T2, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, tile_desc);
-    v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca);
+    v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca, (int32_t)nnodes - 1);
     Bb = v3_load_rec<ABL>(T3, lane, nvis, nnodes, vis_rec, nptr);
     v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
     T0 = T2; T1 = T3; T2 = T4;
