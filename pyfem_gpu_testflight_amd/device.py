@@ -240,73 +240,93 @@ class HipContext:
         return ms.value
 
 
-class DeviceCSR:
-    """Device-resident sparse matrix on a HipContext pattern.
+def _csr_base():
+    from scipy import sparse
 
-    Quacks like the scipy CSR the reference returns wherever its tests/examples touch it
-    (`K.dot(v)`, `K - K2`, `abs(K)`, `.data`, `.indptr`, `.diagonal()`, `.nnz`, `.shape`):
-    `dot` with a vector runs the HIP SpMV; anything else materialises a scipy matrix once
-    (explicit zeros are dropped on export only if `eliminate_zeros` was requested, which is what
-    apply_dirichlet_bcs does in the reference, pyfem.py:826)."""
+    return sparse.csr_matrix
 
-    def __init__(self, hctx, vals, eliminate_zeros=False):
-        self.hctx = hctx
-        self.vals = vals
-        self._eliminate = eliminate_zeros
-        self._host = None
+
+class DeviceCSR(_csr_base()):
+    """Device-resident sparse matrix on a HipContext pattern that IS a scipy CSR matrix for host code.
+
+    `compute_jacobian()` / `apply_dirichlet_bcs()` of the reference return scipy CSR matrices (pyfem.py:921-931, 835) and
+    its tests and examples hand them to scipy (`spsolve(K, rhs)`, `K - K2`, `abs(K)`, `K[i, j]`, `K.diagonal()`,
+    `K.nnz`, printing).  This subclass keeps the values in HBM and materialises `data` / `indices` / `indptr` on the
+    host only when something reads them (explicit zeros are dropped at that point if `eliminate_zeros` was requested,
+    which is what apply_dirichlet_bcs does in the reference, pyfem.py:826).  `dot` / `@` with a real vector run the
+    HIP SpMV without materialising anything.  The device values are authoritative for the GPU path: host arrays are a
+    read-only view of them (`invalidate()` drops the view after the device values changed).
+
+    Results of scipy arithmetic on it (`K - K2`, `abs(K)`, `K.copy()` of a host-only instance, ...) are ordinary host
+    matrices of this class with no device side (`hctx is None`)."""
+
+    def __init__(self, arg1, vals=None, eliminate_zeros=False, shape=None, dtype=None, copy=False):
+        if isinstance(arg1, HipContext):
+            self.hctx, self.vals, self._eliminate = arg1, vals, eliminate_zeros
+            self._shape = (arg1.nrows, arg1.nrows)
+            self.maxprint = 50
+        else:  # scipy's own constructor signature (used by inherited methods that build their result)
+            self.hctx, self.vals, self._eliminate = None, None, False
+            _csr_base().__init__(self, arg1, shape=shape, dtype=dtype, copy=copy)
+
+    # -- lazy host view ------------------------------------------------------------------------
+    def _materialise(self):
+        from scipy import sparse
+
+        indptr, indices = self.hctx.csr_structure()
+        data = self.hctx.vals_to_csr(self.vals).cpu().numpy()
+        K = sparse.csr_matrix((data, indices.copy(), indptr.copy()), shape=self._shape)
+        if self._eliminate:
+            K.eliminate_zeros()
+        d = self.__dict__
+        d["_h_data"], d["_h_indices"], d["_h_indptr"] = K.data, K.indices, K.indptr
+
+    def _host_array(self, name):
+        d = self.__dict__
+        if name not in d:
+            if d.get("hctx") is None:
+                raise AttributeError(name)
+            self._materialise()
+        return d[name]
+
+    data = property(lambda self: self._host_array("_h_data"), lambda self, v: self.__dict__.__setitem__("_h_data", v))
+    indices = property(lambda self: self._host_array("_h_indices"),
+                       lambda self, v: self.__dict__.__setitem__("_h_indices", v))
+    indptr = property(lambda self: self._host_array("_h_indptr"),
+                      lambda self, v: self.__dict__.__setitem__("_h_indptr", v))
 
     @property
-    def shape(self):
-        return (self.hctx.nrows, self.hctx.nrows)
+    def dtype(self):
+        h = self.__dict__.get("_h_data")
+        return np.dtype(np.float64) if h is None else h.dtype
 
     def invalidate(self):
-        self._host = None
+        """Drop the host view (the device values were modified)."""
+        if self.__dict__.get("hctx") is not None:
+            for k in ("_h_data", "_h_indices", "_h_indptr"):
+                self.__dict__.pop(k, None)
 
     def to_scipy(self):
-        if self._host is None:
-            from scipy import sparse
-
-            indptr, indices = self.hctx.csr_structure()
-            data = self.hctx.vals_to_csr(self.vals).cpu().numpy()
-            K = sparse.csr_matrix((data, indices.copy(), indptr.copy()), shape=self.shape)
-            if self._eliminate:
-                K.eliminate_zeros()
-            self._host = K
-        return self._host
+        """A plain scipy CSR matrix over the host view (no copy)."""
+        return _csr_base()((self.data, self.indices, self.indptr), shape=self.shape)
 
     tocsr = to_scipy
 
+    # -- device paths ----------------------------------------------------------------------------
     def dot(self, v):
-        torch = self.hctx.torch
-        if isinstance(v, torch.Tensor):
-            return self.hctx.spmv(self.vals, v)
-        v = np.asarray(v)
-        if v.ndim == 1 and v.dtype != complex:
-            y = self.hctx.spmv(self.vals, self.hctx.to_device(v, torch.float64))
-            return y.cpu().numpy()
-        return self.to_scipy().dot(v)
+        hctx = self.__dict__.get("hctx")
+        if hctx is not None:
+            torch = hctx.torch
+            if isinstance(v, torch.Tensor):
+                return hctx.spmv(self.vals, v)
+            if isinstance(v, np.ndarray) and v.ndim == 1 and not np.iscomplexobj(v) and v.shape[0] == self.shape[1]:
+                return hctx.spmv(self.vals, hctx.to_device(v, torch.float64)).cpu().numpy()
+        return _csr_base().dot(self, v)
 
-    __matmul__ = dot
+    def __matmul__(self, v):
+        return self.dot(v)
 
     def copy(self):
-        return DeviceCSR(self.hctx, self.vals.clone(), self._eliminate)
-
-    def __getattr__(self, name):  # everything else: delegate to the materialised scipy matrix
-        if name.startswith("_"):
-            raise AttributeError(name)
-        return getattr(self.to_scipy(), name)
-
-    def __sub__(self, other):
-        return self.to_scipy() - (other.to_scipy() if isinstance(other, DeviceCSR) else other)
-
-    def __rsub__(self, other):
-        return other - self.to_scipy()
-
-    def __add__(self, other):
-        return self.to_scipy() + (other.to_scipy() if isinstance(other, DeviceCSR) else other)
-
-    def __abs__(self):
-        return abs(self.to_scipy())
-
-    def __getitem__(self, key):
-        return self.to_scipy()[key]
+        if self.__dict__.get("hctx") is not None:
+            return DeviceCSR(self.hctx, self.vals.clone(), self._eliminate)
+        return _csr_base().copy(self)

@@ -220,8 +220,8 @@ class ModelBase:
     def apply_dirichlet_bcs(self, K, rhs, enforce_symmetric_K=True):
         """ref: pyfem.py:781-835.  K: DeviceCSR from compute_jacobian (modified in place, like the
         reference mutates its argument); rhs: numpy array (modified in place) or device tensor."""
-        if not isinstance(K, DeviceCSR):
-            raise TypeError("apply_dirichlet_bcs expects the DeviceCSR returned by compute_jacobian()")
+        if not isinstance(K, DeviceCSR) or K.hctx is None:
+            raise TypeError("apply_dirichlet_bcs expects the device-backed matrix returned by compute_jacobian()")
         torch = self.hctx.torch
         on_device = isinstance(rhs, torch.Tensor)
         rhs_d = rhs if on_device else self.hctx.to_device(rhs, torch.float64)
@@ -268,7 +268,10 @@ class LinearPoisson(ModelBase):
         """ref: pyfem.py:997-1004, 1138-1173."""
         torch = self.hctx.torch
         Xq = self.hctx.quad_points().cpu().numpy()
-        self.fun_vals = np.asarray(self.gfunc(Xq), dtype=float)
+        # the reference assigns gfunc's result into an (nelems, nquads) array (pyfem.py:1126-1128), so a scalar or a
+        # broadcastable result is fine (examples/heat_conduction.py passes `lambda x: source_temp`)
+        self.fun_vals = np.empty(Xq.shape[:2])
+        self.fun_vals[...] = self.gfunc(Xq)
         gq = self.hctx.to_device(np.ascontiguousarray(self.fun_vals), torch.float64)
         self.rhs[:] = self.hctx.poisson_rhs(gq).cpu().numpy()
         return self.rhs

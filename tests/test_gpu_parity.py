@@ -859,3 +859,34 @@ def test_contexts_release_their_device_memory(pf):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 2**20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 24 model lifetimes"
+
+
+def test_returned_matrix_is_a_scipy_matrix_for_host_code(pf, orc):
+    """examples/heat_conduction.py hands the matrix of apply_dirichlet_bcs straight to scipy (`spsolve(K, rhs)`), prints
+    entries (`K[i, j]`), and SciTech2023/verification/verify.py does `np.max(np.abs(K - K_a2d))`: the returned object
+    is a scipy CSR matrix whose arrays materialise on first touch, while `K.dot(v)` stays on the device."""
+    from scipy import sparse
+    from scipy.sparse.linalg import spsolve
+
+    c = pf.ProblemCreator(nnodes_x=4, nnodes_y=3, nnodes_z=3, element_type="block")
+    q, b = _qb(pf, "block")
+    left = [int(c.nodes3d[k, j, 0]) for k in range(3) for j in range(3)]
+    model = pf.LinearPoisson(X=c.X, conn=c.conn, dof_fixed=left, dof_fixed_vals=[1.0] * len(left), quadrature=q, basis=b,
+                             gfunc=lambda x: 0.5, p=5.0)  # scalar source term, keyword arguments: heat_conduction.py:68-82
+    K = model.compute_jacobian()
+    assert sparse.issparse(K) and K.shape == (36, 36) and "_h_data" not in K.__dict__
+    v = np.random.RandomState(0).rand(36)
+    Kv = K.dot(v)                                   # device SpMV, nothing materialised
+    assert "_h_data" not in K.__dict__
+    Ko = orc.assemble_csr(orc.poisson_Ke(c.X, c.conn.astype(np.int64), "block", np.ones(36), 5.0), c.conn.astype(np.int64))
+    assert relmax(Kv, Ko.dot(v)) < K_TOL
+    assert abs(K[5, 5] - Ko[5, 5]) < 1e-12 and np.max(np.abs(K - Ko)) < 1e-12 * np.max(np.abs(Ko))  # materialises
+    rhs = model.compute_rhs()
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=False)
+    u = spsolve(K, rhs)                             # scipy takes it as it is
+    Kb, rb = orc.apply_dirichlet_bcs(Ko, orc.poisson_rhs(c.X, c.conn.astype(np.int64), "block", lambda x: 0.5 + 0 * x[..., 0]),
+                                     np.array(left), np.ones(len(left)), False)
+    assert relmax(u, spsolve(Kb.tocsc(), rb)) < U_TOL
+    assert isinstance(K - K, sparse.csr_matrix) and (K - K).nnz == 0
+    with pytest.raises(TypeError):
+        model.apply_dirichlet_bcs(K - K, rhs)       # a host-only result has no device side
