@@ -890,3 +890,50 @@ def test_returned_matrix_is_a_scipy_matrix_for_host_code(pf, orc):
     assert isinstance(K - K, sparse.csr_matrix) and (K - K).nnz == 0
     with pytest.raises(TypeError):
         model.apply_dirichlet_bcs(K - K, rhs)       # a host-only result has no device side
+
+
+def test_reference_example_flows_run_through_the_mirror(pf, orc, tmp_path):
+    """The call sequences of the reference's example scripts, statement by statement, on the GPU path:
+    examples/heat_conduction.py (3-D Poisson, scalar source, prescribed temperatures, non-symmetric BC elimination,
+    scipy's spsolve on the returned matrix, VTK output, unweighted compliance gradient) and examples/block/block.py
+    (3-D elasticity, Assembler.solve, VTK).  Results against the oracle."""
+    from scipy.sparse.linalg import spsolve
+
+    from pyfem_gpu_testflight_amd import utils
+
+    # ---- heat_conduction.py:42-107 -----------------------------------------------------------
+    nx, ny, nz = 3, 2, 2
+    creator = pf.ProblemCreator(nnodes_x=nx + 1, nnodes_y=ny + 1, nnodes_z=nz + 1, Lx=2.0, Ly=1.0, Lz=1.5,
+                                element_type="block")
+    dof_fixed_left = [creator.nodes3d[k, j, 0] for k in range(nz + 1) for j in range(ny + 1)]
+    conn, X = creator.conn, creator.X
+    nnodes = X.shape[0]
+    quadrature = pf.QuadratureBlock3D()
+    basis = pf.BasisBlock3D(quadrature)
+    model = pf.LinearPoisson(X=X, conn=conn, dof_fixed=dof_fixed_left, dof_fixed_vals=[1.0] * len(dof_fixed_left),
+                             quadrature=quadrature, basis=basis, gfunc=lambda x: 0.25, p=5.0)
+    K = model.compute_jacobian()
+    assert abs(K[0, 0]) > 0 and K.shape == (nnodes, nnodes)           # print_mat(K) indexes entries
+    rhs = model.compute_rhs()
+    K, rhs = model.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=False)
+    u = spsolve(K, rhs)
+    utils.to_vtk(conn, X, {"u": u}, vtk_name=str(tmp_path / "heat.vtk"))
+    c64 = conn.astype(np.int64)
+    Ko = orc.assemble_csr(orc.poisson_Ke(X, c64, "block", np.ones(nnodes), 5.0), c64)
+    ro = orc.poisson_rhs(X, c64, "block", lambda x: 0.25 + 0 * x[..., 0])
+    Kb, rb = orc.apply_dirichlet_bcs(Ko, ro, np.array(dof_fixed_left), np.ones(len(dof_fixed_left)), False)
+    assert relmax(u, spsolve(Kb.tocsc(), rb)) < U_TOL
+    x = np.ones(nnodes)
+    comp, _ = model.compliance(x)
+    grad = model.compliance_grad(x, u, weighted=False)
+    assert np.isfinite(comp) and grad.shape == (nnodes,) and np.all(np.isfinite(grad))
+
+    # ---- block/block.py:27-62 ------------------------------------------------------------------
+    creator = pf.ProblemCreator(6, 4, 4, element_type="block")
+    conn, X, dof_fixed, nodal_force = creator.create_linear_elasticity_problem()
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, nodal_force, quadrature, basis)
+    u = pf.Assembler(model).solve(method="cg")
+    utils.to_vtk(conn, X, {"ux": u[0::3], "uy": u[1::3], "uz": u[2::3]}, vtk_name=str(tmp_path / "block.vtk"))
+    uo, *_ = orc.solve_elasticity(X, conn.astype(np.int64), "block", np.asarray(dof_fixed), nodal_force)
+    assert relmax(u, uo) < U_TOL
+    assert (tmp_path / "block.vtk").stat().st_size > 1000
