@@ -29,6 +29,8 @@ from .utils import time_this
 # (pyfem.py:1827, 2107, 2418).  Tighter than the reference so that ||u - u_direct||_inf stays
 # below 1e-8 ||u||_inf (BASELINE.json north_star) on ill-conditioned large meshes.
 DEFAULT_RTOL = 1e-10
+# method="direct": relative residual the device PCG is driven to in place of the reference's sparse LU
+DIRECT_RTOL = 1e-13
 
 # preconditioner of the device PCG: "amg" (aggregation AMG V-cycle, the counterpart of the reference's
 # pyamg preconditioners, pyfem.py:2393-2400 and :2098; falls back to Jacobi on matrices that are not
@@ -436,7 +438,7 @@ class LinearElasticity(ModelBase):
         K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
         asm = Assembler(self)
         u = asm._solve_linear_system(K, rhs, solver)
-        self.last_iters = asm.last_iters  # PCG iterations of this solve (None for "direct")
+        self.last_iters = asm.last_iters  # PCG iterations of this solve
         return _vdot(rhs, u), u
 
     def volume(self, rho):
@@ -580,22 +582,20 @@ class Assembler:
 
     @time_this
     def _solve_linear_system(self, K, rhs, method):
-        """ref: pyfem.py:2403-2423.
-        "direct": scipy spsolve on the exported matrix -- the reference's own third-party call, kept
-                  for small meshes / parity checks (not an accelerated leg).
-        "cg" and "gmres": device PCG with the smoothed-aggregation AMG V-cycle (self.precond = "amg", default) or
-                  Jacobi.  K is SPD after symmetric BC elimination, so CG reaches the same solution GMRES
-                  does."""
-        if method == "direct":
-            from scipy.sparse.linalg import spsolve
-
-            return spsolve(K.to_scipy().tocsc(), np.asarray(rhs))
+        """ref: pyfem.py:2403-2423.  All three methods run on the device.
+        "cg" and "gmres": PCG with the smoothed-aggregation AMG V-cycle (self.precond = "amg", default) or Jacobi, to
+                  self.rtol.  K is SPD after symmetric BC elimination, so CG reaches the same solution GMRES does.
+        "direct": the reference calls scipy spsolve (pyfem.py:2414).  No factorisation is built on the GPU: the same
+                  PCG is driven to DIRECT_RTOL (1e-13 in ||r||/||b||, the level an LU residual sits at in fp64) and
+                  raises if it does not get there.  Host code that wants the factorisation itself can still hand the
+                  returned matrix to scipy (`spsolve(K, rhs)`: DeviceCSR is a csr_matrix)."""
+        rtol = DIRECT_RTOL if method == "direct" else self.rtol
         hctx = K.hctx
         torch = hctx.torch
         on_device = isinstance(rhs, torch.Tensor)
         b = rhs if on_device else hctx.to_device(rhs, torch.float64)
         try:
-            x, it, rr = hctx.cg(K.vals, b, rtol=self.rtol, precond=_PRECOND[self.precond])
+            x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
         except RuntimeError as e:
             raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
         self.last_iters, self.last_relres = it, rr

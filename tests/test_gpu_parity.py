@@ -435,6 +435,28 @@ def test_linear_poisson_tri_quirk(pf, orc):
     assert relmax(model.compute_rhs(), orc.poisson_rhs(X, conn, "tri", _gfunc)) < K_TOL
 
 
+def test_direct_method_is_a_device_solve_to_lu_grade_residual(pf, monkeypatch):
+    """method="direct" (spsolve in the reference, pyfem.py:2414) stays on the GPU: PCG to ||r|| <= 1e-13 ||b||.  The host
+    solver is made to raise to show it is not what runs; the true residual is checked on the exported matrix."""
+    import scipy.sparse.linalg as spla
+
+    def boom(*a, **k):
+        raise AssertionError("host solver called")
+
+    monkeypatch.setattr(spla, "spsolve", boom)
+    c = pf.ProblemCreator(97, 65)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q, b = _qb(pf, "quad")
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    asm = pf.Assembler(model)
+    u = asm.solve(method="direct")
+    assert asm.last_relres <= pf.DIRECT_RTOL and asm.last_iters > 0
+    K = model.compute_jacobian()
+    K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
+    Ks = K.to_scipy()
+    assert np.linalg.norm(Ks @ u - rhs) <= 1e-11 * np.linalg.norm(rhs)
+
+
 def test_amg_aggregates_stay_compact_on_triangulated_grids(pf):
     """The 7-point graph of a triangulated grid leaves two corners of every 3x3 patch outside the root's hexagon; the
     aggregation attaches them by edge count and distance to the root, so the coarse spaces (and the PCG iteration
