@@ -167,13 +167,13 @@ int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rt
 /* PF_PRECOND_AMG: smoothed-aggregation AMG V(2,2) cycle -- the device counterpart of the reference's
  * pyamg.smoothed_aggregation_solver(K).aspreconditioner() (pyfem.py:2393-2400) and of
  * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,
- * the coarse operators per call.  If the matrix has a non-positive diagonal entry (not SPD) pf_cg
- * silently uses Jacobi instead.  pf_amg_info reports the hierarchy of the last AMG solve (HOST outputs,
+ * the coarse operators per call.  The matrix may be positive or negative definite (arm.inp: every detJ < 0); if the
+ * coupled dofs carry diagonal entries of both signs pf_cg uses Jacobi instead.  pf_amg_info reports the hierarchy of the last AMG solve (HOST outputs,
  * arrays of length cap). */
 int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);
 /* The same V-cycle as a stand-alone operator for drivers with their own Krylov loop (dist.py: one local AMG per
  * rank in an additive Schwarz preconditioner).  prepare: numeric setup for vals (reuse as in PF_PRECOND_AMG_REUSE;
- * PF_E_UNSUPPORTED if not positive definite).  vcycle: z = M^-1 r (device vectors of length nrows, z != r),
+ * PF_E_UNSUPPORTED if the diagonal signs are mixed).  vcycle: z = M^-1 r (device vectors of length nrows, z != r),
  * asynchronous on the ctx stream. */
 int pf_amg_prepare(pf_ctx* ctx, const double* vals, int reuse);
 /* vals[diagonal entry of dof q] += add[q] (add: nrows doubles): the Schwarz driver completes the interface

@@ -275,7 +275,9 @@ static void sa_pattern_host(int64_t n, const std::vector<int32_t>& ptr, const st
 // ------------------------------------------------------------------------------------------
 // device kernels
 // ------------------------------------------------------------------------------------------
-// decoupled dofs + raw diagonal per dof; bad[0] is raised when a diagonal entry is negative
+// decoupled dofs + raw diagonal per dof; over the coupled dofs bad[0] is raised by a non-positive diagonal entry and
+// scale[1] by a positive one: both raised = indefinite (no AMG), bad alone = negative definite (the cycle is
+// sign-agnostic: D^-1 A, the Galerkin products and the coarsest inverse only change sign together)
 template <int D>
 __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                            const double* __restrict__ vals, uint8_t* __restrict__ iso,
@@ -306,9 +308,13 @@ __global__ void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int
     // triple product as rounding noise of either sign: treat a row that is negligible against its node's other rows
     // as decoupled (identity), not as evidence of an indefinite matrix.
     const bool empty = fabs(dg[k]) + off[k] <= 1e-12 * (finest ? rmax : fmax(rmax, scale[0]));
-    iso[D * i + k] = (off[k] == 0.0 || empty) ? 1 : 0;
+    const bool decoupled = off[k] == 0.0 || empty;
+    iso[D * i + k] = decoupled ? 1 : 0;
     if (dg[k] == 0.0 || empty) dg[k] = 1.0;
-    if (!(dg[k] > 0.0)) bad[0] = 1.0;  // benign race: every writer stores the same value
+    if (!decoupled) {  // benign races: every writer stores the same value
+      if (dg[k] > 0.0) scale[1] = 1.0;
+      else bad[0] = 1.0;
+    }
     diag[D * i + k] = dg[k];
   }
   // the finest level leaves the size of its largest diagonal entry for the coarse levels' emptiness test
@@ -1190,7 +1196,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   int64_t maxdof = 1;
   for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
   PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
-  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 2)));  // + not-SPD flag + diagonal scale
+  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 3)));  // + non-positive flag + diagonal scale + positive flag
   return PF_OK;
 }
 
@@ -1251,9 +1257,10 @@ static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, dou
 
 // numeric part, once per matrix: diagonals, Galerkin products, damping factors, coarsest inverse -- all
 // queued on the stream with ONE host read at the end (the per-level lambda estimates and the SPD flag).
-// Returns PF_E_UNSUPPORTED (without touching ctx->err) when a diagonal entry is not positive -- e.g. the
-// all-negative-detJ arm mesh -- so pf_cg can use Jacobi.  With reuse != 0 the numeric setup of
-// the previous call is kept if it was made for the same value array (the caller asserts the values are
+// Returns PF_E_UNSUPPORTED (without touching ctx->err) when the coupled dofs have diagonal entries of both signs, so
+// pf_cg can use Jacobi.  A negative definite K -- the arm mesh, whose triangles all have detJ < 0 --
+// is accepted: every step of the cycle is linear in A, and PCG only sees r.z and p.Ap change sign together.
+// With reuse != 0 the numeric setup of the previous call is kept if it was made for the same value array (the caller asserts the values are
 // unchanged, e.g. the constant Helmholtz filter matrix).
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (!ctx->amg) {
@@ -1270,7 +1277,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (const char* e = getenv("PF_AMG_CHEB")) H->cheb = atof(e);
   if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
   double* bad = H->lam + AMG_MAX_LEVELS;
-  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 2), ctx->stream));
+  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 3), ctx->stream));
   for (int l = 0; l < H->nlevels; ++l) {
     AmgLevel& Lv = H->L[l];
     const unsigned gr = (unsigned)cdiv(Lv.n, 256);
@@ -1338,15 +1345,16 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
     PF_LAUNCH_CHECK();
   }
-  double h[AMG_MAX_LEVELS + 1];
+  double h[AMG_MAX_LEVELS + 3];
   PF_HIP(hipMemcpyAsync(h, H->lam, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipStreamSynchronize(ctx->stream));
   if (getenv("PF_AMG_VERBOSE")) {
-    fprintf(stderr, "[pf_amg] numeric setup: not-SPD flag %g, lambda_max^2 per level:", h[AMG_MAX_LEVELS]);
+    fprintf(stderr, "[pf_amg] numeric setup: non-positive / positive diagonal seen %g / %g, lambda_max^2 per level:",
+            h[AMG_MAX_LEVELS], h[AMG_MAX_LEVELS + 2]);
     for (int l = 0; l < H->nlevels; ++l) fprintf(stderr, " %g", h[l]);
     fprintf(stderr, "\n");
   }
-  if (h[AMG_MAX_LEVELS] != 0.0) return PF_E_UNSUPPORTED;  // not positive definite
+  if (h[AMG_MAX_LEVELS] != 0.0 && h[AMG_MAX_LEVELS + 2] != 0.0) return PF_E_UNSUPPORTED;  // diagonal signs mixed: indefinite
   for (int l = 0; l < H->nlevels; ++l) {
     const double lam = 1.1 * sqrt(h[l]);
     if (!(lam > 0.0) || !(lam < 1e300)) return PF_E_UNSUPPORTED;

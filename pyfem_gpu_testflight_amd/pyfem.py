@@ -33,8 +33,8 @@ DEFAULT_RTOL = 1e-10
 DIRECT_RTOL = 1e-13
 
 # preconditioner of the device PCG: "amg" (aggregation AMG V-cycle, the counterpart of the reference's
-# pyamg preconditioners, pyfem.py:2393-2400 and :2098; falls back to Jacobi on matrices that are not
-# positive definite) or "jacobi"
+# pyamg preconditioners, pyfem.py:2393-2400 and :2098; positive or negative definite K -- only diagonal entries of
+# both signs among the coupled dofs make pf_cg fall back to Jacobi) or "jacobi"
 DEFAULT_PRECOND = "amg"
 
 

@@ -163,6 +163,14 @@ def test_arm_negative_definite_cg(pf):
     np.random.seed(123)
     p = np.random.rand(u.shape[0])
     assert abs(p.dot(u) / 21177.45599189116 - 1) < 1e-8
+    # the AMG cycle is linear in K, so the negative definite matrix keeps its preconditioner (no Jacobi fallback)
+    its = {}
+    for pre in ("jacobi", "amg"):
+        asm = pf.Assembler(_model(pf, g, "tri"))
+        asm.precond = pre
+        assert relmax(asm.solve(method="cg"), g["u"]) < U_TOL
+        its[pre] = asm.last_iters
+    assert its["amg"] * 4 < its["jacobi"], its
 
 
 @pytest.mark.parametrize("name", list(HELMHOLTZ_CASES))
