@@ -454,6 +454,78 @@ __global__ void k_amg_galerkin(int64_t nc, const int32_t* __restrict__ aptr, con
   }
 }
 
+// The same product with one WAVE per coarse row (rows of at most 64 couplings), upper triangle only
+// (k_sa_mirror_lower fills the rest): two members of the aggregate per pass, 32 lanes over each member's row, the
+// DC x DC contributions added into an LDS image of the coarse row.  The lane-per-row kernel above leaves the 36 k
+// aggregates of 96^3 blocks on 560 waves with 27 x 27 block products each: 9.3 ms; this one takes 1.
+template <int DIM, int DR, int DC>
+__global__ __launch_bounds__(64) void k_amg_galerkin_wave(int64_t nc, const int32_t* __restrict__ aptr,
+                                                          const int32_t* __restrict__ amem,
+                                                          const int32_t* __restrict__ agg,
+                                                          const int32_t* __restrict__ ptr,
+                                                          const int32_t* __restrict__ idx,
+                                                          const double* __restrict__ vals,
+                                                          const uint8_t* __restrict__ iso,
+                                                          const double* __restrict__ xy, const double* __restrict__ cxy,
+                                                          const int32_t* __restrict__ cptr,
+                                                          const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
+  __shared__ int32_t crow[64];
+  __shared__ double cacc[64 * DC * DC];
+  const int lane = threadIdx.x, half = lane >> 5, sub = lane & 31;
+  for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
+    const int32_t cb = cptr[I], clen = cptr[I + 1] - cb;
+    if (lane < clen) crow[lane] = cidx[cb + lane];
+    for (int q = lane; q < clen * DC * DC; q += 64) cacc[q] = 0.0;
+    __syncthreads();
+    const int32_t kb = aptr[I], ke = aptr[I + 1];
+    for (int32_t k0 = kb; k0 < ke; k0 += 2) {
+      const int32_t k = k0 + half;
+      const bool ok = k < ke;
+      const int64_t n = ok ? amem[k] : 0;
+      const int32_t rb = ok ? ptr[n] : 0, rl = ok ? ptr[n + 1] - rb : 0;
+      double Pn[DR][DC];
+      amg_P<DIM, DR, DC>(xy + DIM * n, cxy + DIM * I, iso + DR * n, Pn);
+      const int32_t rlmax = max(__shfl(rl, 0), __shfl(rl, 32));
+      for (int32_t g0 = 0; g0 < rlmax; g0 += 32) {
+        const int32_t go = g0 + sub;
+        if (!ok || go >= rl) continue;
+        const int32_t g = rb + go;
+        const int64_t m = idx[g];
+        const int32_t J = agg[m];
+        if (J < (int32_t)I) continue;  // symmetric: mirrored afterwards
+        double Pm[DR][DC];
+        amg_P<DIM, DR, DC>(xy + DIM * m, cxy + DIM * (int64_t)J, iso + DR * m, Pm);
+        const double* a = vals + (int64_t)g * DR * DR;
+        double AP[DR][DC];  // A[n,m] P_m
+#pragma unroll
+        for (int r = 0; r < DR; ++r)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) {
+            double t2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < DR; ++t) t2 += a[r * DR + t] * Pm[t][c];
+            AP[r][c] = t2;
+          }
+        int pos = 0;
+        while (pos < clen - 1 && crow[pos] != J) ++pos;  // J is in the row by construction; bounded anyway
+#pragma unroll
+        for (int r = 0; r < DC; ++r)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) {
+            double t2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < DR; ++t) t2 += Pn[t][r] * AP[t][c];
+            __hip_atomic_fetch_add(cacc + (pos * DC + r) * DC + c, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+      }
+    }
+    __syncthreads();
+    double* dst = cvals + (int64_t)cb * DC * DC;
+    for (int q = lane; q < clen * DC * DC; q += 64) dst[q] = cacc[q];
+    __syncthreads();
+  }
+}
+
 // generic block SpMV for the coarse levels: 64-node tiles, blocks streamed lane-per-block through LDS.
 // MODE fuses the smoother into the product (the coarse levels are launch-bound, every fused pass counts):
 //   AMG_AX   y = A x                         AMG_RESID  y = b - A x
@@ -672,10 +744,12 @@ __global__ void k_sa_galerkin(int64_t nc, const int32_t* __restrict__ tptr, cons
 
 // The same product with one WAVE per coarse row (rows of at most 64 couplings): lanes split the (n, m) pairs --
 // four entries of the column of I times sixteen neighbour slots per pass -- and add their DC x DC contributions
-// into an LDS image of the row with LDS atomics; the row is then written out once.  The lane-per-row kernel above
+// into an LDS image of the row with LDS atomics; the row is then written out once.  NW waves share a row (its
+// column entries dealt round-robin) on levels with few, long columns: 1331 coarse rows of ~200 entries each on the
+// second level of 96^3 blocks kept one wave per row busy for 7 ms.  The lane-per-row kernel above
 // takes 15 ms for the 233 k coarse rows of the 2048x1024 plane-stress matrix; this one well under one.
-template <int DR, int DC>
-__global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32_t* __restrict__ tptr,
+template <int DR, int DC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const int32_t* __restrict__ tptr,
                                                          const int32_t* __restrict__ tnode,
                                                          const int32_t* __restrict__ tslot,
                                                          const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
@@ -687,13 +761,14 @@ __global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32
                                                          const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
   __shared__ int32_t crow[64];
   __shared__ double cacc[64 * DC * DC];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
     const int32_t cb = cptr[I], clen = cptr[I + 1] - cb;
-    if (lane < clen) crow[lane] = cidx[cb + lane];
-    for (int q = lane; q < clen * DC * DC; q += 64) cacc[q] = 0.0;
+    if ((int)threadIdx.x < clen) crow[threadIdx.x] = cidx[cb + threadIdx.x];
+    for (int q = threadIdx.x; q < clen * DC * DC; q += 64 * NW) cacc[q] = 0.0;
+    __syncthreads();
     const int32_t tb = tptr[I], te = tptr[I + 1];
-    for (int32_t e0 = tb; e0 < te; e0 += 4) {
+    for (int32_t e0 = tb + 4 * wave; e0 < te; e0 += 4 * NW) {
       const int32_t e = e0 + (lane >> 4);
       const bool eok = e < te;
       const int64_t n = eok ? tnode[e] : 0;
@@ -736,14 +811,17 @@ __global__ __launch_bounds__(64) void k_sa_galerkin_wave(int64_t nc, const int32
                 double s = 0.0;
 #pragma unroll
                 for (int t = 0; t < DR; ++t) s += T[c][t] * Pm[t * DC + c2];
-                __hip_atomic_fetch_add(cacc + (pos * DC + c) * DC + c2, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __hip_atomic_fetch_add(cacc + (pos * DC + c) * DC + c2, s, __ATOMIC_RELAXED,
+                                       NW == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
               }
           }
         }
       }
     }
+    __syncthreads();
     double* dst = cvals + (int64_t)cb * DC * DC;
-    for (int q = lane; q < clen * DC * DC; q += 64) dst[q] = cacc[q];
+    for (int q = threadIdx.x; q < clen * DC * DC; q += 64 * NW) dst[q] = cacc[q];
+    __syncthreads();
   }
 }
 
@@ -823,6 +901,40 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
 #pragma unroll
       for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
   }
+}
+
+// The same restriction with one wave per coarse row, for levels whose columns of P are long and few (3-D: ~200
+// entries per coarse node, 1331 coarse nodes on the second level of 96^3 blocks -- 21 tiles of 64 rows left the
+// stream kernel on 21 waves, 300 us per call).  Lanes stride over the column, fixed-order wave sum: deterministic.
+template <int DR, int DC>
+__global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int32_t* __restrict__ tptr,
+                                                          const int32_t* __restrict__ tnode,
+                                                          const double* __restrict__ ptvals,
+                                                          const double* __restrict__ resid, double* __restrict__ bc) {
+  const int lane = threadIdx.x & 63;
+  const int64_t I = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (I >= nc) return;  // wave-uniform
+  double acc[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) acc[c] = 0.0;
+  for (int32_t e = tptr[I] + lane; e < tptr[I + 1]; e += 64) {
+    const int64_t n = tnode[e];
+    const double* Pn = ptvals + (int64_t)e * DR * DC;
+    double rv[DR];
+#pragma unroll
+    for (int r = 0; r < DR; ++r) rv[r] = resid[DR * n + r];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) acc[c] += Pn[r * DC + c] * rv[r];
+  }
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
 }
 
 // x_n += over * sum_J P[n,J] e_J
@@ -1202,10 +1314,10 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
       if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s (%s)\n", l, now() - t_c, dptr_c ? "device" : "host");
       PF_HIP(hipMalloc(&Lv.pvals, sizeof(double) * Lv.np * Lv.dr * dc));
       PF_HIP(hipMalloc(&Lv.ptvals, sizeof(double) * Lv.np * Lv.dr * dc));
-      Lv.max_crow = 0;
-      for (int64_t I = 0; I < nc; ++I) Lv.max_crow = std::max(Lv.max_crow, cptr[I + 1] - cptr[I]);
       PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
     }
+    Lv.max_crow = 0;
+    for (int64_t I = 0; I < nc; ++I) Lv.max_crow = std::max(Lv.max_crow, cptr[I + 1] - cptr[I]);
     if (rc == PF_OK && !Lv.agg) rc = to_device(ctx, agg, Lv.agg);
     if (rc == PF_OK) rc = to_device(ctx, aptr, Lv.aptr);
     if (rc == PF_OK) rc = to_device(ctx, amem, Lv.amem);
@@ -1342,8 +1454,12 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 #define PF_SAG(DR_, DC_)                                                                                         \
         do {                                                                                                     \
           if (Lv.max_crow <= 64) {                                                                               \
-            k_sa_galerkin_wave<DR_, DC_><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>(     \
-                Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+            if (Lv.np >= 48 * Lv.nc)                                                                             \
+              k_sa_galerkin_wave<DR_, DC_, 4><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 256, 0, ctx->stream>>>( \
+                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+            else                                                                                                 \
+              k_sa_galerkin_wave<DR_, DC_, 1><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>( \
+                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
             k_sa_mirror_lower<DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Nx.ptr, Nx.idx, Nx.vals);                  \
           } else                                                                                                   \
             k_sa_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, \
@@ -1360,8 +1476,15 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 #undef PF_SAG
       } else {
 #define PF_GAL(DIM_, DR_, DC_)                                                                                \
-        k_amg_galerkin<DIM_, DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
-                                                                   Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals)
+        do {                                                                                                  \
+          if (Lv.max_crow <= 64) {                                                                            \
+            k_amg_galerkin_wave<DIM_, DR_, DC_><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>( \
+                Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals); \
+            k_sa_mirror_lower<DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Nx.ptr, Nx.idx, Nx.vals);               \
+          } else                                                                                                \
+            k_amg_galerkin<DIM_, DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.agg, Lv.ptr, Lv.idx, Lv.vals, \
+                                                                       Lv.iso, Lv.xy, Nx.xy, Nx.ptr, Nx.idx, Nx.vals); \
+        } while (0)
         if (Lv.dr == 1) PF_GAL(2, 1, 1);
         else if (H->dim == 3 && Lv.dr == 3) PF_GAL(3, 3, 6);
         else if (H->dim == 3) PF_GAL(3, 6, 6);
@@ -1442,8 +1565,13 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
     if (Lv.sa) {
 #define PF_SAR(DR_, DC_)                                                                                    \
-  k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, \
-                                                                                                   Lv.ptvals, o, Nx.b)
+  do {                                                                                                      \
+    if (Lv.np >= 48 * Lv.nc) /* long columns, few of them: a wave per coarse row */                          \
+      k_sa_restrict_wave<DR_, DC_><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, Nx.b); \
+    else                                                                                                    \
+      k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, \
+                                                                                                       Lv.ptvals, o, Nx.b); \
+  } while (0)
       if (Lv.dr == 1) PF_SAR(1, 1);
       else if (H->dim == 3 && Lv.dr == 3) PF_SAR(3, 6);
       else if (H->dim == 3) PF_SAR(6, 6);
