@@ -189,12 +189,44 @@ def main_3d(pyfem):
     print("mesh3d_4x3x3 written")
 
 
+def main_highorder(pyfem):
+    """10-node tetrahedra and 20-node bricks (pyfem.py:115-172, 380-632, 2538-2700; tests/test_elements.py): mesh
+    generator, K with nodal RAMP density on a distorted mesh, first element matrix, sensitivities.  The generator
+    leaves grid nodes that no element uses (K is singular on them), so no solution is stored."""
+    for etype, shape, Qc, Bc in (("tet", (5, 5, 3), "QuadratureTetrahedron5Point", "BasisTetrahedron10node"),
+                                 ("brick20", (5, 5, 5), "QuadratureBrick333Point", "BasisBrick20Nodes")):
+        c = pyfem.ProblemCreator(*shape, element_type=etype)
+        conn, X, dof_fixed, nodal_force = c.create_linear_elasticity_problem()
+        rng = np.random.RandomState(21)
+        Xd = X + 0.03 * (rng.rand(*X.shape) - 0.5)
+        rho = 0.1 + 0.9 * rng.rand(X.shape[0])
+        q = getattr(pyfem, Qc)()
+        b = getattr(pyfem, Bc)(q)
+        model = pyfem.LinearElasticity(Xd, conn, dof_fixed, None, nodal_force, q, b, p=5.0)
+        K = model.compute_jacobian(rho)
+        np.random.seed(0)
+        phi, psi = np.random.rand(3 * Xd.shape[0]), np.random.rand(3 * Xd.shape[0])
+        out = dict(X0=X, X=Xd, conn=conn.astype(np.int32), dof_fixed=np.asarray(dof_fixed, dtype=np.int32),
+                   force_nodes=np.array(list(nodal_force.keys()), dtype=np.int32),
+                   force_vals=np.array(list(nodal_force.values()), dtype=float), rho=rho, p=np.float64(5.0),
+                   Ke0=model.Ke_mat[0].copy(), phi=phi, psi=psi, sens=model._compute_K_dv_sens(rho, phi, psi).copy(),
+                   qpts=np.asarray(q.get_pt()), qw=np.asarray(q.get_weight()),
+                   N=np.asarray(b.eval_shape_fun()), dN=np.asarray(b.eval_shape_fun_deriv()))
+        out.update(_csr(K, "K"))
+        name = f"ho_{etype}_{shape[0]}x{shape[1]}x{shape[2]}"
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(f"{name}: nelems={conn.shape[0]} nnz={K.nnz} |K|={np.linalg.norm(K.data):.13e}")
+
+
 def main():
     pyfem, parse_inp = _import_reference()
     os.makedirs(OUT, exist_ok=True)
+    if "--only-ho" in sys.argv:
+        return main_highorder(pyfem)
     if "--only-3d" in sys.argv:
         return main_3d(pyfem)
     main_3d(pyfem)
+    main_highorder(pyfem)
 
     # --- PS32: the reference's own test case (tests/test_elasticity.py:23-51) ------------
     c = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)

@@ -37,13 +37,61 @@ def quadrature(etype):
         g = 1.0 / np.sqrt(3.0)
         pts = np.array([[sx * g, sy * g, sz * g] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
         return pts, np.ones(8)
+    if etype == "tet":  # 5-point rule on the unit tetrahedron, centroid weight -4/5 (ref: pyfem.py:115-134)
+        pts = np.full((5, 3), 1.0 / 6)
+        pts[0] = 0.25
+        pts[1, 0] = pts[2, 1] = pts[3, 2] = 0.5
+        return pts, np.array([-0.8, 0.45, 0.45, 0.45, 0.45])
+    if etype == "brick20":  # 3x3x3 Gauss, x fastest; the weights are the reference's 10-digit literals (pyfem.py:137-172)
+        g = np.sqrt(0.6)
+        k, j, i = np.meshgrid([-1, 0, 1], [-1, 0, 1], [-1, 0, 1], indexing="ij")
+        pts = g * np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1)
+        nzero = (np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1) == 0).sum(axis=1)
+        return pts, np.array([0.1714677641, 0.2743484225, 0.4389574760, 0.7023319616])[nzero]
     raise ValueError(f"unknown element_type: {etype}")
+
+
+BRICK20_NODES = np.array(  # corners CCW on z=-1 then z=+1, mid-edges of the two faces, then the vertical edges
+    [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
+     [0, -1, -1], [1, 0, -1], [0, 1, -1], [-1, 0, -1], [0, -1, 1], [1, 0, 1], [0, 1, 1], [-1, 0, 1],
+     [-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=float)  # ref: pyfem.py:461-484
 
 
 def shape_tables(etype):
     """N (Q,P) and dN/dxi (Q,P,2) at the quadrature points
     (ref: pyfem.py:222-250 driver, :262-284 quad, :365-377 tri)."""
     pts, _ = quadrature(etype)
+    if etype == "tet":  # quadratic tetrahedron in the volume coordinates t = (1-x-y-z, x, y, z)  (ref: pyfem.py:380-445)
+        t = np.concatenate([1.0 - pts.sum(axis=1, keepdims=True), pts], axis=1)  # (Q,4)
+        dt = np.array([[-1.0, -1.0, -1.0], [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]])  # (4,3)
+        edges = [(0, 1), (1, 2), (2, 0), (0, 3), (1, 3), (2, 3)]  # nodes 4..9
+        N = np.empty((pts.shape[0], 10))
+        dN = np.empty((pts.shape[0], 10, 3))
+        N[:, :4] = t * (2.0 * t - 1.0)
+        dN[:, :4] = (4.0 * t - 1.0)[:, :, None] * dt[None]
+        for n, (a, b) in enumerate(edges):
+            N[:, 4 + n] = 4.0 * t[:, a] * t[:, b]
+            dN[:, 4 + n] = 4.0 * (t[:, a, None] * dt[b][None] + t[:, b, None] * dt[a][None])
+        return N, dN
+    if etype == "brick20":  # serendipity brick (ref: pyfem.py:448-632)
+        c = BRICK20_NODES
+        f = 1.0 + pts[:, None, :] * c[None, :, :]  # (Q,20,3)
+        N = np.empty((pts.shape[0], 20))
+        dN = np.empty((pts.shape[0], 20, 3))
+        s8 = (pts[:, None, :] * c[None, :8, :]).sum(axis=2)  # xi.c for the corners
+        N[:, :8] = 0.125 * f[:, :8, 0] * f[:, :8, 1] * f[:, :8, 2] * (s8 - 2.0)
+        for d in range(3):
+            o1, o2 = (d + 1) % 3, (d + 2) % 3
+            dN[:, :8, d] = 0.125 * c[None, :8, d] * f[:, :8, o1] * f[:, :8, o2] * (s8 + pts[:, None, d] * c[None, :8, d] - 1.0)
+        for n in range(8, 20):
+            z = int(np.flatnonzero(c[n] == 0.0)[0])  # the direction the edge runs along
+            o1, o2 = (z + 1) % 3, (z + 2) % 3
+            q = 1.0 - pts[:, z] ** 2
+            N[:, n] = 0.25 * q * f[:, n, o1] * f[:, n, o2]
+            dN[:, n, z] = -0.5 * pts[:, z] * f[:, n, o1] * f[:, n, o2]
+            dN[:, n, o1] = 0.25 * q * c[n, o1] * f[:, n, o2]
+            dN[:, n, o2] = 0.25 * q * f[:, n, o1] * c[n, o2]
+        return N, dN
     if etype == "block":  # trilinear hexahedron, nodes CCW on z=-1 then z=+1 (ref: pyfem.py:287-338)
         sg = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1],
                        [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
@@ -112,6 +160,35 @@ def structured_mesh3d(nnodes_x, nnodes_y, nnodes_z, Lx=None, Ly=None, Lz=None):
     n0 = (i + j * nnodes_x + k * nnodes_x * nnodes_y).ravel()
     lo = np.stack([n0, n0 + 1, n0 + 1 + nnodes_x, n0 + nnodes_x], axis=1)
     conn = np.concatenate([lo, lo + nnodes_x * nnodes_y], axis=1)
+    return conn.astype(np.int64), X
+
+
+TET_CORNERS = np.array(  # the six tetrahedra of a 2x2x2-cell patch, corner offsets (x,y,z) in cells (ref: pyfem.py:2547-2556)
+    [[(0, 0, 0), (2, 0, 0), (2, 2, 0), (2, 2, 2)], [(0, 0, 0), (2, 0, 0), (2, 2, 2), (0, 0, 2)],
+     [(2, 0, 0), (2, 2, 2), (0, 0, 2), (2, 0, 2)], [(0, 0, 0), (0, 2, 0), (0, 2, 2), (2, 2, 0)],
+     [(0, 0, 0), (0, 2, 2), (0, 0, 2), (2, 2, 2)], [(0, 0, 0), (2, 2, 2), (2, 2, 0), (0, 2, 2)]])
+
+
+def structured_mesh3d_ho(nnodes_x, nnodes_y, nnodes_z, etype):
+    """ProblemCreator(element_type="tet" | "brick20") on the same node grid as the block mesh (odd node counts).
+    tet: every 2x2x2-cell patch (patches x fastest) holds six 10-node tetrahedra: corners from TET_CORNERS, then the
+    midpoints of the edges (0,1),(1,2),(0,2),(0,3),(1,3),(2,3)  (ref: pyfem.py:2538-2655).
+    brick20: one brick per 2x2x2-cell patch, corners, then the mid-edge nodes of the bottom face, the top face and the
+    four vertical edges (ref: pyfem.py:2657-2700).  Grid nodes no element uses stay in X."""
+    _, X = structured_mesh3d(nnodes_x, nnodes_y, nnodes_z)
+    nid = lambda c: c[..., 0] + c[..., 1] * nnodes_x + c[..., 2] * nnodes_x * nnodes_y  # noqa: E731
+    px, py, pz = (nnodes_x - 1) // 2, (nnodes_y - 1) // 2, (nnodes_z - 1) // 2
+    k, j, i = np.meshgrid(np.arange(pz), np.arange(py), np.arange(px), indexing="ij")
+    origin = 2 * np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1)  # (patches,3)
+    if etype == "tet":
+        corners = origin[:, None, None, :] + TET_CORNERS[None]  # (patches,6,4,3)
+        pairs = [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
+        mids = np.stack([(corners[:, :, a] + corners[:, :, b]) // 2 for a, b in pairs], axis=2)
+        conn = nid(np.concatenate([corners, mids], axis=2)).reshape(-1, 10)
+    elif etype == "brick20":
+        conn = nid(origin[:, None, :] + (BRICK20_NODES[None].astype(np.int64) + 1))
+    else:
+        raise ValueError(f"unknown element_type: {etype}")
     return conn.astype(np.int64), X
 
 

@@ -202,3 +202,27 @@ def test_block_poisson_matches_reference():
 
     assert relmax(spsolve(Kbc.tocsc(), rhs_bc), g["u"]) < U_TOL
     assert relmax(orc.poisson_K_dv_sens(X, conn, "block", g["rho"], g["phi"], g["psi"], p), g["sens"]) < 1e-13
+
+
+@pytest.mark.parametrize("name,etype,shape", [("ho_tet_5x5x3", "tet", (5, 5, 3)), ("ho_brick20_5x5x5", "brick20", (5, 5, 5))])
+def test_quadratic_elements_match_reference(name, etype, shape):
+    """10-node tetrahedra / 20-node bricks (pyfem.py:115-172, 380-632, 2538-2700): tables, mesh generator, K with
+    nodal RAMP density on a distorted mesh, sensitivities."""
+    g = load(name)
+    pts, w = orc.quadrature(etype)
+    N, dN = orc.shape_tables(etype)
+    assert np.abs(pts - g["qpts"]).max() < 1e-15 and np.abs(w - g["qw"]).max() == 0.0
+    assert np.abs(N - g["N"]).max() < 1e-15 and np.abs(dN - g["dN"]).max() < 1e-15
+    conn, X = orc.structured_mesh3d_ho(*shape, etype)
+    assert np.array_equal(conn, g["conn"]) and np.array_equal(X, g["X0"])
+    dof_fixed, force = orc.elasticity_problem3d(*shape)
+    assert np.array_equal(dof_fixed, g["dof_fixed"]) and list(force) == list(g["force_nodes"])
+    conn = g["conn"].astype(np.int64)
+    Ke = orc.elasticity_Ke(g["X"], conn, etype, rho=g["rho"], p=float(g["p"]))
+    assert relmax(Ke[0], g["Ke0"]) < K_TOL
+    K = orc.assemble_csr(Ke, orc.create_conn_dof(conn, 3))
+    Kref = csr_of(g, "K", K.shape[0])
+    assert np.array_equal(K.indptr, Kref.indptr) and np.array_equal(K.indices, Kref.indices)
+    assert np.abs(K.data - Kref.data).max() < K_TOL * np.abs(Kref.data).max()
+    s = orc.elasticity_K_dv_sens(g["X"], conn, etype, g["rho"], g["phi"], g["psi"], p=float(g["p"]))
+    assert relmax(s, g["sens"]) < 1e-12
