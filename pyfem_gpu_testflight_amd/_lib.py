@@ -41,6 +41,9 @@ SIGNATURES = {
     "pf_assemble_helmholtz3d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_element_matrices3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     "pf_sens3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "pf_assemble_elasticity_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp]),
+    "pf_element_matrices_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp]),
+    "pf_sens_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "pf_quad_points3d": (C.c_int, [_vp, _vp]),
     "pf_poisson_rhs3d": (C.c_int, [_vp, _vp, _vp]),
     "pf_element_matrices_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),

@@ -98,6 +98,22 @@ static void aggregate_host(int64_t n, const std::vector<int32_t>& ptr, const std
   agg.assign(n, -1);
   nc = 0;
   std::vector<int32_t> root;
+  // pass 0: nodes coupled to nothing but themselves -- grid nodes no element uses (the 20-node brick generator leaves
+  // half of its grid empty) and, one level down, their aggregates -- are bundled 64 at a time, so that they vanish
+  // from the hierarchy geometrically instead of surviving as one-node aggregates on every level
+  int32_t bundle = -1;
+  int bundled = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    bool lonely = true;
+    for (int32_t g = ptr[i]; g < ptr[i + 1] && lonely; ++g) lonely = idx[g] == (int32_t)i;
+    if (!lonely) continue;
+    if (bundled % 64 == 0) {
+      bundle = (int32_t)nc++;
+      root.push_back((int32_t)i);
+    }
+    agg[i] = bundle;
+    ++bundled;
+  }
   // pass 1: a node whose whole neighbourhood is free becomes the root of a new aggregate
   for (int64_t i = 0; i < n; ++i) {
     if (agg[i] != -1 || ptr[i + 1] == ptr[i]) continue;

@@ -131,6 +131,59 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
   }
 }
 
+// Rows for elements outside the three hard-wired shapes (10-node tetrahedra, 20-node bricks, ...: the table-driven
+// path of pf_tabular3d.hip): runtime P, up to MAXNB_TAB neighbours (a corner shared by eight 20-node bricks has 81),
+// no byte-position tables -- that path finds positions by bisection.
+static constexpr int MAXNB_TAB = 160;
+
+__device__ inline int collect_row_tab(int P, int64_t n, const int32_t* __restrict__ conn,
+                                      const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e, int32_t* nb) {
+  int cnt = 0;
+  for (int32_t j = n2e_ptr[n]; j < n2e_ptr[n + 1]; ++j) {
+    const int32_t e = n2e[j] / P;
+    for (int b = 0; b < P; ++b) {
+      const int32_t m = conn[(int64_t)e * P + b];
+      int k = 0;
+      while (k < cnt && nb[k] < m) ++k;
+      if (k < cnt && nb[k] == m) continue;
+      if (cnt == MAXNB_TAB) return -1;
+      for (int t = cnt; t > k; --t) nb[t] = nb[t - 1];
+      nb[k] = m;
+      ++cnt;
+    }
+  }
+  return cnt;
+}
+
+__global__ void k_row_count_tab(int P, int64_t nnodes, const int32_t* __restrict__ conn,
+                                const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                                int32_t* __restrict__ rowcnt, int32_t* __restrict__ flag) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t nb[MAXNB_TAB];
+  int c = collect_row_tab(P, n, conn, n2e_ptr, n2e, nb);
+  if (c < 0) {
+    atomicOr(flag, 1);
+    c = 0;
+  }
+  rowcnt[n] = c;
+}
+
+__global__ void k_row_fill_tab(int P, int64_t nnodes, const int32_t* __restrict__ conn,
+                               const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
+                               const int32_t* __restrict__ nptr, int32_t* __restrict__ nidx,
+                               uint8_t* __restrict__ diagpos) {
+  const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  int32_t nb[MAXNB_TAB];
+  const int c = collect_row_tab(P, n, conn, n2e_ptr, n2e, nb);
+  const int32_t base = nptr[n];
+  for (int k = 0; k < c; ++k) {
+    nidx[base + k] = nb[k];
+    if (nb[k] == (int32_t)n) diagpos[n] = (uint8_t)k;
+  }
+}
+
 // visit-ordered element records for the assembly kernel, ONE 16-byte load per incident pair jj of
 // node n:  {o0, o1, o2, w}  where o* are the element's node ids other than n (ascending local index) and
 //   w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | (slot of n in its tile)<<26
@@ -327,7 +380,8 @@ extern "C" int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t
 extern "C" int pf_mesh_set3d(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P, const int32_t* conn,
                              int on_device) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(P == PF_BLOCK8, "pf_mesh_set3d: only the 8-node block element is on this path");
+  PF_REQUIRE(P >= 4 && P <= PF_TAB_MAX_NODES, "pf_mesh_set3d: 4 to 32 nodes per element (8: the hard-wired block kernels, "
+                                               "anything else: the table-driven element of pf_*_tab3d)");
   return mesh_set(ctx, 3, nnodes, X, nelems, P, conn, on_device);
 }
 
@@ -385,6 +439,29 @@ static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
   return PF_OK;
 }
 
+static int build_rows_tab(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
+  const int64_t nn = ctx->nnodes;
+  const int T = 64;
+  k_row_count_tab<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(ctx->P, nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, rowcnt, flag);
+  PF_LAUNCH_CHECK();
+  int32_t f = 0;
+  PF_HIP(hipMemcpyAsync(&f, flag, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  if (f) return pf_fail(ctx, PF_E_UNSUPPORTED, "pf_pattern_build: a node has more than 160 neighbours");
+  int rc = exclusive_scan_i32(ctx, rowcnt, ctx->nptr, nn + 1);
+  if (rc) return rc;
+  int32_t total = 0;
+  PF_HIP(hipMemcpyAsync(&total, ctx->nptr + nn, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->nblocks = total;
+  PF_HIP(hipMalloc(&ctx->nidx, sizeof(int32_t) * (size_t)total));
+  PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
+  k_row_fill_tab<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(ctx->P, nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
+                                                               ctx->nidx, ctx->diagpos);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
 extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->conn, "pf_pattern_build: call pf_mesh_set first");
@@ -417,7 +494,9 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   PF_LAUNCH_CHECK();
   // row counts go into cnt (reused), scanned into nptr
   PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (nn + 1), ctx->stream));
-  rc = (ctx->P == 8) ? build_rows<8>(ctx, cnt, flag) : (ctx->P == 4) ? build_rows<4>(ctx, cnt, flag) : build_rows<3>(ctx, cnt, flag);
+  const bool tabular = ctx->ndims == 3 && ctx->P != 8;  // table-driven elements: rows only, no tiles / visit records
+  rc = tabular ? build_rows_tab(ctx, cnt, flag)
+       : (ctx->P == 8) ? build_rows<8>(ctx, cnt, flag) : (ctx->P == 4) ? build_rows<4>(ctx, cnt, flag) : build_rows<3>(ctx, cnt, flag);
   if (rc == PF_OK) rc = max_i32(ctx, cnt, nn, &ctx->max_row_blocks);
   (void)hipFree(cnt);
   (void)hipFree(cursor);
@@ -432,7 +511,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
   // valence 6-8 get up to 10 nodes = 60 lanes instead of 8 nodes = 48) and keep the LDS image of the tile's rows
   // (npt * max_row_blocks blocks of d*d doubles, two planes for the scalar K+R pair) within ~20 KB per wave.
   ctx->npt = 0;
-  if (ctx->max_valence <= 64) {
+  if (ctx->max_valence <= 64 && !tabular) {
     const int64_t row_bytes = (int64_t)ctx->max_row_blocks * d * d * 8 * (d == 1 ? 2 : 1);
     for (int c = 16; c >= 1; c >>= 1)
       if ((c * ctx->max_valence <= 128 && c * row_bytes <= 20 * 1024) || c == 1) { ctx->npt = c; break; }

@@ -27,7 +27,7 @@ def _ptr(t):
 class HipContext:
     """Owns a pf_ctx: device mesh copy + symbolic pattern.  ref: ModelBase.__init__ (pyfem.py:640-757)."""
 
-    def __init__(self, X, conn, ndof_per_node, device=None):
+    def __init__(self, X, conn, ndof_per_node, device=None, tables=None):
         torch = _torch()
         self.torch = torch
         self.lib = _lib.load()
@@ -39,9 +39,16 @@ class HipContext:
         if X.ndim != 2 or X.shape[1] not in (2, 3):
             raise ValueError("X must have shape (nnodes, 2) or (nnodes, 3)")
         self.ndims = X.shape[1]
-        if conn.ndim != 2 or conn.shape[1] not in ((3, 4) if self.ndims == 2 else (8,)):
-            raise ValueError(f"unknown element_type: {conn.shape[1]}-node elements in {self.ndims}-D are not on the "
-                             "accelerated path (2-D: 3-node triangles, 4-node quads; 3-D: 8-node blocks)")
+        # tables = (N (Q,P), dN (Q,P,3), wq (Q)): a 3-D element given as data (10-node tetrahedra, 20-node bricks, ...)
+        self.tabular = tables is not None
+        if self.tabular:
+            ok = conn.ndim == 2 and self.ndims == 3 and conn.shape[1] != 8 and 4 <= conn.shape[1] <= 32
+        else:
+            ok = conn.ndim == 2 and conn.shape[1] in ((3, 4) if self.ndims == 2 else (8,))
+        if not ok:
+            raise ValueError(f"unknown element_type: {conn.shape[1] if conn.ndim == 2 else '?'}-node elements in "
+                             f"{self.ndims}-D are not on the accelerated path (2-D: 3-node triangles, 4-node quads; "
+                             "3-D: 8-node blocks, or 4..32 nodes with the basis tables)")
         conn32 = np.ascontiguousarray(conn, dtype=np.int32)
         self.nnodes, self.nelems, self.P, self.d = X.shape[0], conn.shape[0], conn.shape[1], int(ndof_per_node)
         self._sync_stream()
@@ -53,6 +60,18 @@ class HipContext:
         self._call("pf_pattern_dims", C.byref(nrows), C.byref(nnz), C.byref(nblocks), C.byref(maxrow))
         self.nrows, self.nnz, self.nblocks, self.max_row_blocks = nrows.value, nnz.value, nblocks.value, maxrow.value
         self._csr_structure = None
+        if self.tabular:
+            if self.d != 3:
+                raise ValueError("table-driven elements are built for 3 dofs per node (elasticity)")
+            N, dN, wq = (np.ascontiguousarray(t, dtype=np.float64) for t in tables)
+            Q = wq.shape[0]
+            if N.shape != (Q, self.P) or dN.shape != (Q, self.P, 3) or Q > 64:
+                raise ValueError("basis tables must be N (Q,P), dN (Q,P,3), weights (Q), Q <= 64")
+            self.Q = Q
+            self._tab = tuple(self.to_device(t, torch.float64) for t in (N, dN, wq))
+
+    def _tab_args(self):
+        return (self.Q,) + tuple(_ptr(t) for t in self._tab)
 
     # -- plumbing -------------------------------------------------------------------------
     def _sync_stream(self):
@@ -110,7 +129,9 @@ class HipContext:
     def assemble_elasticity(self, E, nu, p, rho=None, mode=_lib.PF_SCATTER_GATHER, out=None):
         vals = self.empty(self.nnz) if out is None else out
         self._sync_stream()
-        if self.ndims == 3:
+        if self.tabular:
+            self._call("pf_assemble_elasticity_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(vals))
+        elif self.ndims == 3:
             self._call("pf_assemble_elasticity3d", E, nu, p, _ptr(rho), _ptr(vals))
         else:
             self._call("pf_assemble_elasticity2d", E, nu, p, _ptr(rho), mode, _ptr(vals))
@@ -125,7 +146,9 @@ class HipContext:
     def sens_elasticity(self, E, nu, p, rho, phi, psi):
         out = self.empty(self.nnodes)
         self._sync_stream()
-        if self.ndims == 3:
+        if self.tabular:
+            self._call("pf_sens_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        elif self.ndims == 3:
             self._call("pf_sens3d", 0, E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
         else:
             self._call("pf_sens_elasticity2d", E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
@@ -172,7 +195,9 @@ class HipContext:
         D = self.P * self.ndims
         out = self.empty(self.nelems * D * D)
         self._sync_stream()
-        if self.ndims == 3:
+        if self.tabular:
+            self._call("pf_element_matrices_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(out))
+        elif self.ndims == 3:
             self._call("pf_element_matrices3d", 0, E, nu, p, 0.0, _ptr(rho), _ptr(out), None)
         else:
             self._call("pf_element_matrices_elasticity2d", E, nu, p, _ptr(rho), _ptr(out))

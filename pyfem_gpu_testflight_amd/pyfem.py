@@ -88,6 +88,28 @@ class QuadratureBlock3D(QuadratureBase):
         super().__init__([[sx * g, sy * g, sz * g] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], [1.0] * 8)
 
 
+class QuadratureTetrahedron5Point(QuadratureBase):
+    """ref: pyfem.py:115-134 -- centroid (weight -4/5) and the four points (1/2, 1/6, 1/6) ... (1/6, 1/6, 1/6) (9/20)."""
+
+    def __init__(self):
+        pts = np.full((5, 3), 1.0 / 6)
+        pts[0] = 0.25
+        pts[1, 0] = pts[2, 1] = pts[3, 2] = 0.5
+        super().__init__(pts, [-4 / 5, 9 / 20, 9 / 20, 9 / 20, 9 / 20])
+
+
+class QuadratureBrick333Point(QuadratureBase):
+    """ref: pyfem.py:137-172 -- 3x3x3 Gauss points at 0, +-sqrt(3/5), x fastest; weights are the reference's
+    10-digit products of 5/9 and 8/9, by the number of zero coordinates."""
+
+    _W = np.array([0.1714677641, 0.2743484225, 0.4389574760, 0.7023319616])
+
+    def __init__(self):
+        k, j, i = np.meshgrid([-1, 0, 1], [-1, 0, 1], [-1, 0, 1], indexing="ij")
+        ijk = np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1)
+        super().__init__(ijk * np.sqrt(3.0 / 5.0), self._W[(ijk == 0).sum(axis=1)])
+
+
 class BasisBase:
     def __init__(self, ndims, nnodes_per_elem, quadrature):
         self.ndims = ndims
@@ -143,6 +165,70 @@ class BasisBlock3D(BasisBase):
         return list(d.ravel())
 
 
+class BasisTetrahedron10node(BasisBase):
+    """ref: pyfem.py:380-445 -- quadratic tetrahedron: corners t_i (2 t_i - 1) in the volume coordinates
+    t = (1 - x - y - z, x, y, z), then 4 t_a t_b on the edges (0,1), (1,2), (2,0), (0,3), (1,3), (2,3)."""
+
+    _EDGES = ((0, 1), (1, 2), (2, 0), (0, 3), (1, 3), (2, 3))
+    _DT = np.array([[-1.0, -1.0, -1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+
+    def __init__(self, quadrature):
+        super().__init__(3, 10, quadrature)
+
+    def _eval_shape_fun_on_quad_pt(self, q):
+        t = np.array([1.0 - q[0] - q[1] - q[2], q[0], q[1], q[2]])
+        return np.concatenate([t * (2.0 * t - 1.0), [4.0 * t[a] * t[b] for a, b in self._EDGES]])
+
+    def _eval_shape_deriv_on_quad_pt(self, q):
+        t = np.array([1.0 - q[0] - q[1] - q[2], q[0], q[1], q[2]])
+        d = np.empty((10, 3))
+        d[:4] = (4.0 * t - 1.0)[:, None] * self._DT
+        for n, (a, b) in enumerate(self._EDGES):
+            d[4 + n] = 4.0 * (t[a] * self._DT[b] + t[b] * self._DT[a])
+        return d.ravel()
+
+
+class BasisBrick20Nodes(BasisBase):
+    """ref: pyfem.py:448-632 -- 20-node serendipity brick: corners CCW on z=-1 then z=+1, mid-edge nodes of the two
+    faces, then of the vertical edges."""
+
+    _NODES = np.array(
+        [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
+         [0, -1, -1], [1, 0, -1], [0, 1, -1], [-1, 0, -1], [0, -1, 1], [1, 0, 1], [0, 1, 1], [-1, 0, 1],
+         [-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], dtype=float)
+
+    def __init__(self, quadrature):
+        self.nodecoords = self._NODES.copy()
+        super().__init__(3, 20, quadrature)
+
+    def _eval_shape_fun_on_quad_pt(self, q):
+        c, q = self.nodecoords, np.asarray(q, dtype=float)
+        f = 1.0 + c * q[None, :]
+        N = np.empty(20)
+        N[:8] = 0.125 * f[:8, 0] * f[:8, 1] * f[:8, 2] * (c[:8] @ q - 2.0)
+        for n in range(8, 20):
+            z = int(np.flatnonzero(c[n] == 0.0)[0])
+            N[n] = 0.25 * (1.0 - q[z] ** 2) * f[n, (z + 1) % 3] * f[n, (z + 2) % 3]
+        return N
+
+    def _eval_shape_deriv_on_quad_pt(self, q):
+        c, q = self.nodecoords, np.asarray(q, dtype=float)
+        f = 1.0 + c * q[None, :]
+        s = c[:8] @ q
+        d = np.empty((20, 3))
+        for k in range(3):
+            o1, o2 = (k + 1) % 3, (k + 2) % 3
+            d[:8, k] = 0.125 * c[:8, k] * f[:8, o1] * f[:8, o2] * (s + q[k] * c[:8, k] - 1.0)
+        for n in range(8, 20):
+            z = int(np.flatnonzero(c[n] == 0.0)[0])
+            o1, o2 = (z + 1) % 3, (z + 2) % 3
+            e = 1.0 - q[z] ** 2
+            d[n, z] = -0.5 * q[z] * f[n, o1] * f[n, o2]
+            d[n, o1] = 0.25 * e * c[n, o1] * f[n, o2]
+            d[n, o2] = 0.25 * e * f[n, o1] * c[n, o2]
+        return d.ravel()
+
+
 class BasisTriangle2D(BasisBase):
     """ref: pyfem.py:341-377."""
 
@@ -157,14 +243,18 @@ class BasisTriangle2D(BasisBase):
 
 
 def _check_tables(quadrature, basis):
-    """The kernels hard-wire the two (quadrature, basis) pairs on the path; refuse anything else."""
-    ok = (isinstance(quadrature, QuadratureBilinear2D) and isinstance(basis, BasisBilinear2D)) or (
-        isinstance(quadrature, QuadratureTriangle2D) and isinstance(basis, BasisTriangle2D)) or (
-        isinstance(quadrature, QuadratureBlock3D) and isinstance(basis, BasisBlock3D))
-    if not ok:
-        raise NotImplementedError(
-            "accelerated path: only (QuadratureBilinear2D, BasisBilinear2D), (QuadratureTriangle2D, "
-            "BasisTriangle2D) and (QuadratureBlock3D, BasisBlock3D) are implemented as HIP kernels")
+    """Returns True for a (quadrature, basis) pair that runs on the table-driven 3-D kernels, False for one of the
+    three hard-wired pairs; anything else is refused."""
+    if (isinstance(quadrature, QuadratureBilinear2D) and isinstance(basis, BasisBilinear2D)) or (
+            isinstance(quadrature, QuadratureTriangle2D) and isinstance(basis, BasisTriangle2D)) or (
+            isinstance(quadrature, QuadratureBlock3D) and isinstance(basis, BasisBlock3D)):
+        return False
+    if basis.ndims == 3 and basis.nnodes_per_elem != 8 and 4 <= basis.nnodes_per_elem <= 32 and quadrature.get_nquads() <= 64:
+        return True  # tet10, brick20, or any other 3-D basis given by its tables (pf_*_tab3d)
+    raise NotImplementedError(
+        "accelerated path: (QuadratureBilinear2D, BasisBilinear2D), (QuadratureTriangle2D, BasisTriangle2D) and "
+        "(QuadratureBlock3D, BasisBlock3D) are hard-wired HIP kernels; other 3-D bases with 4..32 nodes and at most "
+        "64 quadrature points run on the table-driven kernels; nothing else is implemented")
 
 
 # ------------------------------------------------------------------------------------------
@@ -175,7 +265,10 @@ class ModelBase:
     and a HipContext with the device mesh + symbolic pattern."""
 
     def __init__(self, ndof_per_node, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=None):
-        _check_tables(quadrature, basis)
+        self.tabular = _check_tables(quadrature, basis)
+        if self.tabular and type(self).__name__ != "LinearElasticity":
+            raise NotImplementedError("accelerated path: the table-driven 3-D elements (tet10, brick20) are built for "
+                                      "LinearElasticity only")
         self.ndof_per_node = ndof_per_node
         self.X = np.array(X, dtype=float)
         self.conn = np.array(conn, dtype=int)
@@ -190,7 +283,8 @@ class ModelBase:
             raise ValueError("conn does not match the basis' nodes per element")
         self.nodes = np.arange(self.nnodes)
         # conn range is asserted on device by pf_mesh_set (ref: pyfem.py:680-681)
-        self.hctx = HipContext(self.X, self.conn, ndof_per_node, device=device)
+        tables = (basis.eval_shape_fun(), basis.eval_shape_fun_deriv(), quadrature.get_weight()) if self.tabular else None
+        self.hctx = HipContext(self.X, self.conn, ndof_per_node, device=device, tables=tables)
         self.ndof = self.nnodes * ndof_per_node
         self.dof = np.arange(self.ndof)
         self.dof_each_node = self.dof.reshape(self.nnodes, ndof_per_node) if ndof_per_node > 1 else self.nodes
@@ -621,9 +715,16 @@ class Assembler:
 
 
 # ------------------------------------------------------------------------------------------
+# corner offsets (x, y, z), in cells, of the six tetrahedra that fill a 2x2x2-cell patch (table of pyfem.py:2547-2556)
+_TET_CORNERS = np.array(
+    [[(0, 0, 0), (2, 0, 0), (2, 2, 0), (2, 2, 2)], [(0, 0, 0), (2, 0, 0), (2, 2, 2), (0, 0, 2)],
+     [(2, 0, 0), (2, 2, 2), (0, 0, 2), (2, 0, 2)], [(0, 0, 0), (0, 2, 0), (0, 2, 2), (2, 2, 0)],
+     [(0, 0, 0), (0, 2, 2), (0, 0, 2), (2, 2, 2)], [(0, 0, 0), (2, 2, 2), (2, 2, 0), (0, 2, 2)]])
+
+
 class ProblemCreator:
     """Vectorised equivalent of the reference's loop-based generator (pyfem.py:2426-2773) for the element
-    types on the path (quad, tri, block); produces identical conn / X / dof_fixed / nodal_force."""
+    reference's element types (quad, tri, block, tet, brick20); produces identical conn / X / dof_fixed / nodal_force."""
 
     def __init__(self, nnodes_x, nnodes_y, nnodes_z=None, Lx=None, Ly=None, Lz=None, element_type="quad"):
         if nnodes_z is None:
@@ -633,8 +734,6 @@ class ProblemCreator:
         else:
             self.ndims = 3
             assert element_type == "block" or element_type == "tet" or element_type == "brick20"
-            if element_type != "block":
-                raise NotImplementedError("accelerated path: of the 3-D elements only the 8-node block is built")
         Lx = (nnodes_x - 1) / (nnodes_y - 1) if Lx is None else Lx
         Ly = 1.0 if Ly is None else Ly
         Lz = (nnodes_z - 1) / (nnodes_y - 1) if Lz is None else Lz
@@ -654,9 +753,24 @@ class ProblemCreator:
             conn = np.empty((2 * n00.size, 3), dtype=int)
             conn[0::2] = np.stack([n00, n10, n11], axis=1)
             conn[1::2] = np.stack([n11, n01, n00], axis=1)
-        else:
+        elif element_type == "block":
             lo = np.stack([n00, n10, n11, n01], axis=1)
             conn = np.concatenate([lo, lo + nnodes_x * nnodes_y], axis=1)
+        else:  # one patch of 2x2x2 cells (27 grid nodes) per brick / per six tetrahedra; node counts must be odd
+            px, py, pz = (nnodes_x - 1) // 2, (nnodes_y - 1) // 2, (nnodes_z - 1) // 2
+            k, j, i = np.meshgrid(np.arange(pz), np.arange(py), np.arange(px), indexing="ij")
+            origin = 2 * np.stack([i.ravel(), j.ravel(), k.ravel()], axis=1)
+
+            def nid(c):
+                return c[..., 0] + c[..., 1] * nnodes_x + c[..., 2] * nnodes_x * nnodes_y
+
+            if element_type == "brick20":  # ref: pyfem.py:2657-2700 -- the basis' own node order, shifted to 0..2
+                conn = nid(origin[:, None, :] + (BasisBrick20Nodes._NODES.astype(int) + 1)[None])
+            else:  # "tet", ref: pyfem.py:2538-2655: six tetrahedra per patch, corners, then the edge midpoints
+                corners = origin[:, None, None, :] + _TET_CORNERS[None]
+                pairs = ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3))
+                mids = np.stack([(corners[:, :, a] + corners[:, :, b]) // 2 for a, b in pairs], axis=2)
+                conn = nid(np.concatenate([corners, mids], axis=2)).reshape(-1, 10)
         self.conn = conn.astype(int)
         self.nnodes_x, self.nnodes_y, self.nnodes_z = nnodes_x, nnodes_y, nnodes_z
         self.nnodes = nnodes_x * nnodes_y * nnodes_z
