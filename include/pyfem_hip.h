@@ -149,8 +149,8 @@ int pf_poisson_rhs3d(pf_ctx* ctx, const double* gq, double* rhs_out);
  *      BasisBrick20Nodes (pyfem.py:115-172, 380-632; tests/test_elements.py, examples/element_plot).
  *      Device arrays: N (Q,P) = basis.eval_shape_fun(), dN (Q,P,3) = basis.eval_shape_fun_deriv(), wq (Q) =
  *      quadrature.get_weight()  (pyfem.py:222-250, 57-65); P is that of pf_mesh_set3d, Q <= PF_TAB_MAX_QUADS.
- *      Same value layout as pf_assemble_elasticity3d (3x3 blocks in node-graph order); blocks are added with fp64
- *      atomics, so repeated calls agree to rounding, not bitwise.
+ *      Same value layout as pf_assemble_elasticity3d (3x3 blocks in node-graph order); the scatter runs colour by
+ *      colour over classes of elements that share no node (built on the first call), so results are bitwise reproducible.
  *      compute_jacobian (pyfem.py:1771-1795) / Ke_mat (E,3P,3P) / _compute_K_dv_sens (pyfem.py:1873-1920). ------- */
 int pf_assemble_elasticity_tab3d(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, double E,
                                  double nu, double p, const double* rho, double* Kvals);

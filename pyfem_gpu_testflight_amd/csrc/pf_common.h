@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "pyfem_hip.h"
 
@@ -45,6 +46,10 @@ struct pf_ctx {
   void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | visits<<8 | blocks<<16}
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
+
+  // table-driven elements (pf_tabular3d.hip): elements sorted by colour, no two of one colour share a node
+  int32_t* tab_order = nullptr;          // (nelems) element ids, colour by colour
+  std::vector<int64_t> tab_color_ptr;    // (ncolours+1) offsets into tab_order (host)
 
   pf_amg* amg = nullptr;       // AMG hierarchy (graph part built once per pattern, pf_amg.hip)
 

@@ -310,6 +310,8 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->e2pos);
   pf_free(ctx->vis_rec);
   pf_free(ctx->tile_desc);
+  pf_free(ctx->tab_order);
+  ctx->tab_color_ptr.clear();
   ctx->ntiles = 0;
   ctx->npt = 0;
   ctx->d = 0;
