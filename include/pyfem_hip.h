@@ -47,7 +47,7 @@ enum {
 };
 
 enum { PF_QUAD4 = 4, PF_TRI3 = 3, PF_BLOCK8 = 8 };  /* nodes per element selects the element */
-enum { PF_TAB_MAX_NODES = 32, PF_TAB_MAX_QUADS = 64 };  /* limits of the table-driven 3-D element */
+enum { PF_TAB_MAX_NODES = 32, PF_TAB_MAX_QUADS = 64 };  /* limits of the table-driven element */
 enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
 enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECOND_AMG_REUSE = 3 };
 
@@ -66,7 +66,7 @@ int pf_mesh_set(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, in
                 const int32_t* conn, int on_device);
 /* 3-D: X (nnodes, 3), conn (nelems, 8) in BasisBlock3D node order (pyfem.py:287-338; ProblemCreator
  * element_type="block", pyfem.py:2531-2548).  pf_pattern_build then takes ndof_per_node 1 or 3.
- * Any other P from 4 to PF_TAB_MAX_NODES selects the table-driven element (pf_*_tab3d below): the 10-node
+ * Any other P from 4 to PF_TAB_MAX_NODES selects the table-driven element (pf_*_tab below): the 10-node
  * tetrahedron and the 20-node brick of pyfem.py:380-632 / ProblemCreator "tet", "brick20" (pyfem.py:2538-2700);
  * the pattern then holds the node rows only (up to 160 neighbours per node). */
 int pf_mesh_set3d(pf_ctx* ctx, int64_t nnodes, const double* X, int64_t nelems, int P /* PF_BLOCK8 or 4..32 */,
@@ -144,20 +144,26 @@ int pf_sens3d(pf_ctx* ctx, int scalar, double E, double nu, double p, const doub
 int pf_quad_points3d(pf_ctx* ctx, double* Xq_out);
 int pf_poisson_rhs3d(pf_ctx* ctx, const double* gq, double* rhs_out);
 
-/* ---- 3-D elasticity with the element given as DATA: any (Quadrature, Basis) pair of the reference other than the
- *      hard-wired ones, i.e. QuadratureTetrahedron5Point + BasisTetrahedron10node and QuadratureBrick333Point +
- *      BasisBrick20Nodes (pyfem.py:115-172, 380-632; tests/test_elements.py, examples/element_plot).
- *      Device arrays: N (Q,P) = basis.eval_shape_fun(), dN (Q,P,3) = basis.eval_shape_fun_deriv(), wq (Q) =
- *      quadrature.get_weight()  (pyfem.py:222-250, 57-65); P is that of pf_mesh_set3d, Q <= PF_TAB_MAX_QUADS.
- *      Same value layout as pf_assemble_elasticity3d (3x3 blocks in node-graph order); the scatter runs colour by
- *      colour over classes of elements that share no node (built on the first call), so results are bitwise reproducible.
- *      compute_jacobian (pyfem.py:1771-1795) / Ke_mat (E,3P,3P) / _compute_K_dv_sens (pyfem.py:1873-1920). ------- */
-int pf_assemble_elasticity_tab3d(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, double E,
-                                 double nu, double p, const double* rho, double* Kvals);
-int pf_element_matrices_tab3d(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, double E,
-                              double nu, double p, const double* rho, double* Ke_out);
-int pf_sens_tab3d(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, double E, double nu,
-                  double p, const double* rho, const double* phi, const double* psi, double* out);
+/* ---- the element given as DATA: N (Q,P) = basis.eval_shape_fun(), dN (Q,P,ndims) = basis.eval_shape_fun_deriv(),
+ *      wq (Q) = quadrature.get_weight() (pyfem.py:222-250, 57-65), device arrays; P is that of pf_mesh_set[3d],
+ *      Q <= PF_TAB_MAX_QUADS.  kind: PF_TAB_ELASTICITY (pattern with ndims dofs per node; plane stress in 2-D) or
+ *      PF_TAB_POISSON (1 dof per node).  Serves
+ *        - any (Quadrature, Basis) pair other than the hard-wired ones: QuadratureTetrahedron5Point +
+ *          BasisTetrahedron10node, QuadratureBrick333Point + BasisBrick20Nodes (pyfem.py:115-172, 380-632;
+ *          tests/test_elements.py, examples/element_plot);
+ *        - drho != NULL: the coefficient RAMP'(rho_q) (N drho)_q instead of RAMP(rho_q), i.e. Im K(rho + i drho) per
+ *          unit step -- what the reference's complex-step derivative tests read (tests/test_elasticity.py:96-98);
+ *        - an independent second implementation of the hard-wired kernels for the parity tests.
+ *      Same value layout as the hard-wired assemblies (d x d blocks in node-graph order); the scatter runs colour by
+ *      colour over classes of elements that share no node (built on the first call): bitwise reproducible.
+ *      compute_jacobian (pyfem.py:1771-1795, 1006-1030) / Ke_mat / _compute_K_dv_sens (pyfem.py:1873-1920, 1240-1276). */
+enum { PF_TAB_ELASTICITY = 0, PF_TAB_POISSON = 1 };
+int pf_assemble_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int kind, double E,
+                    double nu, double p, const double* rho, const double* drho, double* Kvals);
+int pf_element_matrices_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int kind, double E,
+                            double nu, double p, const double* rho, const double* drho, double* Ke_out);
+int pf_sens_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int kind, double E, double nu,
+                double p, const double* rho, const double* phi, const double* psi, double* out);
 
 /* block layout -> scipy CSR data order (identity copy for d == 1) */
 int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr_data);

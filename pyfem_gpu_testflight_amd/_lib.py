@@ -16,6 +16,7 @@ PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
 PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE = 0, 1, 2, 3
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
+PF_TAB_ELASTICITY, PF_TAB_POISSON = 0, 1
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 
@@ -41,9 +42,9 @@ SIGNATURES = {
     "pf_assemble_helmholtz3d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_element_matrices3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _f64, _vp, _vp, _vp]),
     "pf_sens3d": (C.c_int, [_vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
-    "pf_assemble_elasticity_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp]),
-    "pf_element_matrices_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp]),
-    "pf_sens_tab3d": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "pf_assemble_tab": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp]),
+    "pf_element_matrices_tab": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp]),
+    "pf_sens_tab": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
     "pf_quad_points3d": (C.c_int, [_vp, _vp]),
     "pf_poisson_rhs3d": (C.c_int, [_vp, _vp, _vp]),
     "pf_element_matrices_poisson2d": (C.c_int, [_vp, _f64, _vp, _vp]),

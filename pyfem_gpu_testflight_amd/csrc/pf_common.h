@@ -47,7 +47,7 @@ struct pf_ctx {
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 
-  // table-driven elements (pf_tabular3d.hip): elements sorted by colour, no two of one colour share a node
+  // table-driven elements (pf_tabular.hip): elements sorted by colour, no two of one colour share a node
   int32_t* tab_order = nullptr;          // (nelems) element ids, colour by colour
   std::vector<int64_t> tab_color_ptr;    // (ncolours+1) offsets into tab_order (host)
 

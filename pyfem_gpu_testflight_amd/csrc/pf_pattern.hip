@@ -132,7 +132,7 @@ __global__ void k_row_fill(int64_t nnodes, const int32_t* __restrict__ conn, con
 }
 
 // Rows for elements outside the three hard-wired shapes (10-node tetrahedra, 20-node bricks, ...: the table-driven
-// path of pf_tabular3d.hip): runtime P, up to MAXNB_TAB neighbours (a corner shared by eight 20-node bricks has 81),
+// path of pf_tabular.hip): runtime P, up to MAXNB_TAB neighbours (a corner shared by eight 20-node bricks has 81),
 // no byte-position tables -- that path finds positions by bisection.
 static constexpr int MAXNB_TAB = 160;
 
@@ -383,7 +383,7 @@ extern "C" int pf_mesh_set3d(pf_ctx* ctx, int64_t nnodes, const double* X, int64
                              int on_device) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(P >= 4 && P <= PF_TAB_MAX_NODES, "pf_mesh_set3d: 4 to 32 nodes per element (8: the hard-wired block kernels, "
-                                               "anything else: the table-driven element of pf_*_tab3d)");
+                                               "anything else: the table-driven element of pf_*_tab)");
   return mesh_set(ctx, 3, nnodes, X, nelems, P, conn, on_device);
 }
 

@@ -27,7 +27,10 @@ def _ptr(t):
 class HipContext:
     """Owns a pf_ctx: device mesh copy + symbolic pattern.  ref: ModelBase.__init__ (pyfem.py:640-757)."""
 
-    def __init__(self, X, conn, ndof_per_node, device=None, tables=None):
+    def __init__(self, X, conn, ndof_per_node, device=None, tables=None, tabular=False):
+        """tables = (N (Q,P), dN (Q,P,ndims), wq (Q)) of the basis: always used by the table-driven entry points
+        (complex-step imaginary parts, cross-checks); tabular=True makes them THE assembly path (elements other than
+        the hard-wired 3-node triangle, 4-node quad, 8-node block: 10-node tetrahedra, 20-node bricks, ...)."""
         torch = _torch()
         self.torch = torch
         self.lib = _lib.load()
@@ -39,10 +42,9 @@ class HipContext:
         if X.ndim != 2 or X.shape[1] not in (2, 3):
             raise ValueError("X must have shape (nnodes, 2) or (nnodes, 3)")
         self.ndims = X.shape[1]
-        # tables = (N (Q,P), dN (Q,P,3), wq (Q)): a 3-D element given as data (10-node tetrahedra, 20-node bricks, ...)
-        self.tabular = tables is not None
+        self.tabular = bool(tabular)
         if self.tabular:
-            ok = conn.ndim == 2 and self.ndims == 3 and conn.shape[1] != 8 and 4 <= conn.shape[1] <= 32
+            ok = tables is not None and conn.ndim == 2 and self.ndims == 3 and conn.shape[1] != 8 and 4 <= conn.shape[1] <= 32
         else:
             ok = conn.ndim == 2 and conn.shape[1] in ((3, 4) if self.ndims == 2 else (8,))
         if not ok:
@@ -60,18 +62,42 @@ class HipContext:
         self._call("pf_pattern_dims", C.byref(nrows), C.byref(nnz), C.byref(nblocks), C.byref(maxrow))
         self.nrows, self.nnz, self.nblocks, self.max_row_blocks = nrows.value, nnz.value, nblocks.value, maxrow.value
         self._csr_structure = None
-        if self.tabular:
-            if self.d != 3:
-                raise ValueError("table-driven elements are built for 3 dofs per node (elasticity)")
+        self._tab = None
+        if tables is not None:
             N, dN, wq = (np.ascontiguousarray(t, dtype=np.float64) for t in tables)
             Q = wq.shape[0]
-            if N.shape != (Q, self.P) or dN.shape != (Q, self.P, 3) or Q > 64:
-                raise ValueError("basis tables must be N (Q,P), dN (Q,P,3), weights (Q), Q <= 64")
+            if N.shape != (Q, self.P) or dN.shape != (Q, self.P, self.ndims) or Q > 64:
+                raise ValueError("basis tables must be N (Q,P), dN (Q,P,ndims), weights (Q), Q <= 64")
             self.Q = Q
             self._tab = tuple(self.to_device(t, torch.float64) for t in (N, dN, wq))
+        if self.tabular and self.d != 3:
+            raise ValueError("table-driven elements are built for 3 dofs per node (elasticity)")
 
     def _tab_args(self):
+        if self._tab is None:
+            raise ValueError("this context was built without the basis tables")
         return (self.Q,) + tuple(_ptr(t) for t in self._tab)
+
+    # -- table-driven kernels (pf_tabular.hip): any element given by its tables; drho selects the coefficient
+    #    RAMP'(rho_q) (N drho)_q, i.e. the imaginary part of K(rho + i drho) per unit step --------------------------
+    def assemble_tab(self, kind, E, nu, p, rho=None, drho=None, out=None):
+        vals = self.empty(self.nnz) if out is None else out
+        self._sync_stream()
+        self._call("pf_assemble_tab", *self._tab_args(), kind, E, nu, p, _ptr(rho), _ptr(drho), _ptr(vals))
+        return vals
+
+    def element_matrices_tab(self, kind, E, nu, p, rho=None, drho=None):
+        D = self.P * self.d
+        out = self.empty(self.nelems * D * D)
+        self._sync_stream()
+        self._call("pf_element_matrices_tab", *self._tab_args(), kind, E, nu, p, _ptr(rho), _ptr(drho), _ptr(out))
+        return out.view(self.nelems, D, D)
+
+    def sens_tab(self, kind, E, nu, p, rho, phi, psi):
+        out = self.empty(self.nnodes)
+        self._sync_stream()
+        self._call("pf_sens_tab", *self._tab_args(), kind, E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+        return out
 
     # -- plumbing -------------------------------------------------------------------------
     def _sync_stream(self):
@@ -130,7 +156,7 @@ class HipContext:
         vals = self.empty(self.nnz) if out is None else out
         self._sync_stream()
         if self.tabular:
-            self._call("pf_assemble_elasticity_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(vals))
+            self._call("pf_assemble_tab", *self._tab_args(), _lib.PF_TAB_ELASTICITY, E, nu, p, _ptr(rho), None, _ptr(vals))
         elif self.ndims == 3:
             self._call("pf_assemble_elasticity3d", E, nu, p, _ptr(rho), _ptr(vals))
         else:
@@ -147,7 +173,8 @@ class HipContext:
         out = self.empty(self.nnodes)
         self._sync_stream()
         if self.tabular:
-            self._call("pf_sens_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
+            self._call("pf_sens_tab", *self._tab_args(), _lib.PF_TAB_ELASTICITY, E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi),
+                       _ptr(out))
         elif self.ndims == 3:
             self._call("pf_sens3d", 0, E, nu, p, _ptr(rho), _ptr(phi), _ptr(psi), _ptr(out))
         else:
@@ -196,7 +223,8 @@ class HipContext:
         out = self.empty(self.nelems * D * D)
         self._sync_stream()
         if self.tabular:
-            self._call("pf_element_matrices_tab3d", *self._tab_args(), E, nu, p, _ptr(rho), _ptr(out))
+            self._call("pf_element_matrices_tab", *self._tab_args(), _lib.PF_TAB_ELASTICITY, E, nu, p, _ptr(rho), None,
+                       _ptr(out))
         elif self.ndims == 3:
             self._call("pf_element_matrices3d", 0, E, nu, p, 0.0, _ptr(rho), _ptr(out), None)
         else:

@@ -14,10 +14,11 @@ CG) runs in hand-written HIP kernels through the C ABI (include/pyfem_hip.h); th
 holds the host logic the reference has around those calls.  There is no numpy fallback: without
 the library or a GPU the constructors raise.
 
-Scope: 2-D 4-node quads and 3-node triangles; LinearElasticity (plane
-stress, RAMP density, sensitivities), LinearPoisson, Helmholtz filter, Assembler.solve.  3-D elements,
-NonlinearPoisson2D, A2DWrapper and complex-step dtypes are outside the accelerated path and raise
-NotImplementedError here.
+Scope: 4-node quads, 3-node triangles and 8-node blocks as hard-wired kernels
+(LinearElasticity with RAMP density and sensitivities, LinearPoisson, Helmholtz filter, Assembler.solve);
+10-node tetrahedra, 20-node bricks and any other 3-D basis through the table-driven kernels (LinearElasticity);
+complex-step densities (the reference's derivative tests) as a real/imaginary pair of device matrices.
+NonlinearPoisson2D, A2DWrapper and solve_nonlinear raise NotImplementedError here.
 """
 import numpy as np
 
@@ -42,7 +43,10 @@ def _vdot(a, b):
     """rhs . u of the compliance functionals (pyfem.py:1068, 1832) without BLAS: a multi-threaded ddot wakes one
     thread per logical CPU, and on a CPU-quota'd GPU box those spinning threads get the whole process throttled for
     tens of milliseconds -- longer than the solve the number belongs to."""
-    return float(np.add.reduce(np.multiply(a, b)))
+    s = np.add.reduce(np.multiply(a, b))
+    return complex(s) if np.iscomplexobj(s) else float(s)
+
+
 _PRECOND = {"none": _lib.PF_PRECOND_NONE, "jacobi": _lib.PF_PRECOND_JACOBI, "amg": _lib.PF_PRECOND_AMG}
 
 
@@ -250,11 +254,62 @@ def _check_tables(quadrature, basis):
             isinstance(quadrature, QuadratureBlock3D) and isinstance(basis, BasisBlock3D)):
         return False
     if basis.ndims == 3 and basis.nnodes_per_elem != 8 and 4 <= basis.nnodes_per_elem <= 32 and quadrature.get_nquads() <= 64:
-        return True  # tet10, brick20, or any other 3-D basis given by its tables (pf_*_tab3d)
+        return True  # tet10, brick20, or any other 3-D basis given by its tables (pf_*_tab)
     raise NotImplementedError(
         "accelerated path: (QuadratureBilinear2D, BasisBilinear2D), (QuadratureTriangle2D, BasisTriangle2D) and "
         "(QuadratureBlock3D, BasisBlock3D) are hard-wired HIP kernels; other 3-D bases with 4..32 nodes and at most "
         "64 quadrature points run on the table-driven kernels; nothing else is implemented")
+
+
+# ------------------------------------------------------------------------------------------
+# complex-step densities
+# ------------------------------------------------------------------------------------------
+def _split_complex(rho):
+    """(real part, imaginary part or None) of a nodal density given as numpy array or torch tensor."""
+    if hasattr(rho, "is_complex"):  # torch
+        return (rho.real, rho.imag) if rho.is_complex() else (rho, None)
+    if np.iscomplexobj(rho):
+        rho = np.asarray(rho)
+        return rho.real.copy(), rho.imag.copy()
+    return rho, None
+
+
+class ComplexStepCSR:
+    """K(rho + i drho) to first order in drho: `real` = K(rho), `imag` = dK/drho [drho], both device matrices.
+
+    The reference differentiates its assembly by a complex step of 1e-30 (tests/test_elasticity.py:96-98, 127-128;
+    test_linear_poisson.py:82-83, 112-113; test_elements.py:50-51): `compute_jacobian(rho + 1j * p * h)` returns a complex
+    scipy matrix whose imaginary part is exact to first order -- second-order terms (1e-60) are below anything fp64
+    keeps next to the real part.  The kernels are fp64-real, so the two parts are assembled separately: the real part
+    by the usual kernel, the imaginary part by the table-driven kernel with the coefficient RAMP'(rho_q) (N drho)_q
+    (pf_assemble_tab).  Products, Dirichlet conditions and solves act on the pair the way complex arithmetic would."""
+
+    def __init__(self, real, imag):
+        self.real, self.imag = real, imag
+        self.hctx = real.hctx
+        self.shape = real.shape
+        self.dtype = np.dtype(np.complex128)
+
+    def dot(self, v):
+        v = np.asarray(v)
+        if np.iscomplexobj(v):
+            vr, vi = np.ascontiguousarray(v.real), np.ascontiguousarray(v.imag)
+            return (self.real.dot(vr) - self.imag.dot(vi)) + 1j * (self.real.dot(vi) + self.imag.dot(vr))
+        return self.real.dot(v) + 1j * self.imag.dot(v)
+
+    __matmul__ = dot
+
+    def to_scipy(self):
+        from scipy import sparse
+
+        indptr, indices = self.hctx.csr_structure()
+        data = self.hctx.vals_to_csr(self.real.vals).cpu().numpy() + 1j * self.hctx.vals_to_csr(self.imag.vals).cpu().numpy()
+        K = sparse.csr_matrix((data, indices.copy(), indptr.copy()), shape=self.shape)
+        if self.real._eliminate:
+            K.eliminate_zeros()
+        return K
+
+    tocsr = to_scipy
 
 
 # ------------------------------------------------------------------------------------------
@@ -283,8 +338,8 @@ class ModelBase:
             raise ValueError("conn does not match the basis' nodes per element")
         self.nodes = np.arange(self.nnodes)
         # conn range is asserted on device by pf_mesh_set (ref: pyfem.py:680-681)
-        tables = (basis.eval_shape_fun(), basis.eval_shape_fun_deriv(), quadrature.get_weight()) if self.tabular else None
-        self.hctx = HipContext(self.X, self.conn, ndof_per_node, device=device, tables=tables)
+        tables = (basis.eval_shape_fun(), basis.eval_shape_fun_deriv(), quadrature.get_weight())
+        self.hctx = HipContext(self.X, self.conn, ndof_per_node, device=device, tables=tables, tabular=self.tabular)
         self.ndof = self.nnodes * ndof_per_node
         self.dof = np.arange(self.ndof)
         self.dof_each_node = self.dof.reshape(self.nnodes, ndof_per_node) if ndof_per_node > 1 else self.nodes
@@ -316,6 +371,8 @@ class ModelBase:
     def apply_dirichlet_bcs(self, K, rhs, enforce_symmetric_K=True):
         """ref: pyfem.py:781-835.  K: DeviceCSR from compute_jacobian (modified in place, like the
         reference mutates its argument); rhs: numpy array (modified in place) or device tensor."""
+        if isinstance(K, ComplexStepCSR):
+            return self._apply_dirichlet_bcs_complex(K, rhs, enforce_symmetric_K)
         if not isinstance(K, DeviceCSR) or K.hctx is None:
             raise TypeError("apply_dirichlet_bcs expects the device-backed matrix returned by compute_jacobian()")
         torch = self.hctx.torch
@@ -328,6 +385,24 @@ class ModelBase:
             return K, rhs_d
         rhs[:] = rhs_d.cpu().numpy()
         return K, rhs
+
+    def _apply_dirichlet_bcs_complex(self, K, rhs, enforce_symmetric_K):
+        """The complex matrix after pyfem.py:781-835: unit (real) diagonal on the fixed dofs, so the imaginary part gets
+        zero rows, columns and diagonal there; rhs[free] -= K[free, fixed] vals picks up an imaginary part when values
+        are prescribed."""
+        torch = self.hctx.torch
+        rhs_r = self.hctx.to_device(np.asarray(rhs, dtype=float), torch.float64)
+        rhs_i = self.hctx.zeros(self.ndof)
+        self.hctx.apply_dirichlet(K.real.vals, rhs_r, self._fixed_mask, self._fixed_vals, enforce_symmetric_K)
+        self.hctx.apply_dirichlet(K.imag.vals, rhs_i, self._fixed_mask, self._fixed_vals, enforce_symmetric_K,
+                                  diag_scale=self.hctx.zeros(self.ndof))
+        rhs_i[self._fixed_mask.bool()] = 0.0
+        for part in (K.real, K.imag):
+            part.invalidate()
+            part._eliminate = True
+        rhs[:] = rhs_r.cpu().numpy()
+        ri = rhs_i.cpu().numpy()
+        return K, (rhs + 1j * ri if np.any(ri) else rhs)
 
 
 class LinearPoisson(ModelBase):
@@ -347,17 +422,12 @@ class LinearPoisson(ModelBase):
     def _rho_device(self, rho):
         torch = self.hctx.torch
         if isinstance(rho, torch.Tensor):
-            if rho.is_complex():
-                raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
             return rho.to(device=self.hctx.device, dtype=torch.float64).contiguous()
         if not hasattr(rho, "__len__"):
             if rho == 1.0:
                 return None
             rho = np.ones(self.nnodes) * rho
-        rho = np.asarray(rho)
-        if np.iscomplexobj(rho):
-            raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
-        return self.hctx.to_device(rho.astype(float), torch.float64)
+        return self.hctx.to_device(np.asarray(rho).astype(float), torch.float64)
 
     @time_this
     def compute_rhs(self):
@@ -374,9 +444,15 @@ class LinearPoisson(ModelBase):
 
     @time_this
     def compute_jacobian(self, rho=1.0, out=None):
-        """ref: pyfem.py:1006-1030."""
+        """ref: pyfem.py:1006-1030.  A complex density (complex step) returns a ComplexStepCSR."""
+        rho, drho = _split_complex(rho)
         rho_d = self._rho_device(rho)
         self._last_rho = rho_d
+        if drho is not None:
+            if rho_d is None:
+                rho_d = self.hctx.to_device(np.ones(self.nnodes), self.hctx.torch.float64)
+            Ki = self.hctx.assemble_tab(_lib.PF_TAB_POISSON, 0.0, 0.0, self.p, rho_d, self._rho_device(drho))
+            return ComplexStepCSR(DeviceCSR(self.hctx, self.hctx.assemble_poisson(self.p, rho_d)), DeviceCSR(self.hctx, Ki))
         vals = self.hctx.assemble_poisson(self.p, rho_d, out=None if out is None else out.vals)
         if out is not None:
             out.invalidate()
@@ -477,25 +553,29 @@ class LinearElasticity(ModelBase):
     def _rho_device(self, rho):
         torch = self.hctx.torch
         if isinstance(rho, torch.Tensor):
-            if rho.is_complex():
-                raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
             return rho.to(device=self.hctx.device, dtype=torch.float64).contiguous()
         if not hasattr(rho, "__len__"):
             if rho == 1.0:
                 return None  # rho == 1 => Cq == 1 for every p (pyfem.py:1780-1781, 1944)
             rho = np.ones(self.nnodes) * rho
         rho = np.asarray(rho)
-        if np.iscomplexobj(rho):
-            raise NotImplementedError("accelerated path is fp64-real: complex-step densities are not supported")
         if rho.shape != (self.nnodes,):
             raise ValueError("rho must be nodal: shape (nnodes,)")
         return self.hctx.to_device(rho.astype(float), torch.float64)
 
     @time_this
     def compute_jacobian(self, rho=1.0, out=None):
-        """ref: pyfem.py:1771-1795.  Returns a DeviceCSR; Ke never exists in memory."""
+        """ref: pyfem.py:1771-1795.  Returns a DeviceCSR; Ke never exists in memory.  A complex density (the complex
+        step of the reference's derivative tests, pyfem.py:1786-1788) returns a ComplexStepCSR."""
+        rho, drho = _split_complex(rho)
         rho_d = self._rho_device(rho)
         self._last_rho = rho_d
+        if drho is not None:
+            if rho_d is None:
+                rho_d = self.hctx.to_device(np.ones(self.nnodes), self.hctx.torch.float64)
+            Kr = self.hctx.assemble_elasticity(self.E, self.nu, self.p, rho_d, self.scatter_mode)
+            Ki = self.hctx.assemble_tab(_lib.PF_TAB_ELASTICITY, self.E, self.nu, self.p, rho_d, self._rho_device(drho))
+            return ComplexStepCSR(DeviceCSR(self.hctx, Kr), DeviceCSR(self.hctx, Ki))
         vals = self.hctx.assemble_elasticity(self.E, self.nu, self.p, rho_d, self.scatter_mode,
                                              out=None if out is None else out.vals)
         if out is not None:
@@ -684,6 +764,13 @@ class Assembler:
                   raises if it does not get there.  Host code that wants the factorisation itself can still hand the
                   returned matrix to scipy (`spsolve(K, rhs)`: DeviceCSR is a csr_matrix)."""
         rtol = DIRECT_RTOL if method == "direct" else self.rtol
+        if isinstance(K, ComplexStepCSR):  # (Kr + i Ki)(ur + i ui) = br + i bi, to first order in the imaginary parts
+            rhs = np.asarray(rhs)
+            ur = self._solve_linear_system(K.real, np.ascontiguousarray(rhs.real, dtype=float), method)
+            bi = -K.imag.dot(ur)
+            if np.iscomplexobj(rhs):
+                bi = bi + rhs.imag
+            return ur + 1j * self._solve_linear_system(K.real, bi, method)
         hctx = K.hctx
         torch = hctx.torch
         on_device = isinstance(rhs, torch.Tensor)

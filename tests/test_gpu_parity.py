@@ -260,8 +260,10 @@ def test_error_behaviour(pf):
     model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
     with pytest.raises(AssertionError):
         pf.Assembler(model).solve(method="lu")  # pyfem.py:2306
+    Kc = model.compute_jacobian(np.ones(X.shape[0]) + 1j * 1e-30)  # complex step: a real/imaginary pair, not an error
+    assert np.iscomplexobj(Kc.dot(np.ones(2 * X.shape[0])))
     with pytest.raises(NotImplementedError):
-        model.compute_jacobian(np.ones(X.shape[0]) + 1j * 1e-30)
+        pf.Assembler(model).solve_nonlinear()
     # singular system (no BCs) with a tiny iteration cap -> RuntimeError like pyfem.py:2421-2422
     free = pf.LinearElasticity(X, conn, [], None, force, q, b)
     K = free.compute_jacobian()
@@ -1075,3 +1077,100 @@ def test_quadratic_elements_solve_like_the_element_plot_examples(pf, orc, etype,
     monkeypatch.chdir(tmp_path)
     utils.to_vtk(conn, X, {"ux": u[0::3], "uy": u[1::3], "uz": u[2::3]})
     assert (tmp_path / "problem.vtk").stat().st_size > 0
+
+
+# ---- complex-step densities and the table-driven kernels as a second implementation --------------------------------
+def _ref_test_creators(pf):
+    """The meshes of the reference's derivative tests (tests/test_elasticity.py:57-66, test_linear_poisson.py:44-53,
+    test_elements.py:11-19)."""
+    return {"quad": (pf.ProblemCreator(nnodes_x=64, nnodes_y=64, element_type="quad"), lambda: _qb(pf, "quad")),
+            "tri": (pf.ProblemCreator(nnodes_x=64, nnodes_y=64, element_type="tri"), lambda: _qb(pf, "tri")),
+            "block": (pf.ProblemCreator(nnodes_x=8, nnodes_y=8, nnodes_z=8, element_type="block"), lambda: _qb(pf, "block")),
+            "tet": (pf.ProblemCreator(nnodes_x=9, nnodes_y=9, nnodes_z=9, element_type="tet"), lambda: _qb_ho(pf, "tet")),
+            "brick20": (pf.ProblemCreator(nnodes_x=9, nnodes_y=9, nnodes_z=9, element_type="brick20"),
+                        lambda: _qb_ho(pf, "brick20"))}
+
+
+@pytest.mark.parametrize("etype", ["quad", "tri", "block", "tet", "brick20"])
+def test_reference_complex_step_tests_elasticity(pf, etype):
+    """tests/test_elasticity.py:68-132 and tests/test_elements.py:21-56 with their own numbers: the derivative of
+    phi^T K psi and of the compliance by a complex step of 1e-30 through compute_jacobian / compliance."""
+    creator, qb = _ref_test_creators(pf)[etype]
+    conn, X, dof_fixed, nodal_force = creator.create_linear_elasticity_problem()
+    q, b = qb()
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, nodal_force, q, b, p=5.0)
+    np.random.seed(0)
+    nnodes, ndof = X.shape[0], X.shape[0] * X.shape[1]
+    phi, psi = np.random.rand(ndof), np.random.rand(ndof)
+    rho, p = np.random.rand(nnodes), np.random.rand(nnodes)
+    h = 1e-30
+    dfdrho = p.dot(model._compute_K_dv_sens(rho, phi, psi))
+    K = model.compute_jacobian(rho + 1j * p * h)
+    dfdrho_cs = phi.dot(K.dot(psi)).imag / h
+    assert abs((dfdrho - dfdrho_cs) / dfdrho) < 1e-12
+    if etype in ("tet", "brick20"):  # the reference stops here for these (and the brick grid has unused nodes)
+        return
+    np.random.seed(0)
+    rho, p = np.random.rand(nnodes), np.random.rand(nnodes)
+    c, u = model.compliance(rho, solver="cg")
+    grad = p.dot(model.compliance_grad(rho, u))
+    c_cs, _ = model.compliance(rho + 1j * p * h, solver="direct")
+    assert abs((grad - c_cs.imag / h) / grad) < 1e-10
+
+
+@pytest.mark.parametrize("etype", ["quad", "tri", "block"])
+def test_reference_complex_step_tests_poisson(pf, etype):
+    """tests/test_linear_poisson.py:55-117."""
+    creator, qb = _ref_test_creators(pf)[etype]
+    conn, X, dof_fixed = creator.create_poisson_problem()
+    q, b = qb()
+    model = pf.LinearPoisson(X, conn, dof_fixed, None, q, b, _gfunc, p=5.0)
+    np.random.seed(0)
+    nnodes = X.shape[0]
+    phi, psi = np.random.rand(nnodes), np.random.rand(nnodes)
+    rho, p = np.random.rand(nnodes), np.random.rand(nnodes)
+    h = 1e-30
+    dfdrho = p.dot(model._compute_K_dv_sens(rho, phi, psi))
+    K = model.compute_jacobian(rho + 1j * p * h)
+    assert abs((dfdrho - phi.dot(K.dot(psi)).imag / h) / dfdrho) < 1e-12
+    np.random.seed(0)
+    rho, p = np.random.rand(nnodes), np.random.rand(nnodes)
+    c, u = model.compliance(rho, solver="cg")
+    grad = p.dot(model.compliance_grad(rho, u))
+    c_cs, _ = model.compliance(rho + 1j * p * h, solver="direct")
+    assert abs((grad - c_cs.imag / h) / grad) < 1e-10
+
+
+@pytest.mark.parametrize("etype", ["quad", "tri", "block"])
+def test_table_driven_kernels_agree_with_the_hard_wired_ones(pf, etype):
+    """Two independent implementations of the same element: the hand-derived kernels of the hot path and the
+    table-driven one fed with the basis tables -- K, element matrices and sensitivities, elasticity and Poisson."""
+    import torch
+
+    from pyfem_gpu_testflight_amd import _lib
+
+    creator = {"quad": pf.ProblemCreator(23, 17), "tri": pf.ProblemCreator(19, 14, element_type="tri"),
+               "block": pf.ProblemCreator(7, 6, 5, element_type="block")}[etype]
+    conn, X, dof_fixed, nodal_force = creator.create_linear_elasticity_problem()
+    rng = np.random.RandomState(3)
+    X = X + 0.2 / 23 * (rng.rand(*X.shape) - 0.5)
+    q, b = _qb(pf, etype)
+    m = pf.LinearElasticity(X, conn, dof_fixed, None, nodal_force, q, b, p=4.0)
+    h = m.hctx
+    rho = h.to_device(0.1 + 0.9 * rng.rand(X.shape[0]), torch.float64)
+    phi, psi = (h.to_device(rng.rand(X.size), torch.float64) for _ in range(2))
+    K_hw = h.assemble_elasticity(m.E, m.nu, m.p, rho)
+    K_tab = h.assemble_tab(_lib.PF_TAB_ELASTICITY, m.E, m.nu, m.p, rho)
+    assert float((K_hw - K_tab).abs().max()) <= 1e-13 * float(K_hw.abs().max())
+    Ke_hw = h.element_matrices_elasticity(m.E, m.nu, m.p, rho)
+    Ke_tab = h.element_matrices_tab(_lib.PF_TAB_ELASTICITY, m.E, m.nu, m.p, rho)
+    assert float((Ke_hw - Ke_tab).abs().max()) <= 1e-13 * float(Ke_hw.abs().max())
+    s_hw = h.sens_elasticity(m.E, m.nu, m.p, rho, phi, psi)
+    s_tab = h.sens_tab(_lib.PF_TAB_ELASTICITY, m.E, m.nu, m.p, rho, phi, psi)
+    assert float((s_hw - s_tab).abs().max()) <= 1e-12 * float(s_hw.abs().max())
+    mp = pf.LinearPoisson(X, conn, [0, 1], None, q, b, _gfunc, p=4.0)
+    hp = mp.hctx
+    rho = hp.to_device(rho.cpu().numpy(), torch.float64)
+    Kp_hw = hp.assemble_poisson(mp.p, rho)
+    Kp_tab = hp.assemble_tab(_lib.PF_TAB_POISSON, 0.0, 0.0, mp.p, rho)
+    assert float((Kp_hw - Kp_tab).abs().max()) <= 1e-13 * float(Kp_hw.abs().max())
