@@ -218,8 +218,38 @@ def main_highorder(pyfem):
         print(f"{name}: nelems={conn.shape[0]} nnz={K.nnz} |K|={np.linalg.norm(K.data):.13e}")
 
 
+def main_nonlinear(pyfem):
+    """NonlinearPoisson2D (pyfem.py:1332-1665) and Assembler.solve_nonlinear (pyfem.py:2319-2355) on the reference's own
+    test case (tests/test_nonlinear_poisson.py: 32x32 quads, xdv = ones(10)/10): tangent and residual at a random state
+    on a distorted mesh, and the Newton solution with the direct solver."""
+    c = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)
+    conn, X, dof_fixed = c.create_poisson_problem()
+    q = pyfem.QuadratureBilinear2D()
+    b = pyfem.BasisBilinear2D(q)
+    xdv = np.ones(10) / 10
+    model = pyfem.NonlinearPoisson2D(X, conn, dof_fixed, None, q, b)
+    u = pyfem.Assembler(model).solve_nonlinear(method="direct", xdv=xdv).copy()
+    np.random.seed(123)
+    pr = np.random.rand(u.shape[0])
+    out = dict(X=X, conn=conn.astype(np.int32), dof_fixed=np.asarray(dof_fixed, dtype=np.int32), xdv=xdv, u=u,
+               pTu=np.float64(pr.dot(u)))
+    # tangent / residual at a random state on a distorted mesh with a non-uniform design vector
+    rng = np.random.RandomState(7)
+    Xd = X + 0.2 / 31 * (rng.rand(*X.shape) - 0.5)
+    xdv2 = rng.rand(7)
+    us = 0.3 * rng.rand(X.shape[0])
+    m2 = pyfem.NonlinearPoisson2D(Xd, conn, dof_fixed, None, q, b)
+    K = m2.compute_jacobian(xdv2, us)
+    out.update(Xd=Xd, xdv2=xdv2, us=us, res=m2.compute_rhs(xdv2, us).copy(), Ke0=m2.Ke_mat[0].copy())
+    out.update(_csr(K, "K"))
+    np.savez_compressed(os.path.join(OUT, "nlpoisson32_quad.npz"), **out)
+    print(f"nlpoisson32_quad: p.u={out['pTu']!r} |K|={np.linalg.norm(K.data):.13e} |res|={np.linalg.norm(out['res']):.13e}")
+
+
 def main():
     pyfem, parse_inp = _import_reference()
+    if "--only-nl" in sys.argv:
+        return main_nonlinear(pyfem)
     os.makedirs(OUT, exist_ok=True)
     if "--only-ho" in sys.argv:
         return main_highorder(pyfem)
@@ -227,6 +257,7 @@ def main():
         return main_3d(pyfem)
     main_3d(pyfem)
     main_highorder(pyfem)
+    main_nonlinear(pyfem)
 
     # --- PS32: the reference's own test case (tests/test_elasticity.py:23-51) ------------
     c = pyfem.ProblemCreator(nnodes_x=32, nnodes_y=32)

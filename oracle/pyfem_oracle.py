@@ -383,6 +383,73 @@ def poisson_rhs(X, conn, etype, gfunc):
     return rhs
 
 
+# --------------------------------------------------------------------------
+# NonlinearPoisson2D:  -div( h(x)(1 + u^2) grad u ) = g                      ref: pyfem.py:1332-1665
+# --------------------------------------------------------------------------
+def nlpoisson_gfun(Xq):
+    """ref: pyfem.py:1427-1447."""
+    x, y = Xq[..., 0], Xq[..., 1]
+    return 1e4 * x * (1.0 - x) * (1.0 - 2.0 * x) * y * (1.0 - y) * (1.0 - 2.0 * y)
+
+
+def nlpoisson_hfun(xdv, Xq):
+    """h = 1 + 4y(1-y) sum_k xdv[k] C(n-1,k) (1-x)^(n-1-k) x^k   (ref: pyfem.py:1449-1470)."""
+    from scipy import special
+
+    x, y = Xq[..., 0], Xq[..., 1]
+    n = len(xdv)
+    h = np.ones_like(x)
+    for k in range(n):
+        h = h + xdv[k] * special.binom(n - 1, k) * (1.0 - x) ** (n - 1 - k) * x**k * 4.0 * y * (1.0 - y)
+    return h
+
+
+def nlpoisson_element(X, conn, xdv, u, etype="quad"):
+    """Element tangent Ke (E,P,P) and residual re (E,P) at the state u  (ref: pyfem.py:1472-1601):
+    Ke[j,i] = sum_q w detJ h (1+uq^2) gradN_j.gradN_i + sum_q 2 w detJ h uq (gradN_j . grad u) N[q,i]
+    re[j]   = sum_q w detJ h (1+uq^2) gradN_j . grad u - sum_q w detJ g N[q,j]."""
+    _, wq = quadrature(etype)
+    N, dN = shape_tables(etype)
+    detJ, Ngrad = geometry(X, conn, dN)
+    Xq = np.einsum("jl,ilk->ijk", N, X[conn])
+    ue = np.asarray(u, dtype=float)[conn]
+    uq = np.einsum("jl,il->ij", N, ue)
+    h, g = nlpoisson_hfun(xdv, Xq), nlpoisson_gfun(Xq)
+    Ke = np.einsum("nq,q,nqjl,nqkl->njk", detJ * h * (1.0 + uq**2), wq, Ngrad, Ngrad)
+    Ke += np.einsum("nq,nqjl,nqkl,nk,qi->nji", 2.0 * detJ * h * uq * wq, Ngrad, Ngrad, ue, N)
+    re = np.einsum("nq,nqjl,nqkl,nk->nj", detJ * h * (1.0 + uq**2) * wq, Ngrad, Ngrad, ue)
+    re -= np.dot(detJ * wq * g, N)
+    return Ke, re
+
+
+def nlpoisson_residual(X, conn, xdv, u, etype="quad"):
+    """Global residual ("compute_rhs", ref: pyfem.py:1374-1388 with the range(nquads) scatter of :861-875)."""
+    _, re = nlpoisson_element(X, conn, xdv, u, etype)
+    rhs = np.zeros(X.shape[0])
+    for n in range(quadrature(etype)[1].size):
+        np.add.at(rhs, conn[:, n], re[:, n])
+    return rhs
+
+
+def nlpoisson_solve(X, conn, dof_fixed, xdv, etype="quad", tol=1e-10, atol=1e-12, max_iter=10):
+    """Newton iteration of Assembler.solve_nonlinear with the direct solver (ref: pyfem.py:2319-2355): rows of the
+    fixed dofs replaced by the identity (enforce_symmetric_K=False), u -= K^-1 res."""
+    u = np.zeros(X.shape[0])
+    res0 = None
+    for k in range(max_iter):
+        Ke, _ = nlpoisson_element(X, conn, xdv, u, etype)
+        K = assemble_csr(Ke, conn)
+        res = nlpoisson_residual(X, conn, xdv, u, etype)
+        K, res = apply_dirichlet_bcs(K, res, dof_fixed, None, False)
+        rn = np.sqrt(res.dot(res))
+        if k == 0:
+            res0 = rn
+        elif rn < tol * res0 or rn < atol:
+            break
+        u = u - spsolve(K.tocsc(), res)
+    return u
+
+
 def poisson_K_dv_sens(X, conn, etype, rho, phi, psi, p=0.0):
     """d(phi^T K psi)/d rho for LinearPoisson (ref: pyfem.py:1240-1276, 1303-1329)."""
     _, wq = quadrature(etype)

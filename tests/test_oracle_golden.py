@@ -226,3 +226,21 @@ def test_quadratic_elements_match_reference(name, etype, shape):
     assert np.abs(K.data - Kref.data).max() < K_TOL * np.abs(Kref.data).max()
     s = orc.elasticity_K_dv_sens(g["X"], conn, etype, g["rho"], g["phi"], g["psi"], p=float(g["p"]))
     assert relmax(s, g["sens"]) < 1e-12
+
+
+def test_nonlinear_poisson_matches_reference():
+    """NonlinearPoisson2D tangent / residual at a random state on a distorted mesh, and the Newton solution of the
+    reference's own test case (tests/test_nonlinear_poisson.py) with the direct solver."""
+    g = load("nlpoisson32_quad")
+    conn = g["conn"].astype(np.int64)
+    Ke, _ = orc.nlpoisson_element(g["Xd"], conn, g["xdv2"], g["us"])
+    assert relmax(Ke[0], g["Ke0"]) < K_TOL
+    K = orc.assemble_csr(Ke, conn)
+    Kref = csr_of(g, "K", K.shape[0])
+    assert np.array_equal(K.indptr, Kref.indptr) and np.array_equal(K.indices, Kref.indices)
+    assert np.abs(K.data - Kref.data).max() < K_TOL * np.abs(Kref.data).max()
+    assert relmax(orc.nlpoisson_residual(g["Xd"], conn, g["xdv2"], g["us"]), g["res"]) < K_TOL
+    u = orc.nlpoisson_solve(g["X"], conn, g["dof_fixed"], g["xdv"])
+    assert relmax(u, g["u"]) < U_TOL
+    np.random.seed(123)
+    assert abs(np.random.rand(u.shape[0]).dot(u) / float(g["pTu"]) - 1) < 1e-10
