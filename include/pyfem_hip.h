@@ -164,6 +164,16 @@ int pf_element_matrices_tab(pf_ctx* ctx, int Q, const double* N, const double* d
                             double nu, double p, const double* rho, const double* drho, double* Ke_out);
 int pf_sens_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int kind, double E, double nu,
                 double p, const double* rho, const double* phi, const double* psi, double* out);
+/* NonlinearPoisson2D, -div(h(x)(1 + u^2) grad u) = g with the reference's h and g (pyfem.py:1332-1665), on a 2-D pattern
+ * with one dof per node; tables as above.  u: nodal state; ck[k] = xdv[k] * binom(nck - 1, k), k < nck: the design
+ * coefficients of h (pyfem.py:1449-1470).  what:
+ *   PF_NL_TANGENT          compute_jacobian(xdv, u), nonsymmetric (pyfem.py:1390-1405, 1523-1601)  -> nnz values
+ *   PF_NL_TANGENT_SPD      its first, symmetric positive definite term only (what the preconditioner is built from)
+ *   PF_NL_ELEMENT_TANGENT  the element matrices (nelems, P, P) (model.Ke_mat)
+ *   PF_NL_RESIDUAL         compute_rhs(xdv, u): the assembled residual (pyfem.py:1374-1388, 1472-1521) -> nnodes values */
+enum { PF_NL_TANGENT = 0, PF_NL_TANGENT_SPD = 1, PF_NL_ELEMENT_TANGENT = 2, PF_NL_RESIDUAL = 3 };
+int pf_nlpoisson_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int what, const double* u,
+                     const double* ck, int nck, double* out);
 
 /* block layout -> scipy CSR data order (identity copy for d == 1) */
 int pf_vals_to_csr(pf_ctx* ctx, const double* vals, double* csr_data);
@@ -189,6 +199,13 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * that many iterations (<=0: default, 50 for Jacobi / 1 for AMG); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
+/* BiCGStab for the nonsymmetric systems of the reference: K with Dirichlet conditions on the rows only
+ * (enforce_symmetric_K=False) and the Newton tangent of NonlinearPoisson2D, which it solves with scipy gmres or spsolve
+ * (pyfem.py:2340-2349, 2414-2420).  Same stopping rule and outputs as pf_cg.  precond: PF_PRECOND_NONE, _JACOBI (diagonal
+ * of vals) or _AMG: the V-cycle of pvals, a symmetric positive definite matrix on the same pattern (e.g. the same
+ * operator with symmetric boundary conditions; PF_NL_TANGENT_SPD); pvals may be NULL otherwise. */
+int pf_bicgstab(pf_ctx* ctx, const double* vals, const double* pvals, const double* b, double* x, double rtol,
+                double atol, int maxiter, int precond, int32_t* iters_host, double* relres_host);
 /* PF_PRECOND_AMG: smoothed-aggregation AMG V(2,2) cycle -- the device counterpart of the reference's
  * pyamg.smoothed_aggregation_solver(K).aspreconditioner() (pyfem.py:2393-2400) and of
  * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,

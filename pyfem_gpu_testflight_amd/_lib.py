@@ -17,6 +17,7 @@ PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
 PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE = 0, 1, 2, 3
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
 PF_TAB_ELASTICITY, PF_TAB_POISSON = 0, 1
+PF_NL_TANGENT, PF_NL_TANGENT_SPD, PF_NL_ELEMENT_TANGENT, PF_NL_RESIDUAL = 0, 1, 2, 3
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 
@@ -61,6 +62,8 @@ SIGNATURES = {
                         C.POINTER(_f64)]),
     "pf_amg_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_f64), C.c_int]),
     "pf_amg_prepare": (C.c_int, [_vp, _vp, C.c_int]),
+    "pf_bicgstab": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
+    "pf_nlpoisson_tab": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "pf_amg_vcycle": (C.c_int, [_vp, _vp, _vp]),
     "pf_add_to_diag": (C.c_int, [_vp, _vp, _vp]),
     "pf_dot": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),

@@ -848,6 +848,113 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
 }
 
 // ------------------------------------------------------------------------------------------
+// BiCGStab for nonsymmetric matrices on the ctx pattern: the Newton tangent of NonlinearPoisson2D and any K whose
+// Dirichlet conditions were applied to the rows only (enforce_symmetric_K=False) -- the systems the reference hands to
+// scipy gmres / spsolve (pyfem.py:2340-2349, 2414-2420).  Right-preconditioned with the Jacobi diagonal of vals or with
+// the AMG V-cycle of a symmetric positive definite companion on the same pattern (pvals: e.g. the tangent's SPD part).
+// Systems of this kind are small next to the PCG's; scalars are read back every step (four syncs per iteration).
+// ------------------------------------------------------------------------------------------
+// out = a x + b y + c z (z may be NULL); out may alias x or y
+__global__ __launch_bounds__(256) void k_lin3(int64_t n, double* out, double a, const double* x, double b, const double* y,
+                                              double c, const double* z) {
+  PF_VEC_LOOP(i, n) out[i] = a * x[i] + b * y[i] + (z ? c * z[i] : 0.0);
+}
+
+__global__ __launch_bounds__(256) void k_mul(int64_t n, double* __restrict__ out, const double* __restrict__ d,
+                                             const double* __restrict__ x) {
+  PF_VEC_LOOP(i, n) out[i] = d[i] * x[i];
+}
+
+extern "C" int pf_bicgstab(pf_ctx* ctx, const double* vals, const double* pvals, const double* b, double* x, double rtol,
+                           double atol, int maxiter, int precond, int32_t* iters_host, double* relres_host) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && vals && b && x, "pf_bicgstab: no pattern / NULL argument");
+  PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI || precond == PF_PRECOND_AMG,
+             "pf_bicgstab: unknown preconditioner");
+  PF_REQUIRE(precond != PF_PRECOND_AMG || pvals, "pf_bicgstab: the AMG needs the symmetric positive definite companion");
+  PF_HIP(hipSetDevice(ctx->device));
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
+  if (ctx->cgw_cap < 9 * n) {
+    pf_free(ctx->cgw);
+    PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * 9 * n));
+    ctx->cgw_cap = 9 * n;
+  }
+  double *r = ctx->cgw, *rh = r + n, *p = rh + n, *v = p + n, *sv = v + n, *tv = sv + n, *y = tv + n, *z = y + n,
+         *dinv = z + n;
+  hipStream_t st = ctx->stream;
+  const unsigned vg = vec_grid(n);
+  if (precond == PF_PRECOND_AMG) {
+    const int arc = pf_amg_setup(ctx, pvals, 0);
+    if (arc == PF_E_UNSUPPORTED) precond = PF_PRECOND_JACOBI;
+    else if (arc) return arc;
+  }
+  if (precond == PF_PRECOND_JACOBI) {
+    const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
+    if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
+    else if (ctx->d == 3) k_extract_diag<3><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
+    else k_extract_diag<2><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
+    PF_LAUNCH_CHECK();
+  }
+  auto apply_M = [&](const double* in, double* out) -> int {
+    if (precond == PF_PRECOND_AMG) return pf_amg_apply(ctx, in, out);
+    if (precond == PF_PRECOND_JACOBI) k_mul<<<vg, 256, 0, st>>>(n, out, dinv, in);
+    else PF_HIP(hipMemcpyAsync(out, in, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+    return PF_OK;
+  };
+  double h[2];
+  auto dots = [&](const double* a0, const double* b0, const double* a1, const double* b1) -> int {  // h[0], h[1]
+    k_dot<<<vg, 256, 0, st>>>(n, a0, b0, nullptr, part(ctx, PA_PAP));
+    if (a1) k_dot<<<vg, 256, 0, st>>>(n, a1, b1, nullptr, part(ctx, PA_RR));
+    k_finalize<<<1, 256, 0, st>>>(a1 ? 2 : 1, part(ctx, PA_PAP), (int)vg, part(ctx, PA_RR), (int)vg, nullptr, 0,
+                                  part(ctx, PA_BB), nullptr, 0);
+    PF_HIP(hipMemcpyAsync(h, part(ctx, PA_BB), sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+  };
+  int rc = pf_launch_spmv(ctx, vals, x, v, nullptr);  // v = A x0
+  if (rc) return rc;
+  k_lin3<<<vg, 256, 0, st>>>(n, r, 1.0, b, -1.0, v, 0.0, nullptr);
+  PF_HIP(hipMemcpyAsync(rh, r, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  PF_HIP(hipMemsetAsync(p, 0, sizeof(double) * n, st));
+  PF_HIP(hipMemsetAsync(v, 0, sizeof(double) * n, st));
+  if ((rc = dots(b, b, r, r))) return rc;
+  const double bnorm = sqrt(h[0]);
+  const double tol = std::max(rtol * bnorm, atol);
+  double rnorm = sqrt(h[1]), rho = 1.0, alpha = 1.0, omega = 1.0;
+  int it = 0;
+  while (rnorm > tol && it < maxiter) {
+    if ((rc = dots(rh, r, nullptr, nullptr))) return rc;
+    const double rho_new = h[0];
+    if (rho_new == 0.0 || !(rho_new == rho_new)) break;  // breakdown
+    const double beta = (rho_new / rho) * (alpha / omega);
+    k_lin3<<<vg, 256, 0, st>>>(n, p, 1.0, r, beta, p, -beta * omega, v);
+    if ((rc = apply_M(p, y))) return rc;
+    if ((rc = pf_launch_spmv(ctx, vals, y, v, nullptr))) return rc;
+    if ((rc = dots(rh, v, nullptr, nullptr))) return rc;
+    alpha = rho_new / h[0];
+    k_lin3<<<vg, 256, 0, st>>>(n, sv, 1.0, r, -alpha, v, 0.0, nullptr);
+    if ((rc = apply_M(sv, z))) return rc;
+    if ((rc = pf_launch_spmv(ctx, vals, z, tv, nullptr))) return rc;
+    if ((rc = dots(tv, sv, tv, tv))) return rc;
+    omega = h[1] > 0.0 ? h[0] / h[1] : 0.0;
+    k_lin3<<<vg, 256, 0, st>>>(n, x, 1.0, x, alpha, y, omega, z);
+    k_lin3<<<vg, 256, 0, st>>>(n, r, 1.0, sv, -omega, tv, 0.0, nullptr);
+    PF_LAUNCH_CHECK();
+    if ((rc = dots(r, r, nullptr, nullptr))) return rc;
+    rnorm = sqrt(h[0]);
+    rho = rho_new;
+    ++it;
+    if (!(rnorm == rnorm) || omega == 0.0) break;
+  }
+  if (iters_host) *iters_host = it;
+  if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;
+  if (!(rnorm <= tol))
+    return pf_fail(ctx, PF_E_NOCONV, "bicgstab failed with code " + std::to_string(it));  // pyfem.py:2421-2422
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const double* in1, double* out0,
                               double E, double nu, double p, double* ms_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");

@@ -284,6 +284,97 @@ __global__ __launch_bounds__(TAB_THREADS) void k_tab_sens(TabArgs A, const int32
   }
 }
 
+// NonlinearPoisson2D:  -div( h(x) (1 + u^2) grad u ) = g  on quads given by their tables (pyfem.py:1332-1665).
+//   h = 1 + 4y(1-y) sum_k ck[k] (1-x)^(n-1-k) x^k  with ck[k] = xdv[k] C(n-1,k)   (pyfem.py:1449-1470)
+//   g = 1e4 x(1-x)(1-2x) y(1-y)(1-2y)                                             (pyfem.py:1427-1447)
+// MODE 0: tangent into the scalar CSR values (one colour per launch; sym_only drops the second, nonsymmetric term and
+//         leaves the SPD operator the preconditioner is built from)
+//           Ke[j,i] = sum_q w detJ h (1+uq^2) gradN_j.gradN_i + sum_q 2 w detJ h uq (gradN_j.grad u) N[q,i]   (:1523-1562)
+// MODE 1: the element tangents (nelems, P, P)
+// MODE 2: residual ("compute_rhs", :1472-1521) added to the nodal vector:
+//           re[j] = sum_q w detJ h (1+uq^2) gradN_j.grad u - sum_q w detJ g N[q,j];  like _assemble_rhs (pyfem.py:861-875)
+//           only local nodes j < Q are scattered
+struct NlArgs {
+  const double* u;   // nodal state
+  const double* ck;  // (n) design coefficients times binomials
+  int n;
+  int sym_only;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(TAB_THREADS) void k_tab_nlpoisson(TabArgs A, NlArgs B, const int32_t* __restrict__ order,
+                                                             int64_t count, const int32_t* __restrict__ nptr,
+                                                             const int32_t* __restrict__ nidx, double* __restrict__ out) {
+  extern __shared__ double sh[];
+  const int P = A.P, Q = A.Q, t = threadIdx.x;
+  const TabLds L = tab_lds<2>(sh, P, Q, P + 5 * Q);
+  double* ue = L.extra;       // (P)
+  double* hq = ue + P;        // (Q) w detJ h (1 + uq^2)
+  double* fq = hq + Q;        // (Q) 2 w detJ h uq
+  double* gq = fq + Q;        // (Q) w detJ g
+  double* gu = gq + Q;        // (2Q) grad u
+  for (int64_t k = blockIdx.x; k < count; k += gridDim.x) {
+    const int64_t e = order ? order[k] : k;
+    tab_geometry<2>(A, e, L);
+    for (int a = t; a < P; a += TAB_THREADS) ue[a] = B.u[L.en[a]];
+    __syncthreads();
+    for (int q = t; q < Q; q += TAB_THREADS) {
+      double x = 0.0, y = 0.0, uq = 0.0, gx = 0.0, gy = 0.0;
+      for (int a = 0; a < P; ++a) {
+        const double Na = A.N[(int64_t)q * P + a];
+        x += Na * L.Xe[2 * a];
+        y += Na * L.Xe[2 * a + 1];
+        uq += Na * ue[a];
+        gx += ue[a] * L.G[2 * (q * P + a)];
+        gy += ue[a] * L.G[2 * (q * P + a) + 1];
+      }
+      double h = 0.0;
+      for (int c = 0; c < B.n; ++c) h += B.ck[c] * pow(1.0 - x, (double)(B.n - 1 - c)) * pow(x, (double)c);
+      h = 1.0 + h * 4.0 * y * (1.0 - y);
+      const double wd = L.sc[q];
+      hq[q] = wd * h * (1.0 + uq * uq);
+      fq[q] = 2.0 * wd * h * uq;
+      gq[q] = wd * 1e4 * x * (1.0 - x) * (1.0 - 2.0 * x) * y * (1.0 - y) * (1.0 - 2.0 * y);
+      gu[2 * q] = gx;
+      gu[2 * q + 1] = gy;
+    }
+    __syncthreads();
+    if (MODE == 2) {
+      for (int j = t; j < P && j < Q; j += TAB_THREADS) {
+        double r = 0.0;
+        for (int q = 0; q < Q; ++q) {
+          const double* g = L.G + 2 * (q * P + j);
+          r += hq[q] * (g[0] * gu[2 * q] + g[1] * gu[2 * q + 1]) - gq[q] * A.N[(int64_t)q * P + j];
+        }
+        out[L.en[j]] += r;  // coloured
+      }
+    } else {
+      for (int pair = t; pair < P * P; pair += TAB_THREADS) {
+        const int j = pair / P, i = pair - j * P;
+        double v = 0.0;
+        for (int q = 0; q < Q; ++q) {
+          const double* gj = L.G + 2 * (q * P + j);
+          const double* gi = L.G + 2 * (q * P + i);
+          v += hq[q] * (gj[0] * gi[0] + gj[1] * gi[1]);
+          if (!B.sym_only) v += fq[q] * (gj[0] * gu[2 * q] + gj[1] * gu[2 * q + 1]) * A.N[(int64_t)q * P + i];
+        }
+        if (MODE == 1) {
+          out[e * (int64_t)(P * P) + pair] = v;
+        } else {
+          const int32_t nj = L.en[j], ni = L.en[i];
+          int32_t lo = nptr[nj], hi = nptr[nj + 1] - 1;
+          while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (nidx[mid] < ni) lo = mid + 1; else hi = mid;
+          }
+          out[lo] += v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int check_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int kind, const char* who) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   if (kind != PF_TAB_ELASTICITY && kind != PF_TAB_POISSON) return pf_fail(ctx, PF_E_INVALID, std::string(who) + ": unknown kind");
@@ -406,6 +497,38 @@ extern "C" int pf_sens_tab(pf_ctx* ctx, int Q, const double* N, const double* dN
     else if (ctx->ndims == 2) k_tab_sens<2, 2><<<g, TAB_THREADS, lds, ctx->stream>>>(A, order, count, phi, psi, out);
     else if (db == 1) k_tab_sens<3, 1><<<g, TAB_THREADS, lds, ctx->stream>>>(A, order, count, phi, psi, out);
     else k_tab_sens<3, 3><<<g, TAB_THREADS, lds, ctx->stream>>>(A, order, count, phi, psi, out);
+  }
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_nlpoisson_tab(pf_ctx* ctx, int Q, const double* N, const double* dN, const double* wq, int what,
+                                const double* u, const double* ck, int nck, double* out) {
+  if (int rc = check_tab(ctx, Q, N, dN, wq, PF_TAB_POISSON, "pf_nlpoisson_tab")) return rc;
+  PF_REQUIRE(ctx->ndims == 2, "pf_nlpoisson_tab: the nonlinear Poisson model is two-dimensional (pyfem.py:1332)");
+  PF_REQUIRE(u && out && (ck || nck == 0) && nck >= 0, "pf_nlpoisson_tab: NULL argument");
+  PF_REQUIRE(what >= PF_NL_TANGENT && what <= PF_NL_RESIDUAL, "pf_nlpoisson_tab: unknown output");
+  PF_HIP(hipSetDevice(ctx->device));
+  TabArgs A = tab_args(ctx, Q, N, dN, wq, 0.0, 0.0, 0.0, nullptr, nullptr);
+  NlArgs B{u, ck, nck, what == PF_NL_TANGENT_SPD};
+  const size_t lds = tab_lds_bytes(2, A.P, Q, A.P + 5 * Q);
+  if (what == PF_NL_ELEMENT_TANGENT) {
+    k_tab_nlpoisson<1><<<tab_grid(ctx->nelems), TAB_THREADS, lds, ctx->stream>>>(A, B, nullptr, ctx->nelems, ctx->nptr,
+                                                                                 ctx->nidx, out);
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
+  const size_t nout = what == PF_NL_RESIDUAL ? (size_t)ctx->nnodes : (size_t)ctx->nblocks;
+  PF_HIP(hipMemsetAsync(out, 0, sizeof(double) * nout, ctx->stream));
+  if (int rc = ensure_colours(ctx)) return rc;
+  for (size_t c = 0; c + 1 < ctx->tab_color_ptr.size(); ++c) {
+    const int64_t first = ctx->tab_color_ptr[c], count = ctx->tab_color_ptr[c + 1] - first;
+    if (what == PF_NL_RESIDUAL)
+      k_tab_nlpoisson<2><<<tab_grid(count), TAB_THREADS, lds, ctx->stream>>>(A, B, ctx->tab_order + first, count, ctx->nptr,
+                                                                            ctx->nidx, out);
+    else
+      k_tab_nlpoisson<0><<<tab_grid(count), TAB_THREADS, lds, ctx->stream>>>(A, B, ctx->tab_order + first, count, ctx->nptr,
+                                                                            ctx->nidx, out);
   }
   PF_LAUNCH_CHECK();
   return PF_OK;

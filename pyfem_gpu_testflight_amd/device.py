@@ -276,6 +276,26 @@ class HipContext:
             _lib.check(self._ctx, rc, "pf_cg")
         return x, iters.value, relres.value
 
+    def bicgstab(self, vals, b, pvals=None, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI):
+        """Nonsymmetric solve on the device (pf_bicgstab); pvals: SPD companion for the AMG preconditioner."""
+        x = self.zeros(self.nrows) if x0 is None else x0.clone()
+        iters, relres = _lib._i32(), _lib._f64()
+        self._sync_stream()
+        rc = self.lib.pf_bicgstab(self._ctx, _ptr(vals), _ptr(pvals), _ptr(b), _ptr(x), rtol, atol, int(maxiter), precond,
+                                  C.byref(iters), C.byref(relres))
+        _lib.check(self._ctx, rc, "pf_bicgstab")
+        return x, iters.value, relres.value
+
+    def nlpoisson(self, what, u, ck):
+        """NonlinearPoisson2D pieces at the state u (pf_nlpoisson_tab): tangent values, its SPD part, element tangents
+        (nelems,P,P) or the assembled residual (nnodes)."""
+        n = {_lib.PF_NL_TANGENT: self.nnz, _lib.PF_NL_TANGENT_SPD: self.nnz,
+             _lib.PF_NL_ELEMENT_TANGENT: self.nelems * self.P * self.P, _lib.PF_NL_RESIDUAL: self.nnodes}[what]
+        out = self.empty(n)
+        self._sync_stream()
+        self._call("pf_nlpoisson_tab", *self._tab_args(), what, _ptr(u), _ptr(ck), int(ck.numel()), _ptr(out))
+        return out
+
     def amg_info(self):
         """Hierarchy of the last AMG-preconditioned solve: list of (nodes, dofs per node, omega)."""
         cap = 16

@@ -18,7 +18,7 @@ Scope: 4-node quads, 3-node triangles and 8-node blocks as
 (LinearElasticity with RAMP density and sensitivities, LinearPoisson, Helmholtz filter, Assembler.solve);
 10-node tetrahedra, 20-node bricks and any other 3-D basis through the table-driven kernels (LinearElasticity);
 complex-step densities (the reference's derivative tests) as a real/imaginary pair of device matrices.
-NonlinearPoisson2D, A2DWrapper and solve_nonlinear raise NotImplementedError here.
+A2DWrapper (external a2d library) raises NotImplementedError here.
 """
 import numpy as np
 
@@ -378,6 +378,15 @@ class ModelBase:
         torch = self.hctx.torch
         on_device = isinstance(rhs, torch.Tensor)
         rhs_d = rhs if on_device else self.hctx.to_device(rhs, torch.float64)
+        if not enforce_symmetric_K:
+            # rows only: K stays nonsymmetric and goes to BiCGStab, whose AMG is built from a symmetric positive definite
+            # companion on the same pattern -- the tangent's SPD part (NonlinearPoisson2D) or K itself before the
+            # conditions -- with the conditions applied symmetrically
+            comp = getattr(K, "companion", None)
+            if comp is None:
+                comp = K.copy()
+            self.hctx.apply_dirichlet(comp.vals, rhs_d.clone(), self._fixed_mask, self._fixed_vals, True)
+            K.companion = comp
         self.hctx.apply_dirichlet(K.vals, rhs_d, self._fixed_mask, self._fixed_vals, enforce_symmetric_K)
         K.invalidate()
         K._eliminate = True  # the reference ends with K.eliminate_zeros() (pyfem.py:826)
@@ -729,8 +738,61 @@ def _not_on_path(name, where):
     return _Stub
 
 
-NonlinearPoisson2D = _not_on_path("NonlinearPoisson2D", "pyfem.py:1332-1664")
-A2DWrapper = _not_on_path("A2DWrapper", "pyfem.py:2180-2283")
+A2DWrapper = _not_on_path("A2DWrapper", "pyfem.py:2180-2283 (needs the external a2d library)")
+
+
+class NonlinearPoisson2D(ModelBase):
+    """ref: pyfem.py:1332-1665.   -div( h(x) (1 + u^2) grad u ) = g  with the reference's h (Bernstein design variables
+    xdv) and g.  compute_jacobian(xdv, u) is the Newton tangent (nonsymmetric), compute_rhs(xdv, u) the residual --
+    the reference's names; Assembler.solve_nonlinear drives them.  Both are evaluated by the table-driven kernels
+    (pf_nlpoisson_tab) from the basis tables."""
+
+    @time_this
+    def __init__(self, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=None):
+        if np.asarray(X).shape[1] != 2:
+            raise ValueError("NonlinearPoisson2D is two-dimensional")
+        super().__init__(1, X, conn, dof_fixed, dof_fixed_vals, quadrature, basis, device=device)
+        self._state = None
+
+    def _device_state(self, xdv, u):
+        from scipy import special
+
+        torch = self.hctx.torch
+        xdv = np.asarray(xdv, dtype=float)
+        n = xdv.shape[0]
+        ck = self.hctx.to_device(xdv * special.binom(n - 1, np.arange(n)), torch.float64)  # pyfem.py:1464-1468
+        u_d = u if isinstance(u, torch.Tensor) else self.hctx.to_device(np.asarray(u, dtype=float), torch.float64)
+        self._state = (u_d, ck)
+        return u_d, ck
+
+    @time_this
+    def compute_jacobian(self, xdv, u):
+        """ref: pyfem.py:1390-1405, 1523-1562.  The returned matrix carries its symmetric positive definite part as
+        `companion`: the preconditioner of the nonsymmetric solve is built from it."""
+        u_d, ck = self._device_state(xdv, u)
+        K = DeviceCSR(self.hctx, self.hctx.nlpoisson(_lib.PF_NL_TANGENT, u_d, ck))
+        K.companion = DeviceCSR(self.hctx, self.hctx.nlpoisson(_lib.PF_NL_TANGENT_SPD, u_d, ck))
+        return K
+
+    @time_this
+    def compute_rhs(self, xdv, u):
+        """ref: pyfem.py:1374-1388, 1472-1521 -- the residual at u (the reference's name for it is rhs)."""
+        u_d, ck = self._device_state(xdv, u)
+        self.rhs[...] = self.hctx.nlpoisson(_lib.PF_NL_RESIDUAL, u_d, ck).cpu().numpy()
+        return self.rhs
+
+    @property
+    def Ke_mat(self):
+        """Element tangents (nelems, P, P) at the last state (ref attribute: pyfem.py:717-723)."""
+        if self._state is None:
+            raise AttributeError("Ke_mat: call compute_jacobian(xdv, u) first")
+        return self.hctx.nlpoisson(_lib.PF_NL_ELEMENT_TANGENT, *self._state).view(self.nelems, self.nnodes_per_elem,
+                                                                                 self.nnodes_per_elem).cpu().numpy()
+
+    def compute_residual(self, u):
+        """ref: pyfem.py:1407-1425 -- unusable in the reference (it writes into self.Re, which is None)."""
+        raise TypeError("'NoneType' object does not support item assignment (NonlinearPoisson2D.compute_residual is "
+                        "dead code in the reference: self.Re is never allocated, pyfem.py:1372, 1419)")
 
 
 # ------------------------------------------------------------------------------------------
@@ -776,14 +838,36 @@ class Assembler:
         on_device = isinstance(rhs, torch.Tensor)
         b = rhs if on_device else hctx.to_device(rhs, torch.float64)
         try:
-            x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
+            comp = getattr(K, "companion", None)
+            if comp is not None:  # nonsymmetric (rows-only conditions, Newton tangent): BiCGStab, AMG of the companion
+                x, it, rr = hctx.bicgstab(K.vals, b, pvals=comp.vals, rtol=rtol, precond=_PRECOND[self.precond])
+            else:
+                x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
         except RuntimeError as e:
             raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
         self.last_iters, self.last_relres = it, rr
         return x if on_device else x.cpu().numpy()
 
-    def solve_nonlinear(self, *a, **k):
-        raise NotImplementedError("Newton solve (pyfem.py:2320-2355) is outside the accelerated hot path")
+    @time_this
+    def solve_nonlinear(self, method="gmres", xdv=None, u0=None, tol=1e-10, atol=1e-12, max_iter=10):
+        """ref: pyfem.py:2319-2355 -- Newton iteration on model.compute_jacobian(xdv, u) / compute_rhs(xdv, u) with the
+        conditions applied to the rows only; each update is a nonsymmetric device solve (BiCGStab, see
+        _solve_linear_system)."""
+        assert method == "direct" or method == "cg" or method == "gmres"
+        u = np.zeros(self.model.nnodes) if u0 is None else u0
+        res_norm_init = None
+        for k in range(max_iter):
+            K = self.model.compute_jacobian(xdv, u)
+            res = self.model.compute_rhs(xdv, u)
+            self.model.apply_dirichlet_bcs(K, res, enforce_symmetric_K=False)
+            res_norm = np.sqrt(_vdot(res, res))
+            print("pyfem", "{0:5d} {1:25.15e}".format(k, res_norm))
+            if k == 0:
+                res_norm_init = res_norm
+            elif res_norm < tol * res_norm_init or res_norm < atol:
+                break
+            u -= self._solve_linear_system(K, res, method)
+        return u
 
     def plot(self, u, ax, **kwargs):
         """Filled contours of a nodal scalar on a 2-D mesh (ref: pyfem.py:2358-2390; the examples end with it).

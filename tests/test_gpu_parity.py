@@ -263,7 +263,7 @@ def test_error_behaviour(pf):
     Kc = model.compute_jacobian(np.ones(X.shape[0]) + 1j * 1e-30)  # complex step: a real/imaginary pair, not an error
     assert np.iscomplexobj(Kc.dot(np.ones(2 * X.shape[0])))
     with pytest.raises(NotImplementedError):
-        pf.Assembler(model).solve_nonlinear()
+        pf.A2DWrapper(X, conn, dof_fixed, None, q, b)  # needs the external a2d library (pyfem.py:2180-2283)
     # singular system (no BCs) with a tiny iteration cap -> RuntimeError like pyfem.py:2421-2422
     free = pf.LinearElasticity(X, conn, [], None, force, q, b)
     K = free.compute_jacobian()
@@ -1174,3 +1174,63 @@ def test_table_driven_kernels_agree_with_the_hard_wired_ones(pf, etype):
     Kp_hw = hp.assemble_poisson(mp.p, rho)
     Kp_tab = hp.assemble_tab(_lib.PF_TAB_POISSON, 0.0, 0.0, mp.p, rho)
     assert float((Kp_hw - Kp_tab).abs().max()) <= 1e-13 * float(Kp_hw.abs().max())
+
+
+# ---- NonlinearPoisson2D and the nonsymmetric solver ----------------------------------------------------------------
+def test_nonlinear_poisson_matches_reference(pf, orc, capsys):
+    """tests/test_nonlinear_poisson.py of the reference (32x32 quads, xdv = ones(10)/10, methods direct and gmres) against
+    the solution the reference itself produced, plus tangent / element tangent / residual at a random state on a
+    distorted mesh (oracle/gen_golden.py main_nonlinear)."""
+    g = load("nlpoisson32_quad")
+    q, b = _qb(pf, "quad")
+    m2 = pf.NonlinearPoisson2D(g["Xd"], g["conn"], g["dof_fixed"], None, q, b)
+    K = m2.compute_jacobian(g["xdv2"], g["us"])
+    Ks = K.to_scipy()
+    ref = csr_of(g, "K", g["X"].shape[0])
+    assert np.array_equal(Ks.indptr, ref.indptr) and np.array_equal(Ks.indices, ref.indices)
+    assert np.abs(Ks.data - ref.data).max() <= K_TOL * np.abs(ref.data).max()
+    assert np.abs(Ks - Ks.T).max() > 1e-3 * np.abs(ref.data).max()  # the tangent is not symmetric
+    assert np.abs(m2.Ke_mat[0] - g["Ke0"]).max() <= K_TOL * np.abs(g["Ke0"]).max()
+    assert relmax(m2.compute_rhs(g["xdv2"], g["us"]), g["res"]) < K_TOL
+    comp = K.companion.to_scipy()
+    assert np.abs(comp - comp.T).max() <= 1e-13 * np.abs(comp.data).max()
+    # the reference's test
+    creator = pf.ProblemCreator(nnodes_x=32, nnodes_y=32)
+    conn, X, dof_fixed = creator.create_poisson_problem()
+    assert np.array_equal(conn, g["conn"]) and np.array_equal(X, g["X"])
+    model = pf.NonlinearPoisson2D(X, conn, dof_fixed, None, q, b)
+    assembler = pf.Assembler(model)
+    x = np.ones(10) / 10
+    np.random.seed(123)
+    p = np.random.rand(X.shape[0])
+    for method in ("direct", "gmres"):
+        u = assembler.solve_nonlinear(method=method, xdv=x)
+        assert abs((p.dot(u) - float(g["pTu"])) / p.dot(u)) < 1e-8
+        assert relmax(u, g["u"]) < U_TOL
+    assert "pyfem     0" in capsys.readouterr().out  # the reference prints the residual history
+    with pytest.raises(TypeError):
+        model.compute_residual(u)  # dead in the reference as well (SURVEY A.4)
+
+
+@pytest.mark.parametrize("etype", ["quad", "block"])
+def test_rows_only_dirichlet_conditions_are_solved_as_nonsymmetric_systems(pf, orc, etype):
+    """apply_dirichlet_bcs(enforce_symmetric_K=False) leaves the columns of the fixed dofs in place (pyfem.py:813-819);
+    with prescribed values the matrix is nonsymmetric and the reference solves it with spsolve / gmres.  The device path
+    uses BiCGStab with the AMG of the symmetrically constrained companion."""
+    from scipy.sparse.linalg import spsolve
+
+    c = pf.ProblemCreator(31, 23) if etype == "quad" else pf.ProblemCreator(9, 7, 6, element_type="block")
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    rng = np.random.RandomState(9)
+    vals = 0.01 * rng.rand(len(dof_fixed))
+    q, b = _qb(pf, etype)
+    model = pf.LinearElasticity(X, conn, dof_fixed, vals, force, q, b)
+    K = model.compute_jacobian()
+    K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), enforce_symmetric_K=False)
+    Ks = K.to_scipy()
+    assert np.abs(Ks - Ks.T).max() > 0
+    u_ref = spsolve(Ks.tocsc(), rhs)
+    asm = pf.Assembler(model)
+    for method in ("gmres", "direct"):
+        assert relmax(asm._solve_linear_system(K, rhs, method), u_ref) < U_TOL
+    assert asm.last_iters < 60
