@@ -55,6 +55,9 @@ enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECON
 int pf_ctx_create(int device, pf_ctx** out);
 int pf_ctx_destroy(pf_ctx* ctx);
 const char* pf_last_error(pf_ctx* ctx);       /* ctx may be NULL: last global error      */
+/* Non-fatal conditions of the last calls (the call itself returned PF_OK), e.g. "the matrix is not definite, the AMG
+ * preconditioner was refused and Jacobi is used" from pf_cg.  Returns "" when there is none; reading clears it. */
+const char* pf_last_warning(pf_ctx* ctx);
 int pf_ctx_set_stream(pf_ctx* ctx, void* hip_stream);
 int pf_version(void);
 

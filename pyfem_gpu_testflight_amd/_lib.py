@@ -27,6 +27,7 @@ SIGNATURES = {
     "pf_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "pf_ctx_destroy": (C.c_int, [_vp]),
     "pf_last_error": (C.c_char_p, [_vp]),
+    "pf_last_warning": (C.c_char_p, [_vp]),
     "pf_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "pf_mesh_set": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, C.c_int]),
     "pf_mesh_set3d": (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, _vp, C.c_int]),

@@ -18,6 +18,7 @@ struct pf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
+  std::string warn;          // last non-fatal condition (pf_last_warning), e.g. a preconditioner that was refused
 
   // ---- mesh (device copies) ----
   int64_t nnodes = 0, nelems = 0;

@@ -278,6 +278,13 @@ extern "C" int pf_version(void) { return 1; }
 
 extern "C" const char* pf_last_error(pf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_pf_err.c_str(); }
 
+extern "C" const char* pf_last_warning(pf_ctx* ctx) {
+  static thread_local std::string taken;
+  taken.clear();
+  if (ctx) taken.swap(ctx->warn);
+  return taken.c_str();
+}
+
 extern "C" int pf_ctx_create(int device, pf_ctx** out) {
   pf_ctx* ctx = nullptr;
   if (!out) return pf_fail(nullptr, PF_E_INVALID, "pf_ctx_create: out is NULL");

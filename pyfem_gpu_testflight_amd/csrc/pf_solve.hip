@@ -784,8 +784,11 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
 
   if (precond == PF_PRECOND_AMG) {
     const int arc = pf_amg_setup(ctx, vals, amg_reuse);
-    if (arc == PF_E_UNSUPPORTED) precond = PF_PRECOND_JACOBI;  // not positive definite (e.g. detJ < 0 meshes)
-    else if (arc) return arc;
+    if (arc == PF_E_UNSUPPORTED) {  // diagonal entries of both signs among the coupled dofs: not a definite matrix
+      precond = PF_PRECOND_JACOBI;
+      ctx->warn = "pf_cg: the matrix is not definite (diagonal entries of both signs, e.g. negative densities); the AMG "
+                  "preconditioner was refused and Jacobi is used instead";
+    } else if (arc) return arc;
   }
   const bool amg = precond == PF_PRECOND_AMG;
   if (precond == PF_PRECOND_JACOBI) {
@@ -886,8 +889,10 @@ extern "C" int pf_bicgstab(pf_ctx* ctx, const double* vals, const double* pvals,
   const unsigned vg = vec_grid(n);
   if (precond == PF_PRECOND_AMG) {
     const int arc = pf_amg_setup(ctx, pvals, 0);
-    if (arc == PF_E_UNSUPPORTED) precond = PF_PRECOND_JACOBI;
-    else if (arc) return arc;
+    if (arc == PF_E_UNSUPPORTED) {
+      precond = PF_PRECOND_JACOBI;
+      ctx->warn = "pf_bicgstab: the companion matrix is not definite; the AMG preconditioner was refused and Jacobi is used";
+    } else if (arc) return arc;
   }
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);

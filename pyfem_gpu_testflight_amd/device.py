@@ -274,7 +274,16 @@ class HipContext:
                             int(check_every), C.byref(iters), C.byref(relres))
         if not (allow_maxiter and rc == _lib.PF_E_NOCONV):
             _lib.check(self._ctx, rc, "pf_cg")
+        self._warn()
         return x, iters.value, relres.value
+
+    def _warn(self):
+        """Surface the library's non-fatal conditions (a refused preconditioner means a 100x slower solve)."""
+        msg = self.lib.pf_last_warning(self._ctx)
+        if msg:
+            import warnings
+
+            warnings.warn(msg.decode(), RuntimeWarning, stacklevel=3)
 
     def bicgstab(self, vals, b, pvals=None, x0=None, rtol=1e-8, atol=0.0, maxiter=0, precond=_lib.PF_PRECOND_JACOBI):
         """Nonsymmetric solve on the device (pf_bicgstab); pvals: SPD companion for the AMG preconditioner."""
@@ -284,6 +293,7 @@ class HipContext:
         rc = self.lib.pf_bicgstab(self._ctx, _ptr(vals), _ptr(pvals), _ptr(b), _ptr(x), rtol, atol, int(maxiter), precond,
                                   C.byref(iters), C.byref(relres))
         _lib.check(self._ctx, rc, "pf_bicgstab")
+        self._warn()
         return x, iters.value, relres.value
 
     def nlpoisson(self, what, u, ck):

@@ -1234,3 +1234,31 @@ def test_rows_only_dirichlet_conditions_are_solved_as_nonsymmetric_systems(pf, o
     for method in ("gmres", "direct"):
         assert relmax(asm._solve_linear_system(K, rhs, method), u_ref) < U_TOL
     assert asm.last_iters < 60
+
+
+def test_refused_preconditioner_is_reported(pf):
+    """A negative density patch makes K indefinite (diagonal entries of both signs): the AMG is refused, Jacobi is used,
+    and the caller is told -- silently it would just be a 100x slower (or failing) solve."""
+    import torch
+
+    from pyfem_gpu_testflight_amd import _lib
+
+    c = pf.ProblemCreator(41, 31)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q, b = _qb(pf, "quad")
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+    rho = np.ones(X.shape[0])
+    patch = (np.arange(10, 16)[:, None] * 41 + np.arange(10, 16)[None, :]).ravel()  # a 6 x 6 block of nodes
+    rho[patch] = -0.5
+    K = model.compute_jacobian(rho)
+    K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
+    h = model.hctx
+    with pytest.warns(RuntimeWarning, match="not definite"):
+        h.cg(K.vals, h.to_device(rhs, torch.float64), rtol=1e-8, maxiter=20, precond=_lib.PF_PRECOND_AMG, allow_maxiter=True)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a definite matrix raises no warning
+        K = model.compute_jacobian(np.abs(rho))
+        K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
+        h.cg(K.vals, h.to_device(rhs, torch.float64), rtol=1e-8, precond=_lib.PF_PRECOND_AMG)
