@@ -37,7 +37,7 @@ def algorithmic_bytes_spmv(nnz, nrows):
     return 12 * nnz + 20 * nrows
 
 
-def cpu_baseline(n=512, reps=3, cg_iters=40):
+def cpu_baseline(n=1024, reps=3, cg_iters=40):
     """The oracle (numpy/scipy restatement of the reference's path) timed on this host: a bounded
     sample -- an n x n quad mesh of the same plane-stress workload."""
     from oracle import pyfem_oracle as orc  # checker/baseline only
