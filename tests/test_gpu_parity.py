@@ -1262,3 +1262,56 @@ def test_refused_preconditioner_is_reported(pf):
         K = model.compute_jacobian(np.abs(rho))
         K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
         h.cg(K.vals, h.to_device(rhs, torch.float64), rtol=1e-8, precond=_lib.PF_PRECOND_AMG)
+
+
+def test_user_defined_basis_runs_on_the_table_driven_kernels(pf, orc):
+    """Any 3-D basis given by its tables runs without a new kernel: a 4-node linear tetrahedron with a one-point rule,
+    defined here on top of BasisBase / QuadratureBase the way the reference's own elements are (pyfem.py:19-66, 175-250),
+    on the corner nodes of the generator's tetrahedra.  Checked against numpy on the same tables."""
+
+    class QuadratureTet1(pf.QuadratureBase):
+        def __init__(self):
+            super().__init__([[0.25, 0.25, 0.25]], [1.0 / 6.0])
+
+    class BasisTet4(pf.BasisBase):
+        def __init__(self, quadrature):
+            super().__init__(3, 4, quadrature)
+
+        def _eval_shape_fun_on_quad_pt(self, q):
+            return [1.0 - q[0] - q[1] - q[2], q[0], q[1], q[2]]
+
+        def _eval_shape_deriv_on_quad_pt(self, q):
+            return [-1.0, -1.0, -1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+
+    c = pf.ProblemCreator(7, 5, 5, element_type="tet")
+    conn10, X10, _, _ = c.create_linear_elasticity_problem()
+    used, conn = np.unique(conn10[:, :4], return_inverse=True)  # keep the corner nodes only, renumbered
+    conn = conn.reshape(-1, 4)
+    X = X10[used] + 0.02 * (np.random.RandomState(1).rand(used.size, 3) - 0.5)
+    fixed_nodes = np.flatnonzero(X10[used][:, 0] == 0.0)
+    dof_fixed = (3 * fixed_nodes[:, None] + np.arange(3)).ravel()
+    force = {int(np.argmax(X[:, 0])): [0.0, -1.0, 0.0]}
+    q = QuadratureTet1()
+    b = BasisTet4(q)
+    rho = 0.2 + 0.8 * np.random.RandomState(2).rand(X.shape[0])
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+    assert model.tabular
+    K = model.compute_jacobian(rho).to_scipy()
+    # numpy restatement on the same tables
+    N, dN, w = b.eval_shape_fun(), b.eval_shape_fun_deriv(), q.get_weight()
+    detJ, Ngrad = orc.geometry(X, conn, dN)
+    Cq = orc.ramp(np.einsum("jl,il->ij", N, rho[conn]), 3.0)
+    Be = orc._Bmat(Ngrad)
+    Ke = np.einsum("iq,q,iqnj,iq,nm,iqmk->ijk", detJ, w, Be, Cq, orc.elasticity3d_C0(), Be, optimize=True)
+    Ko = orc.assemble_csr(Ke, orc.create_conn_dof(conn, 3))
+    assert np.array_equal(K.indptr, Ko.indptr) and np.array_equal(K.indices, Ko.indices)
+    assert np.abs(K.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    assert np.abs(model.Ke_mat - Ke).max() <= K_TOL * np.abs(Ke).max()
+    from scipy.sparse.linalg import spsolve
+
+    rhs = orc.elasticity_rhs(Ko.shape[0], force)
+    Kbc, rbc = orc.apply_dirichlet_bcs(orc.assemble_csr(
+        np.einsum("iq,q,iqnj,nm,iqmk->ijk", detJ, w, Be, orc.elasticity3d_C0(), Be, optimize=True),
+        orc.create_conn_dof(conn, 3)), rhs, dof_fixed, None, True)
+    u = pf.Assembler(model).solve(method="cg")
+    assert relmax(u, spsolve(Kbc.tocsc(), rbc)) < U_TOL
