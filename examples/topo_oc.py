@@ -8,6 +8,7 @@ inner loop of BASELINE.json's configuration 5 can be run and timed:
 
     python examples/topo_oc.py --element_type quad --nx 512 --ny 256 --iters 30
     python examples/topo_oc.py --element_type block --nx 48 --ny 24 --nz 24 --iters 20
+    python examples/topo_oc.py --physics heat --nx 256 --ny 256 --iters 30        (topo_heat.py: LinearPoisson)
 """
 import argparse
 import os
@@ -78,6 +79,15 @@ def oc_update(x, g, a, con_now, move=0.2, lb=1e-3, ub=1.0):
 
 
 def build(args):
+    if args.physics == "heat":  # topo_heat.py:139-165 -- LinearPoisson, cold wall on the x = 0 edge, uniform heat source
+        creator = pyfem.ProblemCreator(args.nx + 1, args.ny + 1, element_type="quad")
+        quadrature = pyfem.QuadratureBilinear2D()
+        basis = pyfem.BasisBilinear2D(quadrature)
+        dof_fixed = [int(n) for n in creator.nodes3d[0, :, 0]]
+        model = pyfem.LinearPoisson(creator.X, creator.conn, dof_fixed, len(dof_fixed) * [0.0], quadrature, basis,
+                                    gfunc=lambda x: 1.0, p=args.p)
+        filtr = pyfem.Helmholtz(args.r0, creator.X, creator.conn, quadrature, basis)
+        return TopoProblem(model, filtr, args.volume)
     if args.element_type == "block":
         creator = pyfem.ProblemCreator(args.nx + 1, args.ny + 1, args.nz + 1, element_type="block")
         quadrature = pyfem.QuadratureBlock3D()
@@ -94,6 +104,8 @@ def build(args):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--physics", choices=["elasticity", "heat"], default="elasticity",
+                    help="elasticity: topo.py (compliance of a cantilever); heat: topo_heat.py (thermal compliance, 2-D quads)")
     ap.add_argument("--element_type", choices=["quad", "tri", "block"], default="quad")
     ap.add_argument("--nx", type=int, default=256)
     ap.add_argument("--ny", type=int, default=128)
@@ -118,7 +130,7 @@ def main(argv=None):
         history.append((obj, con, t3 - t0))
         print(f"iter {it:3d}  compliance {obj:.6e}  volume slack {con:+.3e}  {1e3 * (t3 - t0):7.1f} ms = objective "
               f"{1e3 * (t1 - t0):.1f} + gradient {1e3 * (t2 - t1):.1f} + update {1e3 * (t3 - t2):.1f}  "
-              f"(PCG iterations: elasticity {prob.model.last_iters}, filter {prob.filtr.last_iters})", flush=True)
+              f"(PCG iterations: state {prob.model.last_iters}, filter {prob.filtr.last_iters})", flush=True)
     return history
 
 

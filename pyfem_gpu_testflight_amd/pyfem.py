@@ -494,7 +494,9 @@ class LinearPoisson(ModelBase):
         K = self.compute_jacobian(rho)
         rhs = self.compute_rhs()
         K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
-        u = Assembler(self)._solve_linear_system(K, rhs, solver)
+        asm = Assembler(self)
+        u = asm._solve_linear_system(K, rhs, solver)
+        self.last_iters = asm.last_iters  # PCG iterations of this solve
         c = _vdot(rhs, u) if weighted else np.sum(u) / len(u)
         return c, u
 

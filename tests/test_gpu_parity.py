@@ -695,7 +695,8 @@ def test_refined_arm_mesh_matches_oracle(pf, orc):
 
 @pytest.mark.parametrize("argv", [["--element_type", "quad", "--nx", "96", "--ny", "48", "--iters", "6", "--r0", "0.04"],
                                   ["--element_type", "block", "--nx", "16", "--ny", "8", "--nz", "8", "--iters", "4",
-                                   "--r0", "0.1"]])
+                                   "--r0", "0.1"],
+                                  ["--physics", "heat", "--nx", "64", "--ny", "64", "--iters", "6", "--r0", "0.04"]])
 def test_topology_loop_example(argv):
     """examples/topo_oc.py: the reference's topology-optimisation callbacks (topo.py:50-75) around the GPU path
     with an optimality-criteria update; compliance must fall while the volume constraint is kept."""
