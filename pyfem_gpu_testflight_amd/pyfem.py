@@ -427,6 +427,7 @@ class LinearPoisson(ModelBase):
         self.kappa0 = kappa0
         self.p = float(p)
         self._last_rho = None
+        self._Xq = None
 
     def _rho_device(self, rho):
         torch = self.hctx.torch
@@ -442,7 +443,9 @@ class LinearPoisson(ModelBase):
     def compute_rhs(self):
         """ref: pyfem.py:997-1004, 1138-1173."""
         torch = self.hctx.torch
-        Xq = self.hctx.quad_points().cpu().numpy()
+        if self._Xq is None:  # quadrature-point coordinates: fixed with the mesh (the reference keeps them in self.Xq)
+            self._Xq = self.hctx.quad_points().cpu().numpy()
+        Xq = self._Xq
         # the reference assigns gfunc's result into an (nelems, nquads) array (pyfem.py:1126-1128), so a scalar or a
         # broadcastable result is fine (examples/heat_conduction.py passes `lambda x: source_temp`)
         self.fun_vals = np.empty(Xq.shape[:2])
