@@ -101,7 +101,8 @@ int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, co
                                   double* Kvals);
 int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* Rvals);
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
-                   const double* sm_dinv = nullptr, const double* sm_b = nullptr);  // smoother epilogues: pf_solve.hip
+                   const double* sm_dinv = nullptr, const double* sm_b = nullptr,  // smoother epilogues: pf_solve.hip
+                   const float* vals32 = nullptr);                                 // fp32 copy of vals to use instead
 void pf_amg_free(pf_ctx* ctx);
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse);   // PF_E_UNSUPPORTED: matrix not positive definite
 int pf_amg_apply(pf_ctx* ctx, const double* r, double* z);

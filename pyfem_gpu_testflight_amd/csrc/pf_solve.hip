@@ -89,10 +89,12 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 //   R = node rows per lane (tile = 64*R nodes), U = blocks per lane in flight, CH = LDS strip entries.
 //   d=1 moves a third of the bytes of d=2 per node, so it takes R=2 / U=6 to amortise the per-tile
 //   overhead (r01: 50 % of peak at R=1/U=3).
+//   VT = float reads an fp32 copy of the values (arithmetic stays fp64): the smoother sweeps of the AMG cycle, whose
+//   operator only has to be a fixed symmetric one.
 // ------------------------------------------------------------------------------------------
-template <int D, int R, int U, int CH, bool IDX16 = false>
+template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
-                                             const int32_t* __restrict__ nidx, const double* __restrict__ vals,
+                                             const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
                                              const double* __restrict__ sm_b) {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
         if constexpr (D == 1) {
           double kv[U], xv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) kv[u] = vals[g[u]];
+          for (int u = 0; u < U; ++u) kv[u] = (double)vals[g[u]];
 #pragma unroll
           for (int u = 0; u < U; ++u) xv[u] = x[m[u]];
 #pragma unroll
@@ -145,8 +147,14 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
           double2 k0[U], k1[U], xv[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            k0[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u]);
-            k1[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u] + 2);
+            if constexpr (sizeof(VT) == 8) {
+              k0[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u]);
+              k1[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u] + 2);
+            } else {  // fp32 copy of the operator (the AMG cycle's smoother): one 16-byte load per block
+              const float4 f = *reinterpret_cast<const float4*>(vals + 4 * (int64_t)g[u]);
+              k0[u] = make_double2((double)f.x, (double)f.y);
+              k1[u] = make_double2((double)f.z, (double)f.w);
+            }
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m[u]);
@@ -217,8 +225,9 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 // 3-vector product in the strip; lane-per-node sums its row.  One wave per block: LDS operations execute in
 // program order, so the staging needs no barrier.  Same epilogues as k_spmv.
 // ------------------------------------------------------------------------------------------
+template <typename VT>
 __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __restrict__ nptr,
-                                              const int32_t* __restrict__ nidx, const double* __restrict__ vals,
+                                              const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
                                               const double* __restrict__ x, double* __restrict__ y,
                                               double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
                                               const double* __restrict__ sm_b) {
@@ -249,10 +258,10 @@ __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __r
           nb[u] = (g0 + 64 * u < c1) ? min(64, c1 - gu) : 0;  // wave-uniform
           g[u] = min(gu + lane, c1 - 1);
           m[u] = nidx[g[u]];
-          const double* src = vals + 9 * (int64_t)gu;
+          const VT* src = vals + 9 * (int64_t)gu;
           const int32_t last = max(nb[u], 1) * 9 - 1;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) v[u][k] = src[min(k * 64 + lane, last)];
+          for (int k = 0; k < 9; ++k) v[u][k] = (double)src[min(k * 64 + lane, last)];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -605,9 +614,25 @@ static int ensure_idx16(pf_ctx* ctx) {
   return PF_OK;
 }
 
+// vals32 != nullptr: the product uses that fp32 copy of the values instead of vals (AMG smoother sweeps)
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
-                   const double* sm_dinv, const double* sm_b) {
+                   const double* sm_dinv, const double* sm_b, const float* vals32) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
+  if (vals32) {
+    if (ctx->d == 3) {
+      k_spmv3<float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals32, x, y, dot_part, sm_dinv, sm_b);
+    } else {
+      if (int rc16 = ensure_idx16(ctx)) return rc16;
+      const bool i16 = ctx->nidx16_state == 1;
+      const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
+      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b);
+      else if (ctx->d == 1) k_spmv<PF_SPMV1, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b);
+      else if (i16) k_spmv<PF_SPMV2, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b);
+      else k_spmv<PF_SPMV2, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b);
+    }
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
 #ifdef PF_SPMV_SWEEP
   const char* sh = getenv("PF_SPMV_SHAPE");
   const int shape = sh ? atoi(sh) : 0;
@@ -623,7 +648,7 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
 #undef PF_TRY
 #endif
   if (ctx->d == 3)
-    k_spmv3<<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
+    k_spmv3<double><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
   else if (ctx->d == 1) {
     if (int rc16 = ensure_idx16(ctx)) return rc16;
     if (ctx->nidx16_state == 1)
