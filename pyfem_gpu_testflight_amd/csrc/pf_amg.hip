@@ -41,7 +41,7 @@ struct AmgLevel {
   bool owns_graph = false;
   int64_t nblk = 0;
   double* vals = nullptr;    // block values (level 0: the caller's matrix, not owned)
-  float* vals32 = nullptr;   // level 0: fp32 copy for the smoother sweeps and the residual of the cycle (owned)
+  float* vals32 = nullptr;   // fp32 copy of vals for the products of the cycle (owned; nullptr with PF_AMG_FP32=0)
   double* dinv = nullptr;    // omega_1 / diag per dof (raw diagonal during the numeric setup)
   double* dinv2 = nullptr;   // omega_2 / diag: second factor of the two-step smoother
   uint8_t* iso = nullptr;    // 1 = decoupled dof (row has no off-diagonal entries)
@@ -549,9 +549,9 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_wave(int64_t nc, const int3
 //   AMG_SMOOTH y = x + dinv .* (b - A x)     (one damped-Jacobi sweep, y != x)
 //   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv2 .* (b - A x1)
 enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
-template <int D, int MODE>
+template <int D, int MODE, typename VT>
 __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
-                                                 const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                                                 const int32_t* __restrict__ idx, const VT* __restrict__ vals,
                                                  const double* __restrict__ x, double* __restrict__ y,
                                                  const double* __restrict__ dinv, const double* __restrict__ dinv2,
                                                  const double* __restrict__ b) {
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
       const int32_t c1 = min(end, c0 + CH);
       for (int32_t g = c0 + lane; g < c1; g += 64) {
         const int64_t m = idx[g];
-        const double* a = vals + (int64_t)g * D * D;
+        const VT* a = vals + (int64_t)g * D * D;  // VT = float: the fp32 copy of the coarse operator (cycle only)
         double xv[D];
 #pragma unroll
         for (int l = 0; l < D; ++l) xv[l] = (MODE == AMG_SMOOTH0) ? dinv[D * m + l] * b[D * m + l] : x[D * m + l];
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
         for (int k = 0; k < D; ++k) {
           double s = 0.0;
 #pragma unroll
-          for (int l = 0; l < D; ++l) s += a[k * D + l] * xv[l];
+          for (int l = 0; l < D; ++l) s += (double)a[k * D + l] * xv[l];
           prod[(g - c0) * D + k] = s;
         }
       }
@@ -1380,7 +1380,11 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
                           Lv.vals32);
   }
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
-#define PF_AS(D_, M_) k_amg_spmv<D_, M_><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b)
+#define PF_AS(D_, M_)                                                                                               \
+  do {                                                                                                              \
+    if (Lv.vals32) k_amg_spmv<D_, M_, float><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    else k_amg_spmv<D_, M_, double><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
+  } while (0)
 #define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
   if (mode == AMG_AX) PF_ASD(AMG_AX);
   else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
@@ -1454,12 +1458,13 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   // The cycle's finest-level operator in fp32 (PF_AMG_FP32=0 keeps fp64): the preconditioner only has to be a fixed
   // symmetric positive definite operator, which the V-cycle of the rounded matrix is as well -- all arithmetic and all
   // vectors stay fp64, PCG's own product uses the fp64 matrix.  Five of the six fine SpMVs per iteration then read
-  // 18 instead of 34 bytes per 2x2 block (40 instead of 76 per 3x3 block).
+  // 18 instead of 34 bytes per 2x2 block (40 instead of 76 per 3x3 block); the coarse operators get the same copy.
+  const char* fp32_env = getenv("PF_AMG_FP32");
+  const bool fp32 = !(fp32_env && atoi(fp32_env) == 0);
   {
-    const char* e = getenv("PF_AMG_FP32");
     AmgLevel& L0 = H->L[0];
     const int64_t nv = L0.nblk * L0.dr * L0.dr;
-    if (e && atoi(e) == 0) {
+    if (!fp32) {
       pf_free(L0.vals32);
     } else {
       if (!L0.vals32) PF_HIP(hipMalloc(&L0.vals32, sizeof(float) * (size_t)nv));
@@ -1532,6 +1537,13 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 #undef PF_GAL
       }
       PF_LAUNCH_CHECK();
+      const int64_t nvc = Nx.nblk * Nx.dr * Nx.dr;
+      if (fp32) {
+        if (!Nx.vals32) PF_HIP(hipMalloc(&Nx.vals32, sizeof(float) * (size_t)std::max<int64_t>(nvc, 1)));
+        k_amg_to_f32<<<(unsigned)std::min<int64_t>(cdiv(nvc, 256), 8192), 256, 0, ctx->stream>>>(nvc, Nx.vals, Nx.vals32);
+      } else {
+        pf_free(Nx.vals32);
+      }
     }
     k_amg_scale_dinv<<<(unsigned)cdiv(ndof, 256), 256, 0, ctx->stream>>>(ndof, H->lam + l, H->omega_scale,
                                                                          H->nsmooth == 2 ? H->cheb : 0.0, Lv.dinv, Lv.dinv2, Lv.iso);
