@@ -40,6 +40,7 @@ struct AmgLevel {
   int32_t* idx = nullptr;
   bool owns_graph = false;
   int64_t nblk = 0;
+  int max_row = 0;           // longest row of the node graph
   double* vals = nullptr;    // block values (level 0: the caller's matrix, not owned)
   float* vals32 = nullptr;   // fp32 copy of vals for the products of the cycle (owned; nullptr with PF_AMG_FP32=0)
   double* dinv = nullptr;    // omega_1 / diag per dof (raw diagonal during the numeric setup)
@@ -760,7 +761,7 @@ __global__ void k_sa_galerkin(int64_t nc, const int32_t* __restrict__ tptr, cons
 }
 
 // The same product with one WAVE per coarse row (rows of at most 64 couplings): lanes split the (n, m) pairs --
-// four entries of the column of I times sixteen neighbour slots per pass -- and add their DC x DC contributions
+// E entries of the column of I times G neighbour slots per pass -- and add their DC x DC contributions
 // into an LDS image of the row with LDS atomics; the row is then written out once.  NW waves share a row (its
 // column entries dealt round-robin) on levels with few, long columns: 1331 coarse rows of ~200 entries each on the
 // second level of 96^3 blocks kept one wave per row busy for 7 ms.  The lane-per-row kernel above
@@ -775,19 +776,23 @@ __global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const 
                                                          const int32_t* __restrict__ pidx,
                                                          const double* __restrict__ pvals,
                                                          const int32_t* __restrict__ cptr,
-                                                         const int32_t* __restrict__ cidx, double* __restrict__ cvals) {
+                                                         const int32_t* __restrict__ cidx, double* __restrict__ cvals,
+                                                         int G) {
+  // G neighbour slots per column entry (the fine level's longest row, at most 32), E = 64 / G entries per pass: 9 x 7
+  // on quads instead of a fixed 16 x 4 takes the 25 entries of a column in 4 passes instead of 7
   __shared__ int32_t crow[64];
   __shared__ double cacc[64 * DC * DC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int E = 64 / G, es = lane / G, gs = lane - es * G;
   for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
     const int32_t cb = cptr[I], clen = cptr[I + 1] - cb;
     if ((int)threadIdx.x < clen) crow[threadIdx.x] = cidx[cb + threadIdx.x];
     for (int q = threadIdx.x; q < clen * DC * DC; q += 64 * NW) cacc[q] = 0.0;
     __syncthreads();
     const int32_t tb = tptr[I], te = tptr[I + 1];
-    for (int32_t e0 = tb + 4 * wave; e0 < te; e0 += 4 * NW) {
-      const int32_t e = e0 + (lane >> 4);
-      const bool eok = e < te;
+    for (int32_t e0 = tb + E * wave; e0 < te; e0 += E * NW) {
+      const int32_t e = e0 + es;
+      const bool eok = es < E && e < te;
       const int64_t n = eok ? tnode[e] : 0;
       const int32_t rb = eok ? ptr[n] : 0, rl = eok ? ptr[n + 1] - rb : 0;
       double pn[DR][DC];
@@ -798,10 +803,9 @@ __global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const 
 #pragma unroll
           for (int c = 0; c < DC; ++c) pn[r][c] = Pn[r * DC + c];
       }
-      const int32_t rlmax = max(max(__shfl(rl, 0), __shfl(rl, 16)), max(__shfl(rl, 32), __shfl(rl, 48)));
-      for (int32_t g0 = 0; g0 < rlmax; g0 += 16) {
-        const int32_t go = g0 + (lane & 15);
-        if (eok && go < rl) {
+      for (int32_t g0 = 0; g0 < rl; g0 += G) {  // rl = 0 for idle lanes
+        const int32_t go = g0 + gs;
+        if (go < rl) {
           const int32_t g = rb + go;
           const int64_t m = idx[g];
           const double* av = vals + (int64_t)g * DR * DR;
@@ -1282,6 +1286,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   PF_HIP(hipStreamSynchronize(ctx->stream));
   H->L[0].n = n; H->L[0].dr = d0; H->L[0].ptr = ctx->nptr; H->L[0].idx = ctx->nidx; H->L[0].nblk = ctx->nblocks;
   H->L[0].xy = ctx->X;
+  H->L[0].max_row = ctx->max_row_blocks;
   int l = 0;
   while (true) {
     AmgLevel& Lv = H->L[l];
@@ -1336,6 +1341,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     }
     Lv.max_crow = 0;
     for (int64_t I = 0; I < nc; ++I) Lv.max_crow = std::max(Lv.max_crow, cptr[I + 1] - cptr[I]);
+    H->L[l + 1].max_row = Lv.max_crow;
     if (rc == PF_OK && !Lv.agg) rc = to_device(ctx, agg, Lv.agg);
     if (rc == PF_OK) rc = to_device(ctx, aptr, Lv.aptr);
     if (rc == PF_OK) rc = to_device(ctx, amem, Lv.amem);
@@ -1497,13 +1503,14 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
                                                                    Nx.xy, Lv.dinv, H->lam + l, Lv.pptr, Lv.pidx, Lv.pvals)
 #define PF_SAG(DR_, DC_)                                                                                         \
         do {                                                                                                     \
+          const int gw_ = std::max(4, std::min(32, Lv.max_row));                                                 \
           if (Lv.max_crow <= 64) {                                                                               \
             if (Lv.np >= 48 * Lv.nc)                                                                             \
               k_sa_galerkin_wave<DR_, DC_, 4><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 256, 0, ctx->stream>>>( \
-                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals, gw_); \
             else                                                                                                 \
               k_sa_galerkin_wave<DR_, DC_, 1><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 64, 0, ctx->stream>>>( \
-                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
+                  Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals, gw_); \
             k_sa_mirror_lower<DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Nx.ptr, Nx.idx, Nx.vals);                  \
           } else                                                                                                   \
             k_sa_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, \
