@@ -245,7 +245,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_assemble_v3<4,Elasticity<4,false>>", "achieved": asm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
                      "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms},
-        "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
+        "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true,double>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
                           "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
                           "note": "algorithmic bytes are CSR's 12 B per scalar nonzero (SURVEY 8d); the 2x2-block layout "
