@@ -338,8 +338,23 @@ class BinCoarseSpace:
         return self
 
 
+def schwarz_prepare(ops, K, iface):
+    """Numeric AMG setup of this rank's block for dist_pcg_schwarz: the local matrix with a tenth of the missing part of
+    its interface diagonals added (assembled minus local value), which pins floating pieces and costs compact
+    partitions nothing (tools/dist_schwarz_rehearsal.py: 0.01 .. 0.1 give the same counts, 1.0 twice as many, 0 fails
+    on floating pieces).  Returns the shifted copy (it must stay alive while the hierarchy is in use)."""
+    import os
+
+    dloc = ops.diag(K)
+    dsum = iface.sum(dloc.clone())
+    Kp = K.clone()
+    ops.add_to_diag(Kp, (dsum - dloc) * float(os.environ.get("PF_SCHWARZ_EPS", "0.1")))
+    ops.amg_prepare(Kp)
+    return Kp
+
+
 def dist_pcg_schwarz(ops, K, b, inv_mult, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, check_every=1,
-                     coarse=None):
+                     coarse=None, prepared=False):
     """PCG over ranks with a one-level additive Schwarz preconditioner whose subdomain solves are the LOCAL AMG
     V-cycles:  M^-1 = sum_i R_i^T D A_i~^-1 D R_i,  D = 1/multiplicity on interface dofs (symmetric, so CG applies),
     A_i~^-1 = one V-cycle on rank i's block with a fraction of the missing part of its interface DIAGONALS added
@@ -354,6 +369,7 @@ def dist_pcg_schwarz(ops, K, b, inv_mult, own_w, iface, rtol=1e-8, atol=0.0, max
     Scalars stay on the device; the residual is read back every `check_every` iterations.  x0 = 0.
     coarse: a BinCoarseSpace -- adds the global correction Z E^+ Z^T (two-level method); its Z^T (K p) rides along
     with all-reduce 1, so the number of collectives per iteration stays two.
+    prepared: schwarz_prepare was already called for this matrix on ops' context (constant matrices: the filter).
     Returns (x_local, iters, relres); raises RuntimeError("cg failed with code <iters>") at maxiter."""
     torch = ops.torch
     n, G = ops.n, iface.G
@@ -363,16 +379,7 @@ def dist_pcg_schwarz(ops, K, b, inv_mult, own_w, iface, rtol=1e-8, atol=0.0, max
     ctail = buf[G + 3:]  # and the coarse-space moments of the un-summed product
     if hasattr(ops, "begin"):
         ops.begin()
-    dloc = ops.diag(K)
-    dsum = iface.sum(dloc.clone())
-    Kp = K.clone()
-    import os
-
-    # a tenth of the missing diagonal is enough to pin floating pieces and costs compact partitions nothing
-    # (tools/dist_schwarz_rehearsal.py: 0.01 .. 0.1 give the same counts, 1.0 twice as many, 0 fails on floating pieces)
-    eps = float(os.environ.get("PF_SCHWARZ_EPS", "0.1"))
-    ops.add_to_diag(Kp, (dsum - dloc) * eps)
-    ops.amg_prepare(Kp)
+    Kp = None if prepared else schwarz_prepare(ops, K, iface)  # prepared: the caller did it for this (constant) matrix
     x, r = ops.zeros(n), b.clone()
     w, z, zl, rs = ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
     cr = None
@@ -437,8 +444,80 @@ def dist_pcg_schwarz(ops, K, b, inv_mult, own_w, iface, rtol=1e-8, atol=0.0, max
 
 
 # ------------------------------------------------------------------------------------------
-# the model-level wrapper
+# the model-level wrappers
 # ------------------------------------------------------------------------------------------
+class _NodeView:
+    """The interface of an ElementBlockPartition seen per node instead of per dof."""
+
+    def __init__(self, part):
+        d = part.d
+        self.n_iface_dofs = part.n_iface_dofs // d
+        self.iface_local_dofs = (part.iface_local_dofs[::d] // d).astype(np.int32)
+        self.iface_slots = (part.iface_slots[::d] // d).astype(np.int32)
+
+
+class PartitionedHelmholtz:
+    """The Helmholtz filter (pyfem.py:2071-2177) over the same element-block partition as the model it serves:
+    K = r0^2 A + M and R = M assembled from the rank's elements, `apply` / `apply_gradient` as distributed PCG solves
+    (additive Schwarz with the local AMG cycle).  Inputs and outputs are this rank's nodal values (device tensors,
+    consistent on shared nodes)."""
+
+    def __init__(self, r0, X, conn, quadrature, basis, group=None, rank=None, world=None, device=None, elem_order="index"):
+        import torch.distributed as dist
+
+        from . import pyfem
+
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.group, self.rank, self.world = group, rank, world
+        X = np.asarray(X, dtype=float)
+        self.nnodes_global = X.shape[0]
+        perm = centroid_element_order(X, conn) if elem_order == "centroid" else None
+        self.part = ElementBlockPartition(conn, X.shape[0], world, rank, 1, elem_perm=perm)
+        pt = self.part
+        self.model = pyfem.Helmholtz(r0, X[pt.nodes], pt.conn_local, quadrature, basis, device=device)
+        self.ops = HipLocalOps(self.model.hctx)
+        self.iface = Interface(self.ops, pt, group)
+        torch = self.ops.torch
+        self.own_w = self.ops.from_numpy(pt.own_weight, torch.float64)
+        self.inv_mult = self.ops.from_numpy(1.0 / pt.multiplicity, torch.float64)
+        self.rtol = 1e-10
+        self.last_iters = None
+        self._Kp = schwarz_prepare(self.ops, self.model.K.vals, self.iface)  # the filter matrix never changes
+
+    def _solve(self, b):
+        x, it, rr = dist_pcg_schwarz(self.ops, self.model.K.vals, b, self.inv_mult, self.own_w, self.iface, rtol=self.rtol,
+                                     prepared=True)
+        self.last_iters = it
+        return x
+
+    def apply(self, x_local):
+        """rho = K^-1 R x (pyfem.py:2102-2107)."""
+        rhs = self.ops.zeros(self.ops.n)
+        self.ops.spmv(self.model.R.vals, x_local, rhs)
+        return self._solve(self.iface.sum(rhs))
+
+    def apply_gradient(self, g_local):
+        """R^T K^-1 g (pyfem.py:2110-2115); g consistent on shared nodes."""
+        y = self._solve(g_local.clone())
+        out = self.ops.zeros(self.ops.n)
+        self.ops.spmv(self.model.R.vals, y, out)
+        return self.iface.sum(out)
+
+    def local_nodal(self, v_global):
+        return self.ops.from_numpy(np.asarray(v_global, dtype=float)[self.part.nodes], self.ops.torch.float64)
+
+    def gather_nodal(self, v_local):
+        """Global nodal vector on every rank (one all-reduce of nnodes values)."""
+        torch = self.ops.torch
+        out = torch.zeros(self.nnodes_global, dtype=torch.float64, device=v_local.device)
+        out[self.ops.from_numpy(self.part.nodes, torch.int64)] = v_local * self.own_w
+        _all_reduce(out, self.group)
+        return out
+
+
+
 class PartitionedElasticity:
     """LinearElasticity (pyfem.py:1667-2068) over an element-block partition.
 
@@ -482,6 +561,8 @@ class PartitionedElasticity:
         torch = self.ops.torch
         self.own_w = self.ops.from_numpy(pt.own_weight, torch.float64)
         self.inv_mult = self.ops.from_numpy(1.0 / pt.multiplicity, torch.float64)
+        self._own_nodes = self.ops.from_numpy(pt.owned_mask_nodes.astype(np.float64), torch.float64)
+        self._niface = None
         self.last_iters = None
 
     @property
@@ -533,6 +614,61 @@ class PartitionedElasticity:
                             check_every=check_every)
         self.last_iters, self.last_relres = it, rr
         return x
+
+    # -- topology-optimisation callbacks over the partition (BASELINE configuration 5; pyfem.py:1798-1870) ------------
+    def _node_iface(self):
+        """Interface sums of NODAL vectors (densities, sensitivities): the dof interface reduced to one slot per node."""
+        if self._niface is None:
+            self._niface = Interface(self.ops, _NodeView(self.part), self.group)
+        return self._niface
+
+    def local_nodal(self, v_global):
+        """This rank's entries of a global nodal vector, as a device tensor."""
+        return self.ops.from_numpy(np.asarray(v_global, dtype=float)[self.part.nodes], self.ops.torch.float64)
+
+    def compliance(self, rho, precond="amg", rtol=1e-10):
+        """(c, u_local): c = f.u summed over the owned dofs of every rank (one scalar all-reduce); rho is the global
+        nodal density (numpy) or this rank's part (device tensor)."""
+        torch = self.ops.torch
+        if isinstance(rho, torch.Tensor):
+            self._rho_local = rho
+            K = self.model.compute_jacobian(rho)
+        else:
+            self._rho_local = None
+            K = self.compute_jacobian(rho)
+        rhs = self.ops.from_numpy(self.model.compute_rhs(), torch.float64)
+        K, b = self.apply_dirichlet_bcs(K, rhs)
+        if precond == "jacobi":
+            dinv = 1.0 / self.iface.sum(self.ops.diag(K.vals))
+            u, it, rr = dist_cg(self.ops, K.vals, b, dinv, self.own_w, self.iface, rtol=rtol)
+        else:
+            u, it, rr = dist_pcg_schwarz(self.ops, K.vals, b, self.inv_mult, self.own_w, self.iface, rtol=rtol)
+        self.last_iters, self.last_relres = it, rr
+        c = torch.dot(b * self.own_w, u).reshape(1)
+        _all_reduce(c, self.group)
+        return float(c.item()), u
+
+    def compliance_grad(self, rho, u_local):
+        """-d(u^T K u)/d rho on this rank's nodes (pyfem.py:1837-1848): sensitivities of the local elements, summed over
+        the ranks that share a node.  rho as in compliance(); returns a device tensor over the local nodes."""
+        torch = self.ops.torch
+        rho_l = rho if isinstance(rho, torch.Tensor) else self.local_nodal(rho)
+        g = -self.model._compute_K_dv_sens(rho_l, u_local, u_local)
+        return self._node_iface().sum(g)
+
+    def volume(self, rho_local):
+        """rho.sum() / nnodes over the whole mesh (pyfem.py:1851-1859) from this rank's nodes: one scalar all-reduce."""
+        v = (rho_local * self._own_nodes).sum().reshape(1)
+        _all_reduce(v, self.group)
+        return float(v.item()) / self.nnodes_global
+
+    def gather_nodal(self, v_local):
+        """Global nodal vector on every rank from consistent local ones (one all-reduce of nnodes values)."""
+        torch = self.ops.torch
+        out = torch.zeros(self.nnodes_global, dtype=torch.float64, device=v_local.device)
+        out[self.ops.from_numpy(self.part.nodes, torch.int64)] = v_local * self._own_nodes
+        _all_reduce(out, self.group)
+        return out
 
     def gather_global(self, x_local):
         """Global vector on every rank (tests / small problems)."""

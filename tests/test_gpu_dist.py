@@ -104,3 +104,87 @@ def test_partitioned_two_ranks_one_gpu(etype):
     import torch.multiprocessing as mp
 
     mp.spawn(_worker, args=(2, _free_port(), etype), nprocs=2, join=True)
+
+
+def _worker_topo(rank, world, port):
+    """BASELINE configuration 5 over a partition: filter -> compliance -> compliance gradient -> gradient filter, each
+    against the single-context models on the whole mesh."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyfem_gpu_testflight_amd import pyfem
+        from pyfem_gpu_testflight_amd.dist import PartitionedElasticity, PartitionedHelmholtz
+
+        conn, X, dof_fixed, force, q, b = _setup("quad")
+        rng = np.random.RandomState(3)
+        x = 0.2 + 0.8 * rng.rand(X.shape[0])
+        # single-context reference
+        filt = pyfem.Helmholtz(0.08, X, conn, q, b)
+        model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+        rho_ref = filt.apply(x)
+        c_ref, u_ref = model.compliance(rho_ref)
+        g_ref = model.compliance_grad(rho_ref, u_ref)
+        gx_ref = filt.apply_gradient(g_ref)
+        # partitioned
+        pf_ = PartitionedHelmholtz(0.08, X, conn, q, b)
+        pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0)
+        assert np.array_equal(pf_.part.nodes, pm.part.nodes)  # same element blocks, same local nodes
+        rho_l = pf_.apply(pf_.local_nodal(x))
+        rho = pf_.gather_nodal(rho_l).cpu().numpy()
+        assert np.abs(rho - rho_ref).max() < 1e-8 * np.abs(rho_ref).max()
+        c, u_l = pm.compliance(rho_l)
+        assert abs(c / c_ref - 1) < 1e-8
+        u = pm.gather_global(u_l).cpu().numpy()
+        assert np.abs(u - u_ref).max() < 1e-8 * np.abs(u_ref).max()
+        g_l = pm.compliance_grad(rho_l, u_l)
+        g = pm.gather_nodal(g_l).cpu().numpy()
+        assert np.abs(g - g_ref).max() < 1e-7 * np.abs(g_ref).max()
+        gx = pf_.gather_nodal(pf_.apply_gradient(g_l)).cpu().numpy()
+        assert np.abs(gx - gx_ref).max() < 1e-7 * np.abs(gx_ref).max()
+        assert abs(pm.volume(rho_l) - rho_ref.sum() / X.shape[0]) < 1e-12
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_topology_callbacks_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_topo, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_loop(rank, world, port, out):
+    import importlib.util
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PF_BENCH_BACKEND="gloo", PF_BENCH_DEVICE="0")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "topo_oc_dist.py")
+    spec = importlib.util.spec_from_file_location("topo_oc_dist", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--nx", "96", "--ny", "48", "--iters", "5", "--r0", "0.04"])
+    if rank == 0:
+        np.save(out, np.array([h[:2] for h in hist]))
+
+
+def test_distributed_topology_loop_follows_the_single_gpu_one(tmp_path):
+    """examples/topo_oc_dist.py on two ranks against examples/topo_oc.py in this process: same callbacks, same update,
+    so the compliance history must agree to solver tolerance."""
+    import importlib.util
+
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "hist.npy")
+    mp.spawn(_worker_loop, args=(2, _free_port(), out), nprocs=2, join=True)
+    dist_hist = np.load(out)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "topo_oc.py")
+    spec = importlib.util.spec_from_file_location("topo_oc", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = np.array([h[:2] for h in mod.main(["--nx", "96", "--ny", "48", "--iters", "5", "--r0", "0.04"])])
+    assert np.abs(dist_hist[:, 0] / hist[:, 0] - 1).max() < 1e-6
+    assert hist[-1, 0] < 0.8 * hist[0, 0]
