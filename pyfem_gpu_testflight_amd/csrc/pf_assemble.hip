@@ -972,7 +972,10 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
   {  // default: v3
     const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
-    const int per_lane = (int)cdiv((int64_t)ctx->npt * ctx->max_row_blocks * (Phys::V == 4 ? 2 : 1), 64);
+    // stores per lane of the copy-out: from the largest tile the greedy pass actually made (tiles stop at 64 incident
+    // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
+    const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
+    const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
     const char* ab = getenv("PF_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
     auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;

@@ -541,6 +541,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     std::vector<int32_t> desc;
     desc.reserve(4 * (size_t)(nn / ctx->npt + 16));
     std::vector<uint8_t> slot(nn);
+    ctx->max_tile_blocks = 0;
     const bool fixed = getenv("PF_TILE_FIXED") != nullptr;  // ablation: npt nodes per tile, no alignment search
     for (int64_t n0 = 0; n0 < nn;) {
       int64_t emax = std::min<int64_t>(n0 + ctx->npt, nn);
@@ -553,6 +554,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
           if (score > best) { best = score; e = c; }
         }
       }
+      ctx->max_tile_blocks = std::max(ctx->max_tile_blocks, hp[e] - hp[n0]);
       for (int64_t n = n0; n < e; ++n) slot[n] = (uint8_t)(n - n0);
       desc.push_back((int32_t)n0);
       desc.push_back(hv[n0]);
