@@ -901,6 +901,15 @@ def test_contexts_release_their_device_memory(pf):
         conn3, X3, fix3, force3 = c3.create_linear_elasticity_problem()
         q3, b3 = _qb(pf, "block")
         pf.Assembler(pf.LinearElasticity(X3, conn3, fix3, None, force3, q3, b3)).solve(method="cg")
+        # table-driven elements (colour tables, fp32 copies of the AMG operators) and the nonsymmetric / Newton path
+        ct = pf.ProblemCreator(7, 5, 5, element_type="tet")
+        connt, Xt, fixt, forcet = ct.create_linear_elasticity_problem()
+        qt = pf.QuadratureTetrahedron5Point()
+        pf.Assembler(pf.LinearElasticity(Xt, connt, fixt, None, forcet, qt, pf.BasisTetrahedron10node(qt))).solve(method="cg")
+        cn = pf.ProblemCreator(24 + k % 3, 24)
+        connn, Xn, fixn = cn.create_poisson_problem()
+        pf.Assembler(pf.NonlinearPoisson2D(Xn, connn, fixn, None, q, b)).solve_nonlinear(method="gmres", xdv=np.ones(6) / 6)
+        m.compute_jacobian(np.ones(X.shape[0]) * (0.5 + 0.1j))
         return float(np.abs(u).max())
 
     one(0)
