@@ -1,7 +1,7 @@
 /*
  * pyfem_hip.h -- C ABI of libpyfem_hip.so, the MI355X (gfx950) implementation of the
  * pyfem hot path: per-element Ke quadrature -> global sparse scatter -> Dirichlet BCs ->
- * CSR SpMV / Jacobi-PCG.
+ * CSR SpMV / PCG (Jacobi or smoothed-aggregation AMG V-cycle).
  *
  * The reference (aaronyicongfu/pyfem_gpu_testflight) is pure Python and has no FFI; each
  * entry point below names the reference method(s) it replaces (file:line relative to the

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyfem_hip.so")
+# PF_LIB_PATH: tools/ point this at libpyfem_hip_exp.so (the -DPF_EXPERIMENTS build with the ablation / tuning knobs)
+LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpyfem_hip.so")
 
 PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1

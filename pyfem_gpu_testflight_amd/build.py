@@ -2,6 +2,9 @@
 
     python -m pyfem_gpu_testflight_amd.build          # incremental
     python -m pyfem_gpu_testflight_amd.build --force
+    python -m pyfem_gpu_testflight_amd.build --experiments   # libpyfem_hip_exp.so with -DPF_EXPERIMENTS for tools/:
+                                                              # the ablation / tuning knobs exist only there
+                                                              # (select it with PF_LIB_PATH=<path> before importing)
 """
 import os
 import shutil
@@ -14,7 +17,8 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libpyfem_hip.so")
 SOURCES = ["pf_pattern.hip", "pf_assemble.hip", "pf_assemble3d.hip", "pf_tabular.hip", "pf_solve.hip", "pf_amg.hip"]
-FLAGS = (["-DPF_SPMV_SWEEP"] if os.environ.get("PF_SPMV_SWEEP") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
+LIB_EXP = os.path.join(PKG, "libpyfem_hip_exp.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
 
@@ -32,9 +36,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, experiments=False):
     hipcc = _hipcc()
-    objdir = os.path.join(PKG, "build")
+    objdir = os.path.join(PKG, "build_exp" if experiments else "build")
+    flags = FLAGS + (["-DPF_EXPERIMENTS", "-DPF_SPMV_SWEEP"] if experiments else [])
+    lib = LIB_EXP if experiments else LIB
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "pf_common.h"), os.path.join(INC, "pyfem_hip.h")]
     objs = []
@@ -43,17 +49,17 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-I", INC, "-I", CSRC, "-c", src, "-o", obj]
+            cmd = [hipcc] + flags + ["-I", INC, "-I", CSRC, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

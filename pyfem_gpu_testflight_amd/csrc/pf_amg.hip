@@ -193,8 +193,9 @@ static void coarse_graph_host(int64_t n, const std::vector<int32_t>& ptr, const 
 // Pattern of the smoothed prolongator and of the Galerkin product built with it (graph only, host):
 //   row n of P couples to the aggregates of n and of its neighbours;  P^T A P couples I and J when some n in a
 //   column of I has a neighbour m whose row of P contains J.
+static thread_local int t_host_threads = 0;  // pf_ctx::host_threads of the hierarchy being built (PF_HOST_THREADS at pf_ctx_create)
 static int host_threads() {
-  if (const char* e = getenv("PF_HOST_THREADS")) return std::max(1, atoi(e));
+  if (t_host_threads > 0) return t_host_threads;
   return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));  // GPU boxes grant ~16 CPUs per GPU
 }
 
@@ -1271,10 +1272,11 @@ static int to_device(pf_ctx* ctx, const std::vector<T>& h, T*& d) {
 static int amg_build_hierarchy(pf_ctx* ctx) {
   pf_amg* H = new pf_amg();
   ctx->amg = H;
+  t_host_threads = ctx->host_threads;
   const int d0 = ctx->d;
   H->dim = (ctx->ndims == 3 && d0 == 3) ? 3 : 2;
   const int dc = (d0 == 1) ? 1 : (H->dim == 3) ? 6 : 3;
-  if (const char* e = getenv("PF_AMG_SA")) H->sa_mode = atoi(e);
+  if (const char* e = pf_exp_env("PF_AMG_SA")) H->sa_mode = atoi(e);
   std::vector<int32_t> ptr(ctx->nnodes + 1), idx(ctx->nblocks);
   PF_HIP(hipMemcpyAsync(ptr.data(), ctx->nptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipMemcpyAsync(idx.data(), ctx->nidx, idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1304,7 +1306,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
     if (last) break;
     std::vector<int32_t> agg, aptr, amem, cptr, cidx;
     int64_t nc = 0;
-    const bool verbose = getenv("PF_AMG_VERBOSE") != nullptr;
+    const bool verbose = ctx->amg_verbose;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
     aggregate_host(n, ptr, idx, xy, xdim, agg, nc);
@@ -1321,7 +1323,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
       const double t_c = now();
       rc = to_device(ctx, agg, Lv.agg);
       if (rc) return rc;
-      rc = getenv("PF_AMG_HOST_PATTERNS") ? PF_E_UNSUPPORTED
+      rc = pf_exp_env("PF_AMG_HOST_PATTERNS") ? PF_E_UNSUPPORTED
                                           : sa_pattern_device(ctx, Lv, n, Lv.ptr, Lv.idx, nc, dptr_c, didx_c, cptr, cidx);
       if (rc == PF_E_UNSUPPORTED) {  // a row beyond the device kernels' local arrays: same patterns on host threads
         std::vector<int32_t> pptr, pidx, tptr, tnode, tslot;
@@ -1456,16 +1458,16 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (reuse && H->numeric_ok && H->L[0].vals == vals) return PF_OK;
   H->numeric_ok = false;
   H->L[0].vals = const_cast<double*>(vals);
-  if (const char* e = getenv("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
-  if (const char* e = getenv("PF_AMG_OVER")) H->over = atof(e);
-  if (const char* e = getenv("PF_AMG_OVER_SA")) H->over_sa = atof(e);
-  if (const char* e = getenv("PF_AMG_CHEB")) H->cheb = atof(e);
-  if (const char* e = getenv("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
+  if (const char* e = pf_exp_env("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
+  if (const char* e = pf_exp_env("PF_AMG_OVER")) H->over = atof(e);
+  if (const char* e = pf_exp_env("PF_AMG_OVER_SA")) H->over_sa = atof(e);
+  if (const char* e = pf_exp_env("PF_AMG_CHEB")) H->cheb = atof(e);
+  if (const char* e = pf_exp_env("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
   // The cycle's finest-level operator in fp32 (PF_AMG_FP32=0 keeps fp64): the preconditioner only has to be a fixed
   // symmetric positive definite operator, which the V-cycle of the rounded matrix is as well -- all arithmetic and all
   // vectors stay fp64, PCG's own product uses the fp64 matrix.  Five of the six fine SpMVs per iteration then read
   // 18 instead of 34 bytes per 2x2 block (40 instead of 76 per 3x3 block); the coarse operators get the same copy.
-  const char* fp32_env = getenv("PF_AMG_FP32");
+  const char* fp32_env = pf_exp_env("PF_AMG_FP32");
   const bool fp32 = !(fp32_env && atoi(fp32_env) == 0);
   {
     AmgLevel& L0 = H->L[0];
@@ -1569,7 +1571,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   double h[AMG_MAX_LEVELS + 3];
   PF_HIP(hipMemcpyAsync(h, H->lam, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PF_HIP(hipStreamSynchronize(ctx->stream));
-  if (getenv("PF_AMG_VERBOSE")) {
+  if (ctx->amg_verbose) {
     fprintf(stderr, "[pf_amg] numeric setup: non-positive / positive diagonal seen %g / %g, lambda_max^2 per level:",
             h[AMG_MAX_LEVELS], h[AMG_MAX_LEVELS + 2]);
     for (int l = 0; l < H->nlevels; ++l) fprintf(stderr, " %g", h[l]);

@@ -938,11 +938,12 @@ static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* o
   auto kern = k_assemble_gather<P, Phys, RHO, GATHER_NW>;
   int nw = GATHER_NW;
   if constexpr (P == 4 && Phys::V == 4 && !RHO) {
-    const char* e = getenv("PF_GATHER_NW");
-    const char* ab = getenv("PF_ABLATE");
+    const char* e = pf_exp_env("PF_GATHER_NW");
+    const char* ab = pf_exp_env("PF_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
     if (e) nw = atoi(e);
     if (nw != 1 && nw != 4) nw = 2;
+#ifdef PF_EXPERIMENTS
 #define PF_PICK(NWV)                                                          \
     if (nw == NWV) {                                                          \
       if (abl == 1) kern = k_assemble_gather<P, Phys, RHO, NWV, 1>;           \
@@ -952,6 +953,9 @@ static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* o
     }
     PF_PICK(1) PF_PICK(2) PF_PICK(4)
 #undef PF_PICK
+#else
+    (void)abl;
+#endif
   }
   if (lds > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -963,12 +967,13 @@ static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* o
   return PF_OK;
 }
 
-// Timing experiments only:  PF_GATHER_IMPL=legacy selects the first-generation kernel
-// (PF_GATHER_NW=1|2|4 waves per tile);  PF_ABLATE=<bits> (1 no quadrature, 4 no write-out) produces
-// deliberately wrong results for phase-cost measurements (quad elasticity without density only).
+// Timing experiments (builds with -DPF_EXPERIMENTS only; the product library never reads these):
+// PF_GATHER_IMPL=legacy selects the first-generation kernel (PF_GATHER_NW=1|2|4 waves per tile);
+// PF_ABLATE=<bits> (1 no quadrature, 4 no write-out) produces deliberately wrong results for phase-cost
+// measurements (quad elasticity without density only).
 template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
-  const char* impl = getenv("PF_GATHER_IMPL");
+  const char* impl = pf_exp_env("PF_GATHER_IMPL");
   if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
   {  // default: v3
     const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
@@ -976,14 +981,16 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
     const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
     const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
-    const char* ab = getenv("PF_ABLATE");
+    const char* ab = pf_exp_env("PF_ABLATE");
     const int abl = ab ? atoi(ab) : 0;
+    (void)abl;
     auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;
     const bool both = (Phys::V == 4) || (out0 && (out1 || Phys::V == 1));
     if (per_lane <= 3 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 3, 0>;
     } else if (per_lane <= 5 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 5, 0>;
+#ifdef PF_EXPERIMENTS
       if constexpr (P == 4 && Phys::V == 4 && !RHO) {
         if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 5, 1>;
         else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 5, 4>;
@@ -996,6 +1003,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
         else if (abl == 25) k3 = k_assemble_v3<P, Phys, RHO, 5, 25>;
         else if (abl == 29) k3 = k_assemble_v3<P, Phys, RHO, 5, 29>;
       }
+#endif
     } else if (per_lane <= 10 && both) {
       k3 = k_assemble_v3<P, Phys, RHO, 10, 0>;
     }
@@ -1003,11 +1011,11 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
       PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     const int64_t nt = ctx->ntiles;
     int wpc = 24;  // persistent waves per CU (tools/abl_v3.py sweep: 24-32 best)
-    const char* g3 = getenv("PF_GATHER_WAVES_PER_CU");
+    const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
     if (g3 && atoi(g3) > 0) wpc = atoi(g3);
     const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
     // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
-    const char* to = getenv("PF_TILE_ORDER");
+    const char* to = pf_exp_env("PF_TILE_ORDER");
     int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
     if (tile_order == 2 && (grid3 & 7)) tile_order = 1;
     hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks, ctx->X,

@@ -479,7 +479,7 @@ int launch_hex(pf_ctx* ctx, const HexParams& pr, double* out0, double* out1) {
   if (lds > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int wpc = 8;  // persistent waves per CU: ~250 VGPRs -> 2 per SIMD
-  if (const char* e = getenv("PF_HEX_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
+  if (const char* e = pf_exp_env("PF_HEX_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
   const unsigned grid = (unsigned)std::min<int64_t>(ctx->ntiles, (int64_t)256 * wpc);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, ctx->stream, ctx->ntiles, plane, ctx->X, ctx->nptr,
                      reinterpret_cast<const int4*>(ctx->tile_desc), reinterpret_cast<const int4*>(ctx->vis_rec), pr,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -14,11 +15,23 @@
 
 struct pf_amg;
 
+// Experiment / ablation knobs (PF_ABLATE, PF_GATHER_IMPL, PF_TILE_*, PF_AMG_* tuning, PF_SPMV_*) exist only in
+// builds with -DPF_EXPERIMENTS (`python -m pyfem_gpu_testflight_amd.build --experiments` makes a separate
+// libpyfem_hip_exp.so for tools/): an inherited environment variable can never change what the product library
+// computes.  The two operational knobs (PF_HOST_THREADS, PF_AMG_VERBOSE) are read once, in pf_ctx_create.
+#ifdef PF_EXPERIMENTS
+static inline const char* pf_exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* pf_exp_env(const char*) { return nullptr; }
+#endif
+
 struct pf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
   std::string warn;          // last non-fatal condition (pf_last_warning), e.g. a preconditioner that was refused
+  int host_threads = 0;      // PF_HOST_THREADS at pf_ctx_create (0: hardware concurrency)
+  bool amg_verbose = false;  // PF_AMG_VERBOSE at pf_ctx_create
 
   // ---- mesh (device copies) ----
   int64_t nnodes = 0, nelems = 0;

@@ -295,6 +295,8 @@ extern "C" int pf_ctx_create(int device, pf_ctx** out) {
   PF_HIP(hipSetDevice(device));
   ctx = new pf_ctx();
   ctx->device = device;
+  if (const char* e = getenv("PF_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e));
+  ctx->amg_verbose = getenv("PF_AMG_VERBOSE") != nullptr;
   hipError_t e = hipMalloc(&ctx->scal, ((size_t)PF_NPART * PF_NPART_ARRAYS + 32) * sizeof(double));  // + trash line [0,16) + AMG scalar [16]
   if (e != hipSuccess) {
     delete ctx;
@@ -442,6 +444,7 @@ static int build_rows(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
   PF_HIP(hipMalloc(&ctx->n2e_pos, (size_t)ctx->nelems * P * PS));
   PF_HIP(hipMemsetAsync(ctx->n2e_pos, 0, (size_t)ctx->nelems * P * PS, ctx->stream));
   PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
+  PF_HIP(hipMemsetAsync(ctx->diagpos, 0, (size_t)nn, ctx->stream));  // nodes no element uses have empty rows: k_row_fill never writes theirs
   k_row_fill<P><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
                                                               ctx->nidx, ctx->n2e_pos, ctx->diagpos);
   PF_LAUNCH_CHECK();
@@ -465,6 +468,7 @@ static int build_rows_tab(pf_ctx* ctx, int32_t* rowcnt, int32_t* flag) {
   ctx->nblocks = total;
   PF_HIP(hipMalloc(&ctx->nidx, sizeof(int32_t) * (size_t)total));
   PF_HIP(hipMalloc(&ctx->diagpos, (size_t)nn));
+  PF_HIP(hipMemsetAsync(ctx->diagpos, 0, (size_t)nn, ctx->stream));
   k_row_fill_tab<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(ctx->P, nn, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->nptr,
                                                                ctx->nidx, ctx->diagpos);
   PF_LAUNCH_CHECK();
@@ -542,7 +546,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     desc.reserve(4 * (size_t)(nn / ctx->npt + 16));
     std::vector<uint8_t> slot(nn);
     ctx->max_tile_blocks = 0;
-    const bool fixed = getenv("PF_TILE_FIXED") != nullptr;  // ablation: npt nodes per tile, no alignment search
+    const bool fixed = pf_exp_env("PF_TILE_FIXED") != nullptr;  // ablation: npt nodes per tile, no alignment search
     for (int64_t n0 = 0; n0 < nn;) {
       int64_t emax = std::min<int64_t>(n0 + ctx->npt, nn);
       while (emax > n0 + 1 && hv[emax] - hv[n0] > 64) --emax;  // at most 64 incident pairs per tile

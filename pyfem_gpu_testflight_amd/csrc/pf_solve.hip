@@ -1,10 +1,10 @@
-// Dirichlet BCs, SpMV and Jacobi-PCG on the blocked value layout (gfx950).
+// Dirichlet BCs, SpMV and PCG (Jacobi or the AMG V-cycle of pf_amg.hip) on the blocked value layout (gfx950).
 //
 // Replaces (reference file:line)
 //   ModelBase.apply_dirichlet_bcs                pyfem.py:781-835
 //   scipy CSR matvec call sites                   pyfem.py:2119 (Helmholtz rhs = R x), inside cg
-//   Assembler._solve_linear_system "cg"           pyfem.py:2403-2423  (scipy.sparse.linalg.cg;
-//       the pyamg SA-AMG preconditioner of :2393-2400 is replaced by Jacobi -- see DESIGN.md)
+//   Assembler._solve_linear_system "cg"           pyfem.py:2403-2423  (scipy.sparse.linalg.cg preconditioned with
+//       pyamg SA-AMG, :2393-2400; here pf_cg with the smoothed-aggregation V-cycle of pf_amg.hip, or Jacobi)
 //
 // SpMV design: HBM-bound streaming of the value array (8 B/nnz) plus one 4-byte node index per
 // d x d block (so 9 B/nnz at d=2 instead of CSR's 12).  One wave owns 64 consecutive nodes whose
@@ -313,10 +313,11 @@ __global__ void k_extract_diag(int64_t nnodes, const int32_t* __restrict__ nptr,
                                const double* __restrict__ vals, double* __restrict__ diag, int invert) {
   const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (n >= nnodes) return;
+  const bool empty = nptr[n] == nptr[n + 1];  // a node no element references (pyfem.py:683-684 allows them): unit diagonal
   const int64_t b = ((int64_t)nptr[n] + diagpos[n]) * D * D;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const double v = vals[b + k * D + k];
+    const double v = empty ? 1.0 : vals[b + k * D + k];
     diag[D * n + k] = invert ? 1.0 / v : v;
   }
 }
@@ -326,7 +327,7 @@ template <int D>
 __global__ void k_add_to_diag(int64_t nnodes, const int32_t* __restrict__ nptr, const uint8_t* __restrict__ diagpos,
                               double* __restrict__ vals, const double* __restrict__ add) {
   const int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (n >= nnodes) return;
+  if (n >= nnodes || nptr[n] == nptr[n + 1]) return;  // empty row: nothing to add to
   const int64_t b = ((int64_t)nptr[n] + diagpos[n]) * D * D;
 #pragma unroll
   for (int k = 0; k < D; ++k) vals[b + k * D + k] += add[D * n + k];
@@ -597,7 +598,7 @@ __global__ void k_build_idx16(int64_t nnodes, int tile_nodes, const int32_t* __r
 
 static int ensure_idx16(pf_ctx* ctx) {
   if (ctx->nidx16_state) return PF_OK;
-  const char* e = getenv("PF_SPMV_IDX16");
+  const char* e = pf_exp_env("PF_SPMV_IDX16");
   if (e && atoi(e) == 0) { ctx->nidx16_state = -1; return PF_OK; }
   int32_t* flag = nullptr;
   PF_HIP(hipMalloc(&ctx->nidx16, sizeof(int16_t) * (size_t)std::max<int64_t>(1, ctx->nblocks)));
@@ -634,7 +635,7 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
     return PF_OK;
   }
 #ifdef PF_SPMV_SWEEP
-  const char* sh = getenv("PF_SPMV_SHAPE");
+  const char* sh = pf_exp_env("PF_SPMV_SHAPE");
   const int shape = sh ? atoi(sh) : 0;
 #define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
   if (shape == ID && ctx->d == D_) {                                                                        \

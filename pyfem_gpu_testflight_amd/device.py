@@ -246,6 +246,39 @@ class HipContext:
         self._call("pf_vals_to_csr", _ptr(vals), _ptr(out))
         return out
 
+    def upload_csr(self, K):
+        """Device values (blocked layout) of a HOST scipy matrix whose entries lie inside this context's pattern --
+        e.g. `K + K2` or `2.0 * K` computed with scipy on matrices that compute_jacobian() returned.  Entries the
+        matrix does not store are zero; an entry outside the pattern is a ValueError.  Boundary path (one upload of
+        nnz values), not a hot one."""
+        from scipy import sparse
+
+        torch = self.torch
+        K = sparse.csr_matrix(K)
+        if K.shape != (self.nrows, self.nrows):
+            raise ValueError(f"matrix of shape {K.shape} does not fit the model's {self.nrows} dofs")
+        if np.iscomplexobj(K.data):
+            raise TypeError("complex matrices take the complex-step path (compute_jacobian with a complex density)")
+        K.sum_duplicates()
+        indptr, indices = self.csr_structure()
+        rows = np.repeat(np.arange(self.nrows, dtype=np.int64), np.diff(K.indptr))
+        key = rows * self.nrows + K.indices
+        pat = np.repeat(np.arange(self.nrows, dtype=np.int64), np.diff(indptr)) * self.nrows + indices
+        pos = np.searchsorted(pat, key)
+        if key.size and (pos.max(initial=0) >= pat.size or not np.array_equal(pat[np.minimum(pos, pat.size - 1)], key)):
+            raise ValueError("the matrix has entries outside the sparsity pattern of this model")
+        data = np.zeros(self.nnz)
+        data[pos] = K.data
+        csr_d = self.to_device(data, torch.float64)
+        if self.d == 1:
+            return csr_d
+        if getattr(self, "_csr_perm", None) is None:  # csr position -> blocked position, from the export kernel itself
+            ar = torch.arange(self.nnz, dtype=torch.float64, device=self.device)
+            self._csr_perm = self.vals_to_csr(ar).to(torch.int64)
+        vals = self.empty(self.nnz)
+        vals[self._csr_perm] = csr_d
+        return vals
+
     def apply_dirichlet(self, vals, rhs, mask, fixed_vals=None, symmetric=True, diag_scale=None):
         self._sync_stream()
         self._call("pf_apply_dirichlet", _ptr(vals), _ptr(rhs), _ptr(mask), _ptr(fixed_vals), int(bool(symmetric)),

@@ -32,6 +32,9 @@ from .utils import time_this
 DEFAULT_RTOL = 1e-10
 # method="direct": relative residual the device PCG is driven to in place of the reference's sparse LU
 DIRECT_RTOL = 1e-13
+DIRECT_ACCEPT = 1e-10   # true relative residual up to which method="direct" accepts (with a warning) what PCG reached
+DIRECT_BURST = 500      # iterations per refinement round of method="direct" with the AMG preconditioner
+DIRECT_ROUNDS = 4
 
 # preconditioner of the device PCG: "amg" (aggregation AMG V-cycle, the counterpart of the reference's
 # pyamg preconditioners, pyfem.py:2393-2400 and :2098; positive or negative definite K -- only diagonal entries of
@@ -374,7 +377,9 @@ class ModelBase:
         if isinstance(K, ComplexStepCSR):
             return self._apply_dirichlet_bcs_complex(K, rhs, enforce_symmetric_K)
         if not isinstance(K, DeviceCSR) or K.hctx is None:
-            raise TypeError("apply_dirichlet_bcs expects the device-backed matrix returned by compute_jacobian()")
+            # a host matrix (the reference takes any scipy CSR, pyfem.py:781): e.g. `K + K2` formed with scipy.  Its
+            # entries must lie inside the model's pattern; the values are uploaded once and the result is device-backed.
+            K = DeviceCSR(self.hctx, self.hctx.upload_csr(K))
         torch = self.hctx.torch
         on_device = isinstance(rhs, torch.Tensor)
         rhs_d = rhs if on_device else self.hctx.to_device(rhs, torch.float64)
@@ -827,9 +832,10 @@ class Assembler:
         "cg" and "gmres": PCG with the smoothed-aggregation AMG V-cycle (self.precond = "amg", default) or Jacobi, to
                   self.rtol.  K is SPD after symmetric BC elimination, so CG reaches the same solution GMRES does.
         "direct": the reference calls scipy spsolve (pyfem.py:2414).  No factorisation is built on the GPU: the same
-                  PCG is driven to DIRECT_RTOL (1e-13 in ||r||/||b||, the level an LU residual sits at in fp64) and
-                  raises if it does not get there.  Host code that wants the factorisation itself can still hand the
-                  returned matrix to scipy (`spsolve(K, rhs)`: DeviceCSR is a csr_matrix)."""
+                  PCG is driven to DIRECT_RTOL (1e-13 in ||r||/||b||, the level an LU residual sits at in fp64) with
+                  restarts (_direct_by_refinement); what it does on stagnation and on indefinite matrices is stated
+                  there.  Host code that wants the factorisation itself can still hand the returned matrix to scipy
+                  (`spsolve(K, rhs)`: DeviceCSR is a csr_matrix)."""
         rtol = DIRECT_RTOL if method == "direct" else self.rtol
         if isinstance(K, ComplexStepCSR):  # (Kr + i Ki)(ur + i ui) = br + i bi, to first order in the imaginary parts
             rhs = np.asarray(rhs)
@@ -846,12 +852,52 @@ class Assembler:
             comp = getattr(K, "companion", None)
             if comp is not None:  # nonsymmetric (rows-only conditions, Newton tangent): BiCGStab, AMG of the companion
                 x, it, rr = hctx.bicgstab(K.vals, b, pvals=comp.vals, rtol=rtol, precond=_PRECOND[self.precond])
+            elif method == "direct":
+                x, it, rr = self._direct_by_refinement(K, b)
             else:
                 x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
-        except RuntimeError as e:
+        except _lib.PyfemHipError:
+            raise  # a HIP / argument error is not a convergence failure: keep its message
+        except RuntimeError as e:  # PF_E_NOCONV: "<solver> failed with code <iters>" (pyfem.py:2421-2422)
             raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
         self.last_iters, self.last_relres = it, rr
         return x if on_device else x.cpu().numpy()
+
+    def _direct_by_refinement(self, K, b):
+        """method="direct" on a symmetric K (pyfem.py:2414 calls spsolve): PCG to DIRECT_RTOL, restarted from the
+        iterate reached whenever a run of DIRECT_BURST iterations ends above it.  A restart recomputes r = b - K x, so
+        the recurrence residual cannot drift away from the true one (iterative refinement); ill-conditioned systems
+        (RAMP densities near the lower bound) whose recurrence stalls get there in two or three rounds.  Acceptance is
+        on the TRUE residual ||b - K x|| / ||b||: <= DIRECT_RTOL silently, <= DIRECT_ACCEPT with a RuntimeWarning that
+        names the level reached; above that -- an indefinite or singular matrix, which spsolve would have factorised
+        -- RuntimeError("direct failed with code <iterations>: ...") naming the residual and the host alternative."""
+        import warnings
+
+        hctx = K.hctx
+        torch = hctx.torch
+        burst = DIRECT_BURST if self.precond == "amg" else 0  # Jacobi by request: scipy's default cap (10 n)
+        x, total, rr = None, 0, float("inf")
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for _ in range(DIRECT_ROUNDS):
+                x, it, rr = hctx.cg(K.vals, b, x0=x, rtol=DIRECT_RTOL, maxiter=burst, precond=_PRECOND[self.precond],
+                                    allow_maxiter=True)
+                total += it
+                if rr <= DIRECT_RTOL or not np.isfinite(rr):
+                    break
+        for w in {str(c.message) for c in caught}:
+            warnings.warn(w, RuntimeWarning, stacklevel=4)
+        bn = float(torch.linalg.vector_norm(b))
+        true_rr = float(torch.linalg.vector_norm(b - hctx.spmv(K.vals, x))) / bn if bn > 0 else 0.0
+        if not np.isfinite(true_rr) or true_rr > DIRECT_ACCEPT:
+            raise RuntimeError(
+                f"direct failed with code {total}: no factorisation is built on the device and PCG stopped at "
+                f"||b - K x|| / ||b|| = {true_rr:.3e} (the matrix may be indefinite or singular); "
+                "scipy.sparse.linalg.spsolve(K, rhs) factorises the returned matrix on the host")
+        if true_rr > 10 * DIRECT_RTOL:
+            warnings.warn(f'method="direct": PCG with refinement reached ||b - K x|| / ||b|| = {true_rr:.3e} '
+                          f"(target {DIRECT_RTOL:g}) after {total} iterations; accepted", RuntimeWarning, stacklevel=4)
+        return x, total, true_rr
 
     @time_this
     def solve_nonlinear(self, method="gmres", xdv=None, u0=None, tol=1e-10, atol=1e-12, max_iter=10):

@@ -342,8 +342,9 @@ def test_cg_is_bitwise_reproducible(pf):
 
 def test_isolated_nodes_and_kernel_variants(pf, orc):
     """Nodes that no element references (the reference allows them: pyfem.py:683-684) give empty rows;
-    32 consecutive ones make whole assembly tiles empty.  Also cross-checks the first-generation
-    kernel (PF_GATHER_IMPL=legacy) against the default one, bit for bit."""
+    32 consecutive ones make whole assembly tiles empty.  Also: the product library must ignore the experiment knobs
+    (they exist only in -DPF_EXPERIMENTS builds), and a Jacobi-PCG solve on such a mesh works (unit diagonal on the
+    empty rows: ADVICE r1, diagpos of empty rows)."""
     import os
 
     conn, X = orc.structured_mesh(9, 7, "quad")
@@ -361,12 +362,21 @@ def test_isolated_nodes_and_kernel_variants(pf, orc):
     assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
     assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
     a = model.compute_jacobian(rho).vals.clone()
+    os.environ["PF_ABLATE"] = "1"  # "no quadrature" ablation of the experiments build: must have no effect here
     os.environ["PF_GATHER_IMPL"] = "legacy"
     try:
         bvals = model.compute_jacobian(rho).vals.clone()
     finally:
-        del os.environ["PF_GATHER_IMPL"]
-    assert float((a - bvals).abs().max()) <= 1e-14 * float(a.abs().max())
+        del os.environ["PF_ABLATE"], os.environ["PF_GATHER_IMPL"]
+    assert bool((a == bvals).all())
+    # solve with the Jacobi preconditioner: the 32 unused nodes have empty rows and no diagonal entry
+    asm = pf.Assembler(model)
+    asm.precond = "jacobi"
+    u = asm.solve(method="cg")
+    uo, *_ = orc.solve_elasticity(X2, conn2, "quad", np.array([0, 1]), {int(conn2.max()): [0.0, -1.0]})
+    used = np.unique(conn2)
+    ud = np.concatenate([2 * used, 2 * used + 1])
+    assert np.abs(u[ud] - uo[ud]).max() <= U_TOL * np.abs(uo[ud]).max()
 
 
 @pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri")])
