@@ -6,16 +6,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one device-resident `compute_jacobian()` pass over the whole mesh: RAMP density at the
-quadrature points -> element stiffness rows -> scatter into the existing sparsity pattern (the
-symbolic pattern is built once outside the timed region).  Inputs (mesh, density) are
-resident in HBM before the timed region.  The CG leg runs a fixed number of Jacobi-PCG iterations
-on the BC-applied matrix.  N>1 is STRONG scaling: the same 4M-quad mesh is split into N element
-blocks (no data-path collective in assembly; one all-reduce per CG iteration).
+A "step" is one device-resident `compute_jacobian()` pass over the whole mesh with the reference's default
+density rho = 1 (pyfem.py:1780-1781; the density-free kernel specialisation): element stiffness rows -> scatter
+into the existing sparsity pattern (the symbolic pattern is built once outside the timed region).
+The mesh is resident in HBM before the timed region.  The CG leg runs a fixed number of Jacobi-PCG iterations on
+the BC-applied matrix.  N>1 is STRONG scaling: the same 4M-quad mesh is split into N element blocks (no data-path
+collective in assembly; per CG iteration one neighbour exchange of the interface rows and one scalar all-reduce).
+
+At N=1 the same JSON line carries, under "legs", the other BASELINE.json configurations at full size, each with
+its algorithmic bytes, its average launch time (HIP events on the launch stream) and its roofline fraction:
+  rho    : the same 4M-quad assembly with a resident nodal RAMP density (the topology-optimisation kernel)
+  c3     : Helmholtz 2048^2 -- K+R assembly and the d=1 SpMV (the SpMV/CG roofline configuration)
+  c4     : triangle assembly -- 1415^2 split quads (4.0 M triangles) and arm.inp red-refined 5 times (2.55 M)
+  c5     : one topology-optimisation inner iteration on 2048x1024 (filter, assemble, BCs, AMG-PCG, 3 gradient filters)
+and "hbm_ceiling": what THIS device sustains in THIS process for a pure write, a pure read and the assembly's
+1:3 read:write mix (pf_hbm_probe), so that every fraction is also given against the measured ceiling.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,17 +34,36 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there ~6290
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")  # falls back to r01 if this round's is absent
 
 
-def algorithmic_bytes_assembly(nelems, nnodes, nnz, P=4, with_rho=False):
-    """conn int32 + X + rho + K.data written once."""
-    return 4 * P * nelems + 16 * nnodes + (8 * nnodes if with_rho else 0) + 8 * nnz
+def algorithmic_bytes_assembly(nelems, nnodes, nnz, P=4, with_rho=False, nmat=1):
+    """conn int32 + X + rho + K.data written once (nmat = 2: Helmholtz writes K and R)."""
+    return 4 * P * nelems + 16 * nnodes + (8 * nnodes if with_rho else 0) + 8 * nnz * nmat
 
 
 def algorithmic_bytes_spmv(nnz, nrows):
     """12 B per nonzero (value + int32 column) + 20 B per row."""
     return 12 * nnz + 20 * nrows
+
+
+def layout_bytes_spmv(nnz, nrows, nnodes, d, idx16=True):
+    """What k_spmv's own layout moves: d x d value blocks + one (2- or 4-byte) node index per block, the row
+    pointer per node, x read once and y written once."""
+    nblocks = nnz // (d * d)
+    return 8 * nnz + (2 if idx16 else 4) * nblocks + 4 * nnodes + 16 * nrows
+
+
+def usable_cpus():
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return usable
 
 
 def cpu_baseline(n=1024, reps=3, cg_iters=40):
@@ -45,14 +74,7 @@ def cpu_baseline(n=1024, reps=3, cg_iters=40):
     # BLAS threads = the CPUs this process may really use (affinity mask and cgroup quota), not the host's logical
     # CPU count: on a quota'd box one OpenBLAS thread per logical CPU only burns the quota and gets the process
     # throttled, which would understate the baseline.
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            usable = max(1, min(usable, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    threads = usable
+    threads = usable = usable_cpus()
     limiter = None
     try:
         from threadpoolctl import threadpool_limits
@@ -86,11 +108,219 @@ def cpu_baseline(n=1024, reps=3, cg_iters=40):
         limiter.restore_original_limits()
     return {
         "value": conn.shape[0] / t_asm, "unit": "elements/s", "cores": int(threads), "kind": "port",
-        "sample": f"{n}x{n}-quad plane-stress mesh ({conn.shape[0]} elements), oracle einsum Ke + coo->csr, "
-                  f"median of {reps} warm passes; BLAS threads limited to the {threads} usable cpus of "
+        "sample": f"{n}x{n}-quad plane-stress mesh ({conn.shape[0]} elements = a quarter of the metric mesh: the "
+                  f"einsum + coo->csr path is linear in the element count and one 2048x2048 pass takes ~20 s and "
+                  f"~25 GB of temporaries, four of them would not fit the few-minute default run), oracle einsum Ke + "
+                  f"coo->csr, median of {reps} warm passes; BLAS threads limited to the {threads} usable cpus of "
                   f"{os.cpu_count()} logical ones",
         "cg_iter_per_sec": 1.0 / t_cg, "spmv_GBps": algorithmic_bytes_spmv(Kbc.nnz, Kbc.shape[0]) / t_spmv / 1e9,
     }
+
+
+def smi_snapshot():
+    """Clocks / power / temperature as rocm-smi reports them (outside every timed region); {} when unreadable."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(s in kl for s in ("sclk", "mclk", "fclk", "power", "junction", "edge")) and len(keep) < 12:
+                keep[k] = v
+        return keep
+    except Exception:
+        return {}
+
+
+def pmc_traffic(kernel_substr, fetch_scale=1.0):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (WRITE_SIZE + FETCH_SIZE
+    in KB, separate passes).  NOT measured in this run: the source file is named in the output."""
+    for name in (PMC_SUMMARY, os.path.join("profiles", "r01_pmc_summary.json")):
+        try:
+            pm = json.load(open(os.path.join(ROOT, name)))
+        except Exception:
+            continue
+        for k, v in pm.items():
+            if kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                return 1024.0 * (v["WRITE_SIZE"] + fetch_scale * v["FETCH_SIZE"]), v["FETCH_SIZE"], name
+    return None, None, None
+
+
+class Timer:
+    """Average device milliseconds of fn() over `reps` back-to-back calls: HIP events on torch's current stream,
+    which is the stream every pf_* launch goes to (HipContext binds the ctx to it before each call)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def __call__(self, fn, reps, warmup=2):
+        torch = self.torch
+        for _ in range(warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
+def arm_mesh(levels):
+    """examples/torque_arm arm.inp (tests/golden/arm_tri.npz holds its nodes, triangles and groups) after `levels`
+    uniform red refinements, refinement order; BASELINE.json config 4 (5 levels = 2.55 M triangles)."""
+    from pyfem_gpu_testflight_amd import meshtools
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "arm_tri.npz"))
+    X, conn = g["X"], g["conn"].astype(np.int64)
+    sets = {"fixed": np.unique(g["dof_fixed"] // 2), "load": g["force_nodes"].astype(np.int64)}
+    load_val = g["force_vals"][0]
+    for _ in range(levels):
+        X, conn, sets = meshtools.red_refine_tri(X, conn, sets)
+    dof_fixed = list(np.stack([2 * sets["fixed"], 2 * sets["fixed"] + 1], axis=1).ravel())
+    force = {int(n): [float(load_val[0]), float(load_val[1])] for n in sets["load"]}
+    return conn, X, dof_fixed, force
+
+
+def roof(bytes_, ms, ceiling=None):
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    out = {"algorithmic_bytes": int(bytes_), "avg_launch_ms": ms, "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS}
+    if ceiling:
+        out["frac_of_measured"] = gbs / ceiling
+    return out
+
+
+def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
+    """The other BASELINE.json configurations at full size (N=1 only).  Every number is a device time from HIP events."""
+    legs = {}
+    dev = model4m.hctx.device
+    qq = pyfem.QuadratureBilinear2D()
+    bq = pyfem.BasisBilinear2D(qq)
+    qt = pyfem.QuadratureTriangle2D()
+    bt = pyfem.BasisTriangle2D(qt)
+
+    if "rho" in which:  # nodal RAMP density on the metric mesh (the kernel C5 runs)
+        h = model4m.hctx
+        model4m.p = 5.0
+        rho = torch.rand(h.nnodes, dtype=torch.float64, device=dev) * 0.7 + 0.3
+        ms = timer(lambda: model4m.compute_jacobian(rho, out=K4m), 20)
+        legs["rho"] = {"workload": "2048x2048 quads, nodal RAMP density p=5 (k_assemble_v3<4,Elasticity<4,true>>)",
+                       "elements_per_s": h.nelems / (ms * 1e-3),
+                       **roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, with_rho=True), ms, ceil.get("mix"))}
+        model4m.p = 0.0
+        model4m.compute_jacobian(out=K4m)
+
+    if "c3" in which:  # tests/test_helmholtz.py:11-44 at 2048^2
+        c = pyfem.ProblemCreator(2049, 2049)
+        conn, X, x = c.create_helmhotz_problem()
+        m = pyfem.Helmholtz(0.05, X, conn, qq, bq)
+        h = m.hctx
+        ms_asm = h.time_kernel(_lib.PF_K_ASSEMBLE_HELMHOLTZ, 20, out0=m.K.vals, E=0.05)  # K only (R = None inside)
+        Kv, Rv = h.assemble_helmholtz(0.05)
+        ms_asm2 = timer(lambda: h._call("pf_assemble_helmholtz2d", 0.05, pyfem_ptr(Kv), pyfem_ptr(Rv)), 20)
+        xd = h.to_device(x, torch.float64)
+        y = torch.empty_like(xd)
+        ms_spmv = h.time_kernel(_lib.PF_K_SPMV, 50, in0=m.K.vals, in1=xd, out0=y)
+        m.apply(xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rho = m.apply(xd)
+        torch.cuda.synchronize()
+        t_apply = time.perf_counter() - t0
+        Rx = h.spmv(m.R.vals, xd)
+        relres = float((Rx - m.K.dot(rho)).norm() / Rx.norm())
+        sp = roof(algorithmic_bytes_spmv(h.nnz, h.nrows), ms_spmv, ceil.get("read"))
+        lay = layout_bytes_spmv(h.nnz, h.nrows, h.nnodes, 1)
+        sp["layout_bytes"] = lay
+        sp["frac_layout"] = lay / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS
+        legs["c3"] = {"workload": "Helmholtz filter r0=0.05 on 2048x2048 quads (4198401 rows, d=1)",
+                      "assemble_K": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz), ms_asm, ceil.get("mix")),
+                      "assemble_K_and_R": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, nmat=2), ms_asm2, ceil.get("mix")),
+                      "spmv": sp, "apply_s": t_apply, "apply_iters": m.last_iters, "apply_true_relres": relres}
+        del m, Kv, Rv
+
+    if "c4" in which:  # examples/torque_arm/arm.py:19-48 scaled to BASELINE's 4M triangles
+        tri = {}
+        for tag, mesh in (("split1415", None), ("arm5", "arm")):
+            if mesh is None:
+                c = pyfem.ProblemCreator(1416, 1416, element_type="tri")
+                conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+                desc = "1415x1415 split quads (4.0 M triangles), structured order"
+            else:
+                conn, X, dof_fixed, force = arm_mesh(5)
+                desc = "arm.inp red-refined 5 times (2.55 M triangles, detJ < 0), refinement order"
+            m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, qt, bt)
+            h = m.hctx
+            K = m.compute_jacobian()
+            ms = timer(lambda: m.compute_jacobian(out=K), 20)
+            xv = torch.rand(h.nrows, dtype=torch.float64, device=dev)
+            yv = torch.empty_like(xv)
+            ms_spmv = h.time_kernel(_lib.PF_K_SPMV, 30, in0=K.vals, in1=xv, out0=yv)
+            tri[tag] = {"workload": desc, "nelems": h.nelems, "elements_per_s": h.nelems / (ms * 1e-3),
+                        "assemble": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, P=3), ms, ceil.get("mix")),
+                        "spmv": roof(algorithmic_bytes_spmv(h.nnz, h.nrows), ms_spmv, ceil.get("read"))}
+            if mesh == "arm":
+                rhs = h.to_device(m.compute_rhs(), torch.float64)
+                Kbc, bb = m.apply_dirichlet_bcs(K, rhs, True)
+                h.cg(Kbc.vals, bb, rtol=1e-8, precond=_lib.PF_PRECOND_AMG)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, it, rr = h.cg(Kbc.vals, bb, rtol=1e-8, precond=_lib.PF_PRECOND_AMG)
+                torch.cuda.synchronize()
+                tri[tag]["amg_pcg_solve_s"] = time.perf_counter() - t0
+                tri[tag]["amg_pcg_iters"] = it
+            del m, K
+        legs["c4"] = tri
+
+    if "c5" in which:  # examples/topology_optimization/topo.py:50-75, one inner iteration
+        c = pyfem.ProblemCreator(2049, 1025)
+        conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+        filtr = pyfem.Helmholtz(0.05, X, conn, qq, bq)
+        model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, qq, bq, p=5.0)
+        filtr.rtol = 1e-8
+        h = model.hctx
+        xk = h.to_device(np.random.default_rng(0).uniform(1e-3, 1, X.shape[0]), torch.float64)
+        asm = pyfem.Assembler(model)
+        asm.rtol = 1e-8
+
+        def iteration():
+            torch.cuda.synchronize()
+            t = [time.perf_counter()]
+            rho = filtr.apply(xk).clamp(1e-3, 1.0)
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+            K = model.compute_jacobian(rho)
+            rhs = h.to_device(model.compute_rhs(), torch.float64)
+            K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+            u = asm._solve_linear_system(K, rhs, "cg")
+            comp = float(rhs.dot(u))
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+            g = model.compliance_grad(rho, u)  # device tensors in -> device tensor out (fused sensitivity kernel)
+            for _ in range(3):
+                filtr.apply_gradient(g)
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+            return t, comp
+
+        iteration()  # builds the graph-only AMG hierarchies once per mesh and loads every kernel
+        t, comp = iteration()
+        legs["c5"] = {"workload": "one topology-optimisation inner iteration, 2048x1024 quads, nodal density, RAMP p=5, "
+                                  "AMG-PCG rtol 1e-8 (second iteration: hierarchies cached)",
+                      "filter_apply_s": t[1] - t[0], "filter_iters": filtr.last_iters, "assemble_bc_s": t[2] - t[1],
+                      "elasticity_solve_s": t[3] - t[2], "elasticity_cg_iters": asm.last_iters, "compliance": comp,
+                      "sensitivity_and_three_filter_gradients_s": t[4] - t[3], "iteration_total_s": t[4] - t[0]}
+    return legs
+
+
+def pyfem_ptr(t):
+    import ctypes as C
+
+    return C.c_void_p(t.data_ptr())
 
 
 def main():
@@ -102,6 +332,7 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=200)
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs", default="rho,c3,c4,c5", help="comma list of secondary legs at N=1 ('' = none)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +370,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    smi0 = smi_snapshot() if rank == 0 else {}
+
     # ---- workload (synthetic, ProblemCreator semantics of the reference) --------------------
     nx = args.nx
     creator = pyfem.ProblemCreator(nnodes_x=nx + 1, nnodes_y=nx + 1)
@@ -158,6 +391,18 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
     h = model.hctx
+    timer = Timer(torch)
+
+    # ---- HBM ceiling of this device, now (N=1: also normalises box-to-box spread) ------------------
+    ceil = {}
+    if world == 1:
+        nb = 8 * h.nnz  # the size of the K value array
+        for name, mode in (("write", _lib.PF_HBM_FILL), ("read", _lib.PF_HBM_READ), ("mix", _lib.PF_HBM_MIX)):
+            ceil[name] = h.hbm_probe(mode, nb, reps=20)
+            ceil[name + "_nt"] = h.hbm_probe(mode, nb, reps=20, nt=True)
+        ceil["bytes_per_pass"] = nb
+        ceil["note"] = ("pf_hbm_probe: persistent waves, 16 B per lane; mix = 1/4 read + 3/4 written (the assembly's "
+                        "byte mix); GB/s")
 
     # ---- assembly: W warm-up + exactly K timed steps ------------------------------------------
     K = model.compute_jacobian()
@@ -184,8 +429,10 @@ def main():
     spmv_ms = h.time_kernel(_lib.PF_K_SPMV, args.spmv_reps, in0=K.vals, in1=xv, out0=yv)
     b_spmv = algorithmic_bytes_spmv(h.nnz, h.nrows)
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
+    lay_spmv = layout_bytes_spmv(h.nnz, h.nrows, h.nnodes, 2)
 
     # ---- CG leg: fixed iteration count on the BC-applied system -----------------------------------
+    cg_extra = {}
     if world == 1:
         rhs = h.to_device(model.compute_rhs(), torch.float64)
         Kbc, b = model.apply_dirichlet_bcs(K, rhs, True)
@@ -214,24 +461,21 @@ def main():
         barrier()
         t_cg = max_over_ranks(time.perf_counter() - t0)
         iters = args.cg_iters
+        cg_extra = {"cg_transport": getattr(pm.iface, "transport", "all-reduce of the packed interface vector")}
     cg_rate = iters / t_cg
 
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/r01_pmc_summary.json: WRITE_SIZE + FETCH_SIZE in KB, separate passes; FETCH_SIZE of the
-    # 16-B/lane SpMV stream doubled as MI355X_MICROARCH.md prescribes; of the assembly's reads only the visit-record
-    # stream is a 16-B/lane coalesced read, so the half of its 16 B x (4 nelems) that the counter misses is added back,
-    # the gathers are left as counted).  null when the summary is missing or the mesh is not the profiled one.
-    traffic_asm = traffic_spmv = None
-    try:
-        if nx == 2048 and world == 1:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            for k, v in pm.items():
-                if "k_assemble_v3" in k:
-                    traffic_asm = 1024.0 * (v["WRITE_SIZE"] + v["FETCH_SIZE"]) + 0.5 * 16.0 * 4 * h.nelems
-                if "k_spmv" in k:
-                    traffic_spmv = 1024.0 * (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"])
-    except Exception:
-        pass
+    # HBM traffic per launch: replayed from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
+    # passes of this command), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE of a 16-B/lane coalesced stream
+    # is under-reported x2 -- the whole SpMV stream, and of the assembly's reads the visit-record stream only (the
+    # half of its 16 B x 4 nelems the counter misses is added back; the gathers are left as counted).
+    traffic_asm = traffic_spmv = src_asm = src_spmv = None
+    if nx == 2048 and world == 1:
+        t, _, src_asm = pmc_traffic("k_assemble_v3<4, Elasticity<4, false>")
+        if t is not None:
+            traffic_asm = t + 0.5 * 16.0 * 4 * h.nelems
+        t, fetch_kb, src_spmv = pmc_traffic("k_spmv<2")
+        if t is not None:
+            traffic_spmv = t + 1024.0 * fetch_kb  # FETCH counted twice
 
     out = {
         "metric": "element-assemblies/sec (4M-quad plane-stress); CG-iter/sec alongside",
@@ -241,18 +485,35 @@ def main():
         "config": {"workload": f"{nx}x{nx}-quad plane-stress mesh (ProblemCreator), E=10 nu=0.3 rho=1, "
                                f"{nelems_total} elements, ndof={2 * (nx + 1) ** 2}, element-block partition over "
                                f"{world} GPU(s)", "nelems": nelems_total, "cg_iters_timed": int(iters)},
-        "cg_iter_per_sec": cg_rate,
+        "cg_iter_per_sec": cg_rate, **cg_extra,
         "roofline": {"bound": "hbm", "kernel": "k_assemble_v3<4,Elasticity<4,false>>", "achieved": asm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
-                     "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms},
+                     "traffic_source": None if src_asm is None else f"replay of {src_asm} (committed rocprofv3 --pmc "
+                                                                   "passes of this command; not measured in this run)",
+                     "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms,
+                     "frac_of_measured": (asm_gbs / ceil["mix"]) if ceil else None,
+                     "measured_ceiling": "hbm_ceiling.mix" if ceil else None},
         "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true,double>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
+                          "traffic_source": None if src_spmv is None else f"replay of {src_spmv}",
                           "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
-                          "note": "algorithmic bytes are CSR's 12 B per scalar nonzero (SURVEY 8d); the 2x2-block layout "
-                                  "with 16-bit column offsets moves 8.5 B, so frac can exceed the real HBM utilisation "
-                                  "(traffic / time)"},
+                          "layout_bytes_per_launch": lay_spmv,
+                          "frac_layout": lay_spmv / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "frac_layout_of_measured": (lay_spmv / (spmv_ms * 1e-3) / 1e9 / ceil["read"]) if ceil else None,
+                          "note": "frac counts CSR's 12 B per scalar nonzero (SURVEY 8d); frac_layout counts what the "
+                                  "2x2-block layout with 16-bit column offsets really moves (8.5 B per nonzero + "
+                                  "vectors) and is the HBM utilisation"},
         "setup_s": t_setup,
     }
+    if ceil:
+        out["hbm_ceiling"] = ceil
+    if rank == 0 and world == 1:
+        which = [w for w in args.legs.split(",") if w]
+        try:
+            out["legs"] = secondary_legs(torch, pyfem, _lib, timer, ceil, model, K, which)
+        except Exception as e:  # a secondary leg must never cost the headline line
+            out["legs"] = {"error": f"{type(e).__name__}: {e}"}
+        out["device_state"] = {"before": smi0, "after": smi_snapshot()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

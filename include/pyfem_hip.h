@@ -85,6 +85,14 @@ int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks,
 int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx);
 /* scipy-layout CSR structure (device out): indptr int32[nrows+1], indices int32[nnz] */
 int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices);
+/* Gather maps of the fused assembly kernel (2-D meshes and 8-node blocks), for tests that replay its index
+ * arithmetic on the host.  Sizes come back through the HOST outputs ntiles / npt / nvisits (any may be NULL);
+ * the DEVICE outputs may be NULL: tile_desc int32[4*ntiles] = {first node, first visit, first block,
+ * nodes | visits<<8 | blocks<<16} per tile, vis_rec int32[4*nvisits] (12*nvisits for blocks) = the visit records,
+ * n2e_ptr int32[nnodes+1] = first visit of each node.  No counterpart in the reference (its scatter is
+ * coo_matrix(...).tocsr(), pyfem.py:921-931). */
+int pf_pattern_get_tiles(pf_ctx* ctx, int64_t* ntiles, int32_t* npt, int64_t* nvisits, int32_t* tile_desc,
+                         int32_t* vis_rec, int32_t* n2e_ptr);
 
 /* ---- numeric assembly --------------------------------------------------------------------
  * pf_assemble_elasticity2d replaces LinearElasticity.compute_jacobian (pyfem.py:1771-1795):
@@ -258,6 +266,15 @@ int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, co
 enum { PF_K_ASSEMBLE_ELASTICITY = 0, PF_K_SPMV = 1, PF_K_ASSEMBLE_HELMHOLTZ = 2 };
 int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const double* in1,
                    double* out0, double E, double nu, double p, double* ms_host);
+
+/* ---- HBM ceiling of THIS device in THIS process (bench.py: `frac_of_measured` next to the spec-sheet fraction).
+ *      Streams `nbytes` of scratch (allocated and freed inside) `reps` times with persistent waves and 16-byte
+ *      lane accesses; ms_host = average milliseconds per pass (HIP events).  No counterpart in the reference.
+ *      mode PF_HBM_FILL: write only;  PF_HBM_READ: read only;  PF_HBM_MIX: one quarter read, three quarters
+ *      written (the byte mix of the quad assembly: K written once, records + coordinates read).
+ *      nt != 0: non-temporal loads / stores. */
+enum { PF_HBM_FILL = 0, PF_HBM_READ = 1, PF_HBM_MIX = 2 };
+int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int reps, double* ms_host);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
 PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE = 0, 1, 2, 3
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
+PF_HBM_FILL, PF_HBM_READ, PF_HBM_MIX = 0, 1, 2
 PF_TAB_ELASTICITY, PF_TAB_POISSON = 0, 1
 PF_NL_TANGENT, PF_NL_TANGENT_SPD, PF_NL_ELEMENT_TANGENT, PF_NL_RESIDUAL = 0, 1, 2, 3
 
@@ -36,6 +37,7 @@ SIGNATURES = {
     "pf_pattern_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "pf_pattern_get_graph": (C.c_int, [_vp, _vp, _vp]),
     "pf_pattern_get_csr": (C.c_int, [_vp, _vp, _vp]),
+    "pf_pattern_get_tiles": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), _vp, _vp, _vp]),
     "pf_assemble_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, C.c_int, _vp]),
     "pf_assemble_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_sens_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "pf_cgcg_reduce": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pf_cgcg_update_ps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
+    "pf_hbm_probe": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_f64)]),
 }
 
 _lib = None

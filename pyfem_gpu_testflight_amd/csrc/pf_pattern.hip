@@ -620,6 +620,20 @@ extern "C" int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx) {
   return PF_OK;
 }
 
+extern "C" int pf_pattern_get_tiles(pf_ctx* ctx, int64_t* ntiles, int32_t* npt, int64_t* nvisits, int32_t* tile_desc,
+                                    int32_t* vis_rec, int32_t* n2e_ptr) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && ctx->npt && ctx->tile_desc && ctx->vis_rec, "pf_pattern_get_tiles: this pattern has no assembly tiles");
+  const int64_t nv = ctx->nelems * ctx->P;
+  if (ntiles) *ntiles = ctx->ntiles;
+  if (npt) *npt = ctx->npt;
+  if (nvisits) *nvisits = nv;
+  if (tile_desc) PF_HIP(hipMemcpyAsync(tile_desc, ctx->tile_desc, sizeof(int32_t) * 4 * ctx->ntiles, hipMemcpyDeviceToDevice, ctx->stream));
+  if (vis_rec) PF_HIP(hipMemcpyAsync(vis_rec, ctx->vis_rec, sizeof(int32_t) * 4 * nv * (ctx->P == 8 ? 3 : 1), hipMemcpyDeviceToDevice, ctx->stream));
+  if (n2e_ptr) PF_HIP(hipMemcpyAsync(n2e_ptr, ctx->n2e_ptr, sizeof(int32_t) * (ctx->nnodes + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  return PF_OK;
+}
+
 extern "C" int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d, "pf_pattern_get_csr: no pattern built");

@@ -1014,3 +1014,79 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
   (void)hipEventDestroy(e1);
   return rc;
 }
+
+// ------------------------------------------------------------------------------------------
+// HBM ceiling probe (measurement helper of bench.py): what this device sustains in this process for a pure write,
+// a pure read and the assembly's 1:3 read:write mix, with the access shape the kernels of this library use
+// (persistent waves, 16 bytes per lane, 1 KiB per wave access).
+// ------------------------------------------------------------------------------------------
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, const double2* __restrict__ b, int64_t n2,
+                                                   double* __restrict__ sink) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (MODE == PF_HBM_FILL) {
+      const double2 v = make_double2((double)i, 1.0);
+      if constexpr (NT) { __builtin_nontemporal_store(v.x, &a[i].x); __builtin_nontemporal_store(v.y, &a[i].y); }
+      else a[i] = v;
+    } else if constexpr (MODE == PF_HBM_READ) {
+      double2 v;
+      if constexpr (NT) { v.x = __builtin_nontemporal_load(&b[i].x); v.y = __builtin_nontemporal_load(&b[i].y); }
+      else v = b[i];
+      s += v.x + v.y;
+    } else {
+      double2 v;
+      if constexpr (NT) { v.x = __builtin_nontemporal_load(&b[i].x); v.y = __builtin_nontemporal_load(&b[i].y); }
+      else v = b[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double2 w = make_double2(v.x + k, v.y - k);
+        double2* dst = a + i + k * n2;
+        if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
+        else *dst = w;
+      }
+    }
+  }
+  if (MODE == PF_HBM_READ && s == 0.12345) sink[0] = s;  // keeps the loads alive
+}
+
+extern "C" int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int reps, double* ms_host) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(mode >= PF_HBM_FILL && mode <= PF_HBM_MIX && nbytes >= 4096 && reps > 0 && ms_host, "pf_hbm_probe: bad arguments");
+  PF_HIP(hipSetDevice(ctx->device));
+  // FILL: a = nbytes; READ: b = nbytes; MIX: b = nbytes/4 read, a = 3 nbytes/4 written
+  const int64_t n2 = (mode == PF_HBM_MIX ? nbytes / 4 : nbytes) / 16;
+  double2 *a = nullptr, *b = nullptr;
+  if (mode != PF_HBM_READ) PF_HIP(hipMalloc(&a, (size_t)n2 * 16 * (mode == PF_HBM_MIX ? 3 : 1)));
+  if (mode != PF_HBM_FILL) {
+    PF_HIP(hipMalloc(&b, (size_t)n2 * 16));
+    PF_HIP(hipMemsetAsync(b, 0, (size_t)n2 * 16, ctx->stream));
+  }
+  hipEvent_t e0, e1;
+  PF_HIP(hipEventCreate(&e0));
+  PF_HIP(hipEventCreate(&e1));
+  const unsigned grid = 256 * 8;
+  auto launch = [&]() {
+#define PF_PROBE(M_)                                                                                            \
+    if (mode == M_) {                                                                                           \
+      if (nt) k_hbm_probe<M_, true><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                        \
+      else k_hbm_probe<M_, false><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                          \
+    }
+    PF_PROBE(PF_HBM_FILL) PF_PROBE(PF_HBM_READ) PF_PROBE(PF_HBM_MIX)
+#undef PF_PROBE
+  };
+  for (int i = 0; i < 3; ++i) launch();  // warm-up
+  PF_HIP(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i) launch();
+  PF_HIP(hipEventRecord(e1, ctx->stream));
+  PF_HIP(hipEventSynchronize(e1));
+  PF_LAUNCH_CHECK();
+  float ms = 0;
+  PF_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_host = (double)ms / reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  return PF_OK;
+}

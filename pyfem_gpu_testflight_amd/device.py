@@ -151,6 +151,23 @@ class HipContext:
         self._call("pf_pattern_get_graph", _ptr(nptr), _ptr(nidx))
         return nptr, nidx
 
+    def assembly_maps(self):
+        """Host copies of the fused assembly kernel's gather maps (pf_pattern_get_tiles): dict with npt, tile_desc
+        (ntiles,4), vis_rec (nvisits,4 | 12), n2e_ptr (nnodes+1), nptr (nnodes+1).  For tests that replay the kernel's
+        index arithmetic."""
+        torch = self.torch
+        nt, npt, nv = _lib._i64(), _lib._i32(), _lib._i64()
+        self._sync_stream()
+        self._call("pf_pattern_get_tiles", C.byref(nt), C.byref(npt), C.byref(nv), None, None, None)
+        w = 12 if self.P == 8 else 4
+        td = self.empty(4 * nt.value, torch.int32)
+        vr = self.empty(w * nv.value, torch.int32)
+        n2e = self.empty(self.nnodes + 1, torch.int32)
+        self._call("pf_pattern_get_tiles", None, None, None, _ptr(td), _ptr(vr), _ptr(n2e))
+        nptr, _ = self.graph()
+        return {"npt": npt.value, "tile_desc": td.cpu().numpy().reshape(-1, 4), "vis_rec": vr.cpu().numpy().reshape(-1, w),
+                "n2e_ptr": n2e.cpu().numpy(), "nptr": nptr.cpu().numpy()}
+
     # -- numeric --------------------------------------------------------------------------
     def assemble_elasticity(self, E, nu, p, rho=None, mode=_lib.PF_SCATTER_GATHER, out=None):
         vals = self.empty(self.nnz) if out is None else out
@@ -348,6 +365,13 @@ class HipContext:
         om = (_lib._f64 * cap)()
         self._call("pf_amg_info", C.byref(nl), nodes, dpn, om, cap)
         return [(nodes[i], dpn[i], om[i]) for i in range(nl.value)]
+
+    def hbm_probe(self, mode, nbytes, reps=20, nt=False):
+        """GB/s this device sustains now for a pure write / pure read / 1:3 read:write mix of `nbytes` (pf_hbm_probe)."""
+        ms = _lib._f64()
+        self._sync_stream()
+        self._call("pf_hbm_probe", int(mode), int(bool(nt)), _lib._i64(int(nbytes)), int(reps), C.byref(ms))
+        return nbytes / (ms.value * 1e-3) / 1e9
 
     def time_kernel(self, which, reps, in0=None, in1=None, out0=None, E=0.0, nu=0.0, p=0.0):
         ms = _lib._f64()

@@ -1,0 +1,128 @@
+"""Replay of the fused assembly kernel's index arithmetic on the host (run with -m gpu; the maps are built on the
+device by pf_pattern_build).
+
+k_assemble_v3 (csrc/pf_assemble.hip) prefetches UNCONDITIONALLY with clamped indices: every lane of every tile loads a
+visit record, a row pointer, four coordinate pairs and four densities whether or not the lane has a pair to integrate
+(commit 7bf4609 fixed a gather 15 nodes past the end of X that such a lane produced).  This test downloads
+tile_desc / vis_rec / n2e_ptr / nptr through pf_pattern_get_tiles and re-derives, in numpy, every index the kernel
+forms -- v3_load_tile, v3_load_rec, v3_load_visit, the LDS adds of v3_tile and its copy-out -- for all 64 lanes of all
+tiles plus the pipeline's look-ahead tiles, asserting that each one lies inside its array.  Meshes: ragged sizes around
+the 16-node / 64-pair tile limits, shuffled triangles, a valence-63 hub, runs of unused nodes, a last tile whose
+slots reach past the last node."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from pyfem_gpu_testflight_amd import pyfem
+
+    return pyfem
+
+
+def _replay(maps, nnodes, P, max_row_blocks, d):
+    td, vr, n2e, nptr, npt = maps["tile_desc"], maps["vis_rec"], maps["n2e_ptr"], maps["nptr"], maps["npt"]
+    ntiles, nvis = td.shape[0], vr.shape[0]
+    assert nvis == n2e[-1]
+    plane = npt * max_row_blocks + 1  # doubles per value plane of the LDS image (k_assemble_v3: `plane`)
+    lanes = np.arange(64)
+    covered_nodes = covered_vis = covered_blocks = 0
+    # the kernel reads descriptors min(t, t1 - 1) for t up to 4 tiles ahead: always inside [0, ntiles)
+    for t in range(ntiles):
+        n0, vb, base, w = (int(v) for v in td[t])
+        nn_t, nv_t, nblk = w & 255, (w >> 8) & 255, (w >> 16) & 0xFFFF
+        assert 0 <= n0 and n0 + nn_t <= nnodes and 1 <= nn_t <= npt
+        assert nv_t <= 64 and vb == n2e[n0] and vb + nv_t == n2e[n0 + nn_t]
+        assert base == nptr[n0] and base + nblk == nptr[n0 + nn_t] and nblk <= npt * max_row_blocks
+        assert n0 == covered_nodes and vb == covered_vis and base == covered_blocks  # tiles partition everything
+        covered_nodes, covered_vis, covered_blocks = n0 + nn_t, vb + nv_t, base + nblk
+        # v3_load_rec: all 64 lanes
+        jj = vb + lanes
+        active = jj < vb + nv_t
+        rec = vr[np.minimum(jj, nvis - 1)]
+        assert (np.minimum(jj, nvis - 1) >= 0).all()
+        rp_idx = np.minimum(n0 + lanes, nnodes)
+        assert ((rp_idx >= 0) & (rp_idx <= nnodes)).all()  # nptr has nnodes + 1 entries
+        rp = nptr[rp_idx]
+        # v3_load_visit: all 64 lanes (gathers are unconditional)
+        wv = rec[:, 3].astype(np.int64) & 0xFFFFFFFF
+        a, ln = (wv >> 24) & 3, (wv >> 26) & 15
+        n = np.minimum(n0 + ln, nnodes - 1)
+        o = rec[:, :3].astype(np.int64)
+        nd = np.stack([np.where(a == 0, n, o[:, 0]),
+                       np.where(a == 1, n, np.where(a < 1, o[:, 0], o[:, 1])),
+                       np.where(a == 2, n, np.where(a < 2, o[:, 1], o[:, 2])),
+                       np.where(a == 3, n, o[:, 2])], axis=1)
+        assert ((nd >= 0) & (nd < nnodes)).all(), f"tile {t}: gather outside X / rho"
+        # lanes with a pair: the record belongs to node n0 + ln of this tile, positions stay inside the tile's image
+        la = np.flatnonzero(active)
+        assert (ln[la] < nn_t).all()
+        own = n0 + ln[la]
+        assert ((n2e[own] <= jj[la]) & (jj[la] < n2e[own + 1])).all(), "visit record filed under the wrong node"
+        assert (a[la] < P).all()
+        roff = rp[ln[la]] - rp[0]
+        for b in range(P):
+            pos = (wv[la] >> (6 * b)) & 63
+            blk = roff + pos
+            assert ((blk >= 0) & (blk < nblk)).all(), f"tile {t}: LDS add outside the tile's segment"
+            assert (pos < nptr[own + 1] - nptr[own]).all(), "position byte beyond the node's row"
+            assert (blk < plane).all()
+        # copy-out: pieces min(lane + 64 u, np - 1) of a segment of np = nblk * (2 if d == 2 else 1) pieces
+        np_ = nblk * (2 if d == 2 else 1)
+        if np_:
+            q = np.minimum(lanes[:, None] + 64 * np.arange(10)[None, :], np_ - 1)
+            assert (q >= 0).all() and ((q >> (1 if d == 2 else 0)) < nblk).all()
+    assert covered_nodes == nnodes and covered_vis == nvis and covered_blocks == nptr[-1]
+
+
+def _fan_mesh(k):
+    ang = 2 * np.pi * np.arange(k) / k
+    X = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    conn = np.stack([np.zeros(k, dtype=np.int64), 1 + np.arange(k), 1 + (np.arange(k) + 1) % k], axis=1)
+    return X, conn
+
+
+def _meshes(pf):
+    out = []
+    for nx, ny, et in ((13, 9, "quad"), (16, 16, "quad"), (17, 5, "quad"), (3, 2, "quad"), (11, 8, "tri"), (33, 2, "tri")):
+        c = pf.ProblemCreator(nnodes_x=nx, nnodes_y=ny, element_type=et)
+        conn, X, _, _ = c.create_linear_elasticity_problem()
+        out.append((f"{et}{nx}x{ny}", X, conn))
+    # shuffled triangles: valence / row lengths vary per wave
+    c = pf.ProblemCreator(nnodes_x=19, nnodes_y=14, element_type="tri")
+    conn, X, _, _ = c.create_linear_elasticity_problem()
+    rng = np.random.RandomState(4)
+    perm = rng.permutation(X.shape[0])
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    out.append(("tri_shuffled", X[perm], inv[conn][rng.permutation(conn.shape[0])]))
+    out.append(("fan63",) + _fan_mesh(63))
+    out.append(("fan30",) + _fan_mesh(30))
+    # 32 unused nodes in the middle and 5 at the end: empty tiles, and a last tile whose slots pass the last node
+    c = pf.ProblemCreator(nnodes_x=9, nnodes_y=7)
+    conn, X, _, _ = c.create_linear_elasticity_problem()
+    shift = np.where(np.arange(X.shape[0]) >= 20, 32, 0)
+    X2 = np.zeros((X.shape[0] + 32 + 5, 2))
+    X2[np.arange(X.shape[0]) + shift] = X
+    out.append(("gaps", X2, conn + shift[conn]))
+    return out
+
+
+@pytest.mark.parametrize("d", [1, 2])
+def test_every_index_the_assembly_kernel_forms_is_in_range(pf, d):
+    from pyfem_gpu_testflight_amd.device import HipContext
+
+    for name, X, conn in _meshes(pf):
+        conn = np.asarray(conn)
+        if name == "gaps":  # pf_mesh_set asserts conn spans 0..nnodes-1 (pyfem.py:680-681): make the last node used
+            conn = conn.copy()
+            conn[-1, 2] = X.shape[0] - 1
+        h = HipContext(X, conn, d)
+        maps = h.assembly_maps()
+        _replay(maps, h.nnodes, h.P, h.max_row_blocks, d)
+        h.close()
