@@ -102,13 +102,22 @@ def _manufactured_elasticity(pf, orc, X, conn, dof_fixed, etype, rho=None, p=0.0
     return relmax(u, ustar), asm.last_iters
 
 
-def _direct(K, b):
-    """Sparse LU of a symmetric matrix with a minimum-degree ordering of A + A^T and one refinement step."""
+def _factor(K):
+    """Sparse LU of a symmetric matrix with a minimum-degree ordering of A + A^T; returns solve(b) with one
+    refinement step."""
     from scipy.sparse.linalg import splu
 
     lu = splu(K.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
-    u = lu.solve(b)
-    return u + lu.solve(b - K @ u)
+
+    def solve(b):
+        u = lu.solve(b)
+        return u + lu.solve(b - K @ u)
+
+    return solve
+
+
+def _direct(K, b):
+    return _factor(K)(b)
 
 
 # ---- C2 ---------------------------------------------------------------------------------------------------------
@@ -152,21 +161,20 @@ def test_c3_helmholtz_apply_against_sparse_lu_and_full_size_properties(pf, orc):
     """tests/test_helmholtz.py:11-44 at 1024x1024 against the oracle's factorised filter (the reference's own check),
     then 2048x2048: apply_gradient of a manufactured right-hand side K rho* must return R rho* (exact at any size),
     and apply's true residual || R x - K rho || / || R x ||."""
-    from scipy import sparse
-
     q, b = _qb(pf, "quad")
     n = 1024
     conn, X = orc.structured_mesh(n + 1, n + 1, "quad")
     x = orc.helmholtz_input(n + 1, n + 1)
     Ke, Re = orc.helmholtz_Ke_Re(X, conn, "quad", 0.05)
     Ko, Ro = orc.assemble_csr(Ke, conn), orc.assemble_csr(Re, conn)
-    rho_lu = _direct(Ko, Ro @ x)
+    lu = _factor(Ko)
+    rho_lu = lu(Ro @ x)
     filtr = pf.Helmholtz(0.05, X, conn, q, b)
     rho = filtr.apply(x)
     assert relmax(rho, rho_lu) < U_TOL
     g = np.cos(7 * X[:, 0]) + X[:, 1]
-    assert relmax(filtr.apply_gradient(g), Ro.T @ _direct(Ko, g)) < U_TOL
-    del filtr, Ko, Ro, rho_lu
+    assert relmax(filtr.apply_gradient(g), Ro.T @ lu(g)) < U_TOL
+    del filtr, Ko, Ro, rho_lu, lu
 
     n = 2048
     conn, X = orc.structured_mesh(n + 1, n + 1, "quad")
