@@ -28,7 +28,6 @@
 #include "pf_common.h"
 
 static constexpr double GP = 0.5773502691896258;  // 1/sqrt(3), == 1.0/np.sqrt(3.0)  (pyfem.py:87-90)
-static constexpr int LDS_STRIDE = 65;             // doubles between consecutive slots of the tile
 
 // ------------------------------------------------------------------------------------------
 // element geometry at one quadrature point: det J, grad N (global), N
@@ -138,8 +137,10 @@ __device__ __forceinline__ void tri_point(const Elem<3>& el, Own& own, double& d
   Ny[1] = i11;
   Nx[2] = -i00 - i10;
   Ny[2] = -i01 - i11;
-  own.Nxa = fma(own.s0, i00, own.s1 * i10);
-  own.Nya = fma(own.s0, i01, own.s1 * i11);
+  // own.s0 / s1 are compile-time constants at every call site (local index known after inlining): pick the form the
+  // compiler can fold (0.0 * x is not foldable under IEEE rules, 1.0 * x is)
+  own.Nxa = (own.s1 == 0.0) ? own.s0 * i00 : (own.s0 == 0.0) ? own.s1 * i10 : fma(own.s0, i00, own.s1 * i10);
+  own.Nya = (own.s1 == 0.0) ? own.s0 * i01 : (own.s0 == 0.0) ? own.s1 * i11 : fma(own.s0, i01, own.s1 * i11);
 }
 
 template <int P>
@@ -310,115 +311,128 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 }
 
 // ------------------------------------------------------------------------------------------
-// GATHER assembly v3 (default): lane = incident (node, element) pair, tile = npt consecutive nodes.
+// GATHER assembly v4 (default): lane = incident (node, element) pair, tile = up to npt consecutive nodes.
 //
-// The measurements that led here (profiles/r01_*): with lane = node the accumulator tile is
+// The measurements that led here (profiles/r01_*, r02_*): with lane = node the accumulator tile is
 // 18.7 KB per 64 nodes, which caps a CU at 8 tiles; every tile then pays its dependent load chain,
-// its quadrature and its store drain back to back (phases measured additive: 172 + 132 + 184 us) and
-// boundary/irregular nodes leave lanes idle.  Here
+// its quadrature and its store drain back to back and boundary/irregular nodes leave lanes idle.  Here
 //   * each lane integrates ONE incident element for one node (perfect load balance for any
 //     valence); a tile is the npt nodes (16 for quads) whose <= 64 incident pairs fill the wave;
 //   * the tile's rows are ONE contiguous segment of the value array, and the LDS accumulator is an
 //     exact image of that segment (4.6 KB for quads): contributions go in with LDS fp64 atomic adds
 //     at (row offset + position byte), the write-out is a straight 16-byte-per-lane copy -- no maps,
-//     no barriers, 4x less LDS per wave than v1/v2;
+//     no barriers;
 //   * waves are persistent and software-pipelined: row pointers two tiles ahead, the visit records
 //     one tile ahead, the coordinate gathers of the next tile in flight during the quadrature of the
 //     current one.  Every wait targets loads that were issued BEFORE the latest stores (vmcnt retires
 //     in issue order, stores included), so the store drain of tile t overlaps the work of tile t+1.
+// v4 (round 2) is an INSTRUCTION diet of v3: the r02 ISA count showed ~330 wave instructions per 10-node triangle
+// tile, 4 issue cycles each on a 16-lane SIMD -- more than half of the kernel's time is instruction issue, most of it
+// integer bookkeeping, not fp64:
+//   * the element is rotated so that the lane's node is local node 0 (pf_pattern.hip k_build_visits): no selects on
+//     the local index, constant shape-function signs;
+//   * every global access is a BUFFER access (raw buffer resources built with scalar instructions): one 32-bit
+//     offset per gather instead of 64-bit address arithmetic, and the hardware's range check replaces every clamp --
+//     lanes without a pair read zeros (= node 0, in range) and store nothing; the copy-out is `buffer_store_dwordx4`
+//     with an immediate offset per piece against a resource that ends where the tile's segment ends;
+//   * the image is cleared with flat 16-byte LDS stores; the copy-out reads LDS at immediate offsets from two
+//     per-lane base addresses computed once per tile.
 // Summation order inside a tile is fixed by the instruction stream (same lanes, same addresses every
 // run), so results are bitwise reproducible although the adds are LDS atomics.
-// dynamic LDS: double2 img[npt*maxrow*V/2]
+// dynamic LDS: double img[V*plane + 32*NOUT]  (V planes of `plane` = npt*maxrow + 1 doubles)
 // ------------------------------------------------------------------------------------------
-struct V3Rec {        // stage B: the lane's visit record + the tile's row pointers (one tile ahead)
-  int4 rec;           // {o0, o1, o2, w}: other node ids of the element, w = packed pos/a/ln (pf_pattern.hip)
-  int32_t rp;         // lanes 0..npt: nptr[n0 + lane]
-  int32_t n0;         // first node of the tile
+typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
+typedef double pf_f64x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t pf_rsrc;
+
+// raw buffer (stride 0): offsets and num_records in bytes; out-of-range loads return 0, stores are dropped
+__device__ __forceinline__ pf_rsrc make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2 buf_ld_f64x2(pf_rsrc r, uint32_t off) {
+  const pf_f64x2 v = __builtin_bit_cast(pf_f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double buf_ld_f64(pf_rsrc r, uint32_t off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+
+struct V4Rec {        // stage B: the lane's visit record + the tile's row pointers (one tile ahead)
+  int4 rec;           // {o1, o2, o3, w}: rotated element, own node first (pf_pattern.hip k_build_visits)
+  int32_t rp;         // lanes 0..nodes of the tile: nptr[n0 + lane]
+  int32_t n0, base;   // first node / first block of the tile
   bool active;
 };
 
 template <int P, bool RHO>
-struct V3Visit {      // stage C: what the quadrature needs (gathers in flight during the previous tile)
+struct V4Visit {      // stage C: what the quadrature needs (gathers in flight during the previous tile)
   Elem<P> el;
   double rho_e[P];
-  uint32_t w;         // packed positions / local index
+  uint32_t w;         // packed positions
   int32_t roff;       // first block of the lane's node inside the tile segment
   bool active;
 };
 
-struct V3Tile {       // wave-uniform tile scalars (scalar loads, two tiles ahead)
-  int32_t vb, ve, base, nblk, n0;
+struct V4Tile {       // wave-uniform tile scalars (one 16-byte scalar load, two tiles ahead)
+  int32_t vb, nv, base, nblk, n0, nn;
 };
 
 // NOTE: the pipeline stages are free __forceinline__ functions, not lambdas: hipcc keeps local arrays of
 // a lambda that is inlined at two call sites in scratch memory (seen twice in this file's history).
-
-// All prefetch loads are UNCONDITIONAL with clamped indices: a load under `if (active)` that is merged
-// with a default at the join makes hipcc wait for it on the spot (s_waitcnt vmcnt right behind the
-// issue), which exposes a full memory latency per tile.
-__device__ __forceinline__ V3Tile v3_load_tile(int64_t t, int64_t t1, const int4* __restrict__ tile_desc) {
-  V3Tile T;  // t is wave-uniform: ONE 16-byte scalar load
+// All prefetch loads are UNCONDITIONAL: a load under `if (active)` that is merged with a default at the join makes
+// hipcc wait for it on the spot (s_waitcnt vmcnt right behind the issue), which exposes a full memory latency per
+// tile.  The buffer resources make that safe without clamps.
+__device__ __forceinline__ V4Tile v4_load_tile(int64_t t, int64_t t1, const int4* __restrict__ tile_desc) {
+  V4Tile T;  // t is wave-uniform; look-ahead past the wave's last tile re-reads that tile's descriptor with no pairs
   const int4 dsc = tile_desc[min(t, t1 - 1)];
   T.n0 = dsc.x;
   T.vb = dsc.y;
-  T.ve = (t < t1) ? dsc.y + ((dsc.w >> 8) & 255) : dsc.y;
   T.base = dsc.z;
+  T.nn = dsc.w & 255;
+  T.nv = (t < t1) ? ((dsc.w >> 8) & 255) : 0;
   T.nblk = (int32_t)((uint32_t)dsc.w >> 16);
   return T;
 }
 
-template <int ABL = 0>
-__device__ __forceinline__ V3Rec v3_load_rec(const V3Tile& T, int lane, int32_t nvis, int64_t nnodes,
-                                             const int4* __restrict__ vis_rec, const int32_t* __restrict__ nptr) {
-  V3Rec B;
-  const int32_t jj = T.vb + lane;
-  B.active = jj < T.ve;
+__device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const int4* __restrict__ vis_rec,
+                                             const int32_t* __restrict__ nptr) {
+  V4Rec B;
+  B.active = lane < T.nv;
   B.n0 = T.n0;
-  if constexpr (ABL & 16) {  // ablation: no record stream (fake positions inside the first row)
-    B.rec = make_int4(T.n0, T.n0 + 1, T.n0 + 2, (int)((lane & 3) | (1 << 6) | (2 << 12) | (3 << 18) | ((lane & 3) << 24) | ((lane >> 2) << 26)));
-  } else {
-    B.rec = vis_rec[min(jj, nvis - 1)];
-  }
-  B.rp = nptr[min((int64_t)T.n0 + lane, nnodes)];
+  B.base = T.base;
+  const pf_rsrc rr = make_rsrc(vis_rec + T.vb, (uint32_t)T.nv * 16u);         // this tile's records only
+  const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);      // and its nn + 1 row pointers
+  const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
+  B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);
+  B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
   return B;
 }
 
-template <int P, bool RHO, int ABL = 0>
-__device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __restrict__ X,
-                                              const double* __restrict__ rho, V3Visit<P, RHO>& C, int32_t nlast) {
+template <int P, bool RHO>
+__device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C) {
   const uint32_t w = (uint32_t)B.rec.w;
-  const int a = (int)((w >> 24) & 3), ln = (int)((w >> 26) & 15);
+  const int ln = (int)((w >> 26) & 15);
   C.w = w;
   C.active = B.active;
-  C.roff = __shfl(B.rp, ln) - __shfl(B.rp, 0);
-  // the lane's own node; clamped, because a lane past the tile's last pair carries the slot of another tile's record
-  // and n0 + slot can then lie beyond the last node (its gathers are unconditional, their values unused)
-  const int32_t n = min(B.n0 + ln, nlast);
-  int32_t nd[4];
-  nd[0] = (a == 0) ? n : B.rec.x;
-  nd[1] = (a == 1) ? n : ((a < 1) ? B.rec.x : B.rec.y);
-  nd[2] = (a == 2) ? n : ((a < 2) ? B.rec.y : B.rec.z);
-  nd[3] = (a == 3) ? n : B.rec.z;
-  if constexpr (ABL & 16) {  // ablation: no coordinate gathers
-#pragma unroll
-    for (int b = 0; b < P; ++b) { C.el.x[b] = (double)nd[b]; C.el.y[b] = (double)(nd[b] + b); C.rho_e[b] = 1.0; }
-    return;
-  }
-  const double2 p0 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[0]);
-  const double2 p1 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[1]);
-  const double2 p2 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[2]);
+  C.roff = __shfl(B.rp, ln) - B.base;
+  // a lane without a pair holds an all-zero record: its gathers read node n0 and node 0, both in range
+  const uint32_t n = (uint32_t)(B.n0 + ln);
+  const double2 p0 = buf_ld_f64x2(RX, n * 16u);
+  const double2 p1 = buf_ld_f64x2(RX, (uint32_t)B.rec.x * 16u);
+  const double2 p2 = buf_ld_f64x2(RX, (uint32_t)B.rec.y * 16u);
   C.el.x[0] = p0.x; C.el.y[0] = p0.y;
   C.el.x[1] = p1.x; C.el.y[1] = p1.y;
   C.el.x[2] = p2.x; C.el.y[2] = p2.y;
   if constexpr (P == 4) {
-    const double2 p3 = *reinterpret_cast<const double2*>(X + 2 * (int64_t)nd[3]);
+    const double2 p3 = buf_ld_f64x2(RX, (uint32_t)B.rec.z * 16u);
     C.el.x[3] = p3.x; C.el.y[3] = p3.y;
   }
   if constexpr (RHO) {
-    C.rho_e[0] = rho[nd[0]];
-    C.rho_e[1] = rho[nd[1]];
-    C.rho_e[2] = rho[nd[2]];
-    if constexpr (P == 4) C.rho_e[3] = rho[nd[3]];
+    C.rho_e[0] = buf_ld_f64(Rrho, n * 8u);
+    C.rho_e[1] = buf_ld_f64(Rrho, (uint32_t)B.rec.x * 8u);
+    C.rho_e[2] = buf_ld_f64(Rrho, (uint32_t)B.rec.y * 8u);
+    if constexpr (P == 4) C.rho_e[3] = buf_ld_f64(Rrho, (uint32_t)B.rec.z * 8u);
   } else {
 #pragma unroll
     for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
@@ -430,113 +444,113 @@ __device__ __forceinline__ void v3_load_visit(const V3Rec& B, const double* __re
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
 // 8 of the 32 banks (PMC counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
 // touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
-template <int P, class Phys, bool RHO, int NOUT, int ABL>
-__device__ __forceinline__ void v3_tile(const typename Phys::Params& pr, const V3Tile& Tcur,
-                                        const V3Visit<P, RHO>& Cuse, double* img, int plane, int lane,
-                                        double* __restrict__ out0, double* __restrict__ out1,
-                                        double* __restrict__ trash) {
+template <int P, class Phys, bool RHO, int NOUT>
+__device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V4Tile& Tcur,
+                                        const V4Visit<P, RHO>& Cuse, double* img, int plane, int lane,
+                                        double* __restrict__ out0, double* __restrict__ out1) {
   constexpr int V = Phys::V;
-  constexpr int VH = (V == 4) ? 2 : 1;  // 16-byte pieces (d=2) or entries (d=1) per coupling
-  const int32_t nblk = Tcur.nblk;
-  // zero the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
-#pragma unroll
-  for (int k = 0; k < V; ++k)
-    for (int32_t q = lane; q < nblk; q += 64) img[k * plane + q] = 0.0;
+  // clear the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
+  {  // whole 1 KiB wave stores, a wave-uniform trip count (scalar loop): the allocation is rounded up to that
+    pf_f64x2* img2 = reinterpret_cast<pf_f64x2*>(img) + lane;
+    const int nzit = (V * plane + 127) >> 7;
+    const pf_f64x2 z = {0.0, 0.0};
+    for (int it = 0; it < nzit; ++it) img2[64 * it] = z;
+  }
 
   if (Cuse.active) {
-    const int a = (int)((Cuse.w >> 24) & 3);
-    const int roff = Cuse.roff;
     double v[P][V];
-    if constexpr (ABL & 1) {
-#pragma unroll
-      for (int b = 0; b < P; ++b)
-#pragma unroll
-        for (int k = 0; k < V; ++k) v[b][k] = Cuse.el.x[b] + (double)(k + a);
-    } else {
-      element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, a, v);
-    }
+    element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, 0, v);  // the lane's node is local node 0 (rotated record)
+    double* row = img + Cuse.roff;
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      const int blk = roff + (int)((Cuse.w >> (6 * b)) & 63);
+      double* dst = row + (int)((Cuse.w >> (6 * b)) & 63);
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        if constexpr (ABL & 8) img[k * plane + blk] = v[b][k];  // ablation: plain LDS store (wrong sums)
-        else __hip_atomic_fetch_add(img + k * plane + blk, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
+      for (int k = 0; k < V; ++k)
+        __hip_atomic_fetch_add(dst + k * plane, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
   }
 
-  // copy-out: 16 bytes per lane, 1 KiB contiguous per wave store.  STATIC store count (NOUT > 0): pieces
-  // past the end are clamped to the last piece (the same 16 bytes rewritten with the same value); with a
-  // data-dependent number of stores hipcc cannot count what is in flight behind a prefetch and falls back
-  // to s_waitcnt vmcnt(0), i.e. to draining the stores.  A tile of isolated nodes has no blocks: its
-  // stores go to a trash line instead of a branch.
-  const int32_t np = ((ABL & 4) ? min(nblk, 1) : nblk) * VH;
-  const int64_t base = Tcur.base;
-  const bool any = np > 0;
-  double2* d4 = any ? reinterpret_cast<double2*>(out0) + 2 * base : reinterpret_cast<double2*>(trash);
-  double* d0 = any ? out0 + base : trash;
-  double* d1 = (any && V == 2) ? out1 + base : trash + 1;
-  if constexpr (NOUT > 0) {
+  // copy-out: one buffer resource that covers exactly the tile's segment; pieces past its end are dropped by the
+  // hardware, so the store COUNT is static (NOUT > 0: hipcc can then count what is in flight behind a prefetch and
+  // keeps every s_waitcnt vmcnt partial) without clamps or branches; an empty tile (isolated nodes) stores nothing.
+  const int32_t nblk = Tcur.nblk;
+  if constexpr (V == 4) {
+    const pf_rsrc ro = make_rsrc(out0 + 4 * (int64_t)Tcur.base, (uint32_t)nblk * 32u);
+    // piece q = lane + 64 u = values (2 (q & 1), 2 (q & 1) + 1) of block q >> 1:  (q >> 1) = (lane >> 1) + 32 u
+    const double* a0 = img + (lane & 1) * 2 * plane + (lane >> 1);
+    const double* a1 = a0 + plane;
+    if constexpr (NOUT > 0) {
 #pragma unroll
-    for (int u = 0; u < NOUT; ++u) {
-      const int32_t q = any ? min(lane + 64 * u, np - 1) : 0;
-      if constexpr (V == 4) {
-        const int32_t tb = q >> 1, h2 = (q & 1) * 2;
-        d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
-      } else {
-        d0[q] = img[q];
-        if constexpr (V == 2) d1[q] = img[plane + q];
+      for (int u = 0; u < NOUT; ++u) {
+        const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
+      }
+    } else {
+      for (int u = 0; 32 * u < nblk; ++u) {
+        const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
       }
     }
   } else {
-    for (int32_t q = lane; q < np; q += 64) {
-      if constexpr (V == 4) {
-        const int32_t tb = q >> 1, h2 = (q & 1) * 2;
-        d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
-      } else {
-        if (out0) out0[base + q] = img[q];
+    const pf_rsrc r0 = make_rsrc(out0 ? out0 + Tcur.base : nullptr, out0 ? (uint32_t)nblk * 8u : 0u);
+    const pf_rsrc r1 = make_rsrc((V == 2 && out1) ? out1 + Tcur.base : nullptr, (V == 2 && out1) ? (uint32_t)nblk * 8u : 0u);
+    const double* a0 = img + lane;
+    if constexpr (NOUT > 0) {
+#pragma unroll
+      for (int u = 0; u < NOUT; ++u) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[64 * u]), r0, lane * 8 + 512 * u, 0, 0);
         if constexpr (V == 2)
-          if (out1) out1[base + q] = img[plane + q];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[plane + 64 * u]), r1, lane * 8 + 512 * u, 0, 0);
+      }
+    } else {
+      for (int u = 0; 64 * u < nblk; ++u) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[64 * u]), r0, lane * 8 + 512 * u, 0, 0);
+        if constexpr (V == 2)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[plane + 64 * u]), r1, lane * 8 + 512 * u, 0, 0);
       }
     }
   }
 }
 
-template <int P, class Phys, bool RHO, int NOUT, int ABL = 0>
-__global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
+#ifndef PF_V4_WPE
+#define PF_V4_WPE 3
+#endif
+template <int P, class Phys, bool RHO, int NOUT>
+__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int4* __restrict__ tile_desc,
-                                                    const int4* __restrict__ vis_rec, int32_t nvis, int32_t strided,
+                                                    const int4* __restrict__ vis_rec, int32_t strided,
                                                     typename Phys::Params pr, double* __restrict__ out0,
-                                                    double* __restrict__ out1, double* __restrict__ trash) {
+                                                    double* __restrict__ out1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* const img = reinterpret_cast<double*>(smem);
   const int plane = npt * maxrow + 1;  // odd plane stride: the V planes start on different banks
   const int lane = threadIdx.x;
   // tile walk: contiguous run per wave (tstride == 1) or round-robin over the grid (tstride == gridDim)
   // strided == 2: XCD-aware round-robin.  Workgroups are dealt to the 8 XCDs round-robin (b % 8), so with
-  // the plain strided walk neighbouring tiles always sit on different XCDs: the cache line shared by two
-  // adjacent segments is then written back partially by two L2s.  Renumber the blocks so that one XCD's
+  // the plain strided walk neighbouring tiles always sit on different XCDs.  Renumber the blocks so that one XCD's
   // blocks take a contiguous eighth of every grid-wide row of tiles.
   const int64_t tstride = strided ? gridDim.x : 1;
   const int64_t vblk = (strided == 2) ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const int64_t t0 = strided ? vblk : ntiles * blockIdx.x / gridDim.x;
   const int64_t t1 = strided ? ntiles : ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
+  // resources of the gathered arrays (the host checked that nnodes * 16 fits 32 bits)
+  const pf_rsrc RX = make_rsrc(X, (uint32_t)nnodes * 16u);
+  const pf_rsrc Rrho = make_rsrc(pr.rho, pr.rho ? (uint32_t)nnodes * 8u : 0u);
 
   // Pipeline state.  Two register sets (a/b) are used on alternate tiles, so nothing a load is about to
   // write is ever copied: a rotation by copy would have to wait for the loads just issued.
-  V3Tile T0 = v3_load_tile(t0, t1, tile_desc);
-  V3Tile T1 = v3_load_tile(t0 + tstride, t1, tile_desc);
-  V3Tile T2 = v3_load_tile(t0 + 2 * tstride, t1, tile_desc);
-  V3Rec Ba = v3_load_rec<ABL>(T0, lane, nvis, nnodes, vis_rec, nptr);
-  V3Rec Bb = v3_load_rec<ABL>(T1, lane, nvis, nnodes, vis_rec, nptr);
-  V3Visit<P, RHO> Ca, Cb;
-  v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca, (int32_t)nnodes - 1);
+  V4Tile T0 = v4_load_tile(t0, t1, tile_desc);
+  V4Tile T1 = v4_load_tile(t0 + tstride, t1, tile_desc);
+  V4Tile T2 = v4_load_tile(t0 + 2 * tstride, t1, tile_desc);
+  V4Rec Ba = v4_load_rec(T0, lane, vis_rec, nptr);
+  V4Rec Bb = v4_load_rec(T1, lane, vis_rec, nptr);
+  V4Visit<P, RHO> Ca, Cb;
+  v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
-  // load" (prologue: needs vmcnt(0)) with "five stores are younger than it" (back edge: vmcnt(5) is
+  // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
   asm volatile("" ::"v"(Bb.rec.x), "v"(Bb.rec.y), "v"(Bb.rec.z), "v"(Bb.rec.w), "v"(Bb.rp));
   asm volatile("" ::"v"(Ca.el.x[0]), "v"(Ca.el.x[1]), "v"(Ca.el.x[2]), "v"(Ca.el.y[0]), "v"(Ca.el.y[1]), "v"(Ca.el.y[2]));
@@ -548,149 +562,18 @@ __global__ __launch_bounds__(64) void k_assemble_v3(int64_t nnodes, int64_t ntil
   int64_t t = t0;
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
-    const V3Tile T3 = v3_load_tile(t + 3 * tstride, t1, tile_desc);
-    v3_load_visit<P, RHO, ABL>(Bb, X, pr.rho, Cb, (int32_t)nnodes - 1);
-    Ba = v3_load_rec<ABL>(T2, lane, nvis, nnodes, vis_rec, nptr);
-    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);
+    const V4Tile T3 = v4_load_tile(t + 3 * tstride, t1, tile_desc);
+    v4_load_visit<P, RHO>(Bb, RX, Rrho, Cb);
+    Ba = v4_load_rec(T2, lane, vis_rec, nptr);
+    v4_tile<P, Phys, RHO, NOUT>(pr, T0, Ca, img, plane, lane, out0, out1);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
-    const V3Tile T4 = v3_load_tile(t + 4 * tstride, t1, tile_desc);
-    v3_load_visit<P, RHO, ABL>(Ba, X, pr.rho, Ca, (int32_t)nnodes - 1);
-    Bb = v3_load_rec<ABL>(T3, lane, nvis, nnodes, vis_rec, nptr);
-    v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T1, Cb, img, plane, lane, out0, out1, trash);
+    const V4Tile T4 = v4_load_tile(t + 4 * tstride, t1, tile_desc);
+    v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca);
+    Bb = v4_load_rec(T3, lane, vis_rec, nptr);
+    v4_tile<P, Phys, RHO, NOUT>(pr, T1, Cb, img, plane, lane, out0, out1);
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (t < t1) v3_tile<P, Phys, RHO, NOUT, ABL>(pr, T0, Ca, img, plane, lane, out0, out1, trash);  // odd tail
-}
-
-// ------------------------------------------------------------------------------------------
-// GATHER assembly: one workgroup of NW waves per 64 consecutive nodes.
-//   lane  = node (owns the node's d rows of K)
-//   wave w handles incident elements w, w+NW, ... of every node of the tile, so the dependent
-//   n2e -> conn -> X load chain is paid once per wave instead of once per incident element and
-//   NW times more waves are in flight per LDS byte (the r01 profile showed 61 % of wave cycles
-//   waiting on that chain at 8 waves/CU).
-//   The LDS tile is shared by the NW waves; the adds into it are ordered by incident-element
-//   index with workgroup barriers, so the summation order (ascending element id) and hence the
-//   result is bitwise reproducible.
-// dynamic LDS: double acc[max_row_blocks*V*65] ; int32 prefix[64] ; uint8 owner[64*max_row_blocks]
-// ------------------------------------------------------------------------------------------
-template <int P, class Phys, bool RHO, int NW, int ABL = 0>
-__global__ __launch_bounds__(64 * NW, NW) void k_assemble_gather(int64_t nnodes, int32_t maxrow, int32_t maxval,
-                                                             const double* __restrict__ X,
-                                                             const int32_t* __restrict__ conn,
-                                                             const int32_t* __restrict__ nptr,
-                                                             const int32_t* __restrict__ n2e_ptr,
-                                                             const int32_t* __restrict__ n2e,
-                                                             const uint8_t* __restrict__ n2e_pos,
-                                                             typename Phys::Params pr, double* __restrict__ out0,
-                                                             double* __restrict__ out1) {
-  constexpr int V = Phys::V;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* acc = reinterpret_cast<double*>(smem);
-  int32_t* prefix = reinterpret_cast<int32_t*>(acc + (size_t)maxrow * V * LDS_STRIDE);
-  uint8_t* owner = reinterpret_cast<uint8_t*>(prefix + 64);
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t n0 = (int64_t)blockIdx.x * 64;
-  const int64_t n = n0 + lane;
-  const bool valid = n < nnodes;
-  const int32_t rowbase = valid ? nptr[n] : 0;
-  const int32_t cnt = valid ? nptr[n + 1] - rowbase : 0;
-  const int32_t jb = valid ? n2e_ptr[n] : 0;
-  const int32_t nj = valid ? n2e_ptr[n + 1] - jb : 0;
-
-  // exclusive wave scan of cnt (every wave computes it; wave 0 publishes)
-  int32_t incl = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int32_t t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  const int32_t pre = incl - cnt;
-  const int32_t total = __shfl(incl, 63);
-  const int32_t wavebase = __shfl(rowbase, 0);
-  if (wave == 0) {
-    prefix[lane] = pre;
-    for (int c = 0; c < cnt; ++c) owner[pre + c] = (uint8_t)lane;
-  }
-  for (int s = wave; s < cnt * V; s += NW) acc[s * LDS_STRIDE + lane] = 0.0;
-  __syncthreads();
-
-  for (int32_t r0 = 0; r0 < maxval; r0 += NW) {
-    const int32_t j = r0 + wave;
-    const bool has = j < nj;
-    double v[P][V];
-    uint8_t pos[P];
-    if (has) {
-      const int32_t jj = jb + j;
-      const int32_t ea = n2e[jj];
-      const int32_t e = ea / P;
-      const int a = ea - e * P;
-      int32_t nd[P];
-      load_conn<P>(conn, e, nd);
-      if constexpr (P == 4) {
-        const uint32_t pk = *reinterpret_cast<const uint32_t*>(n2e_pos + 4 * (int64_t)jj);
-        pos[0] = pk & 255; pos[1] = (pk >> 8) & 255; pos[2] = (pk >> 16) & 255; pos[3] = pk >> 24;
-      } else {
-#pragma unroll
-        for (int b = 0; b < P; ++b) pos[b] = n2e_pos[4 * (int64_t)jj + b];
-      }
-      if constexpr (ABL & 1) {  // ablation: no quadrature (keeps the index loads)
-#pragma unroll
-        for (int b = 0; b < P; ++b)
-#pragma unroll
-          for (int k = 0; k < V; ++k) v[b][k] = (double)(nd[b] + k + a);
-      } else {
-        element_rows<P, Phys, RHO>(pr, X, nd, a, v);
-      }
-    }
-    // ordered accumulate: incident element r0+0, r0+1, ... (fixed order => reproducible sums)
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if (w == wave && has) {
-        if constexpr (ABL & 2) {  // ablation: no LDS accumulate (one add keeps v alive)
-          double t = 0.0;
-#pragma unroll
-          for (int b = 0; b < P; ++b)
-#pragma unroll
-            for (int k = 0; k < V; ++k) t += v[b][k];
-          acc[pos[0] * V * LDS_STRIDE + lane] += t;
-        } else {
-#pragma unroll
-          for (int b = 0; b < P; ++b)
-#pragma unroll
-            for (int k = 0; k < V; ++k) acc[(pos[b] * V + k) * LDS_STRIDE + lane] += v[b][k];
-        }
-      }
-      __syncthreads();
-    }
-  }
-
-  // coalesced write-out: thread t takes coupling (block) t of the tile's contiguous range
-  if constexpr (V == 4) {
-    // thread t stores the t-th 16-byte half block: a wave store covers 1 KiB contiguous
-    const int32_t total2 = (ABL & 4) ? min(total, 1) : 2 * total;  // ABL&4: no write-out
-    double2* dst = reinterpret_cast<double2*>(out0 + 4 * (int64_t)wavebase);
-    for (int32_t q = threadIdx.x; q < total2; q += 64 * NW) {
-      const int32_t tb = q >> 1;
-      const int hb = (q & 1) * 2;
-      const int o = owner[tb];
-      const int c = tb - prefix[o];
-      double2 v2;
-      v2.x = acc[(c * 4 + hb) * LDS_STRIDE + o];
-      v2.y = acc[(c * 4 + hb + 1) * LDS_STRIDE + o];
-      dst[q] = v2;
-    }
-  } else {
-    for (int32_t tb = threadIdx.x; tb < ((ABL & 4) ? min(total, 1) : total); tb += 64 * NW) {
-      const int o = owner[tb];
-      const int c = tb - prefix[o];
-      const int64_t g = (int64_t)wavebase + tb;
-      if (out0) out0[g] = acc[(c * 2 + 0) * LDS_STRIDE + o];
-      if (out1) out1[g] = acc[(c * 2 + 1) * LDS_STRIDE + o];
-    }
-  }
+  if (t < t1) v4_tile<P, Phys, RHO, NOUT>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -710,13 +593,8 @@ __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const d
   if (n >= nnodes) return;
   double acc = 0.0;
   for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
-    const int4 rec = vis_rec[jj];
-    const int a = (int)(((uint32_t)rec.w >> 24) & 3);
-    int32_t nd[4];
-    nd[0] = (a == 0) ? (int32_t)n : rec.x;
-    nd[1] = (a == 1) ? (int32_t)n : ((a < 1) ? rec.x : rec.y);
-    nd[2] = (a == 2) ? (int32_t)n : ((a < 2) ? rec.y : rec.z);
-    nd[3] = (a == 3) ? (int32_t)n : rec.z;
+    const int4 rec = vis_rec[jj];  // rotated element: n is its local node 0 (pf_pattern.hip k_build_visits)
+    const int32_t nd[4] = {(int32_t)n, rec.x, rec.y, rec.z};
     Elem<P> el;
     double rho_e[P], fx[P], fy[P], gx[P], gy[P];
 #pragma unroll
@@ -733,7 +611,7 @@ __global__ __launch_bounds__(128) void k_sens_elasticity(int64_t nnodes, const d
         fx[b] = f.x; fy[b] = f.y; gx[b] = g.x; gy[b] = g.y;
       }
     }
-    Own own = make_own<P>(a);
+    Own own = make_own<P>(0);
     auto point = [&](double det, double w, const double* N, const double* Nx, const double* Ny) {
       double rq = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
 #pragma unroll
@@ -923,108 +801,45 @@ static inline ElasticityParams make_elasticity(double E, double nu, double p, co
   return pr;
 }
 
-static size_t gather_lds_bytes(int maxrow, int V) {
-  size_t b = (size_t)maxrow * V * LDS_STRIDE * sizeof(double) + 64 * sizeof(int32_t) + (size_t)64 * maxrow;
-  return (b + 15) & ~(size_t)15;
-}
-
-static constexpr int GATHER_NW = 2;  // waves per 64-node tile of the legacy kernel
-
-template <int P, class Phys, bool RHO>
-static int launch_gather_legacy(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
-  const size_t lds = gather_lds_bytes(ctx->max_row_blocks, Phys::V);
-  if (lds > 160 * 1024)
-    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node valence too high for the LDS row tile");
-  auto kern = k_assemble_gather<P, Phys, RHO, GATHER_NW>;
-  int nw = GATHER_NW;
-  if constexpr (P == 4 && Phys::V == 4 && !RHO) {
-    const char* e = pf_exp_env("PF_GATHER_NW");
-    const char* ab = pf_exp_env("PF_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
-    if (e) nw = atoi(e);
-    if (nw != 1 && nw != 4) nw = 2;
-#ifdef PF_EXPERIMENTS
-#define PF_PICK(NWV)                                                          \
-    if (nw == NWV) {                                                          \
-      if (abl == 1) kern = k_assemble_gather<P, Phys, RHO, NWV, 1>;           \
-      else if (abl == 4) kern = k_assemble_gather<P, Phys, RHO, NWV, 4>;      \
-      else if (abl == 5) kern = k_assemble_gather<P, Phys, RHO, NWV, 5>;      \
-      else kern = k_assemble_gather<P, Phys, RHO, NWV, 0>;                    \
-    }
-    PF_PICK(1) PF_PICK(2) PF_PICK(4)
-#undef PF_PICK
-#else
-    (void)abl;
-#endif
-  }
-  if (lds > 48 * 1024)
-    PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const unsigned grid = (unsigned)cdiv(ctx->nnodes, 64);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), lds, ctx->stream, ctx->nnodes, ctx->max_row_blocks,
-                     ctx->max_valence, ctx->X, ctx->conn, ctx->nptr, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, pr, out0,
-                     out1);
-  PF_LAUNCH_CHECK();
-  return PF_OK;
-}
-
-// Timing experiments (builds with -DPF_EXPERIMENTS only; the product library never reads these):
-// PF_GATHER_IMPL=legacy selects the first-generation kernel (PF_GATHER_NW=1|2|4 waves per tile);
-// PF_ABLATE=<bits> (1 no quadrature, 4 no write-out) produces deliberately wrong results for phase-cost
-// measurements (quad elasticity without density only).
+// Launch of the fused assembly kernel.  Experiment knobs (builds with -DPF_EXPERIMENTS only; the product library never
+// reads them): PF_GATHER_WAVES_PER_CU, PF_TILE_ORDER=c|x.
 template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
-  const char* impl = pf_exp_env("PF_GATHER_IMPL");
-  if ((impl && impl[0] == 'l') || ctx->npt == 0) return launch_gather_legacy<P, Phys, RHO>(ctx, pr, out0, out1);
-  {  // default: v3
-    const size_t lds3 = ((((size_t)ctx->npt * ctx->max_row_blocks + 1) * Phys::V * 8) + 15) & ~(size_t)15;
-    // stores per lane of the copy-out: from the largest tile the greedy pass actually made (tiles stop at 64 incident
-    // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
-    const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
-    const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
-    const char* ab = pf_exp_env("PF_ABLATE");
-    const int abl = ab ? atoi(ab) : 0;
-    (void)abl;
-    auto k3 = k_assemble_v3<P, Phys, RHO, 0, 0>;
-    const bool both = (Phys::V == 4) || (out0 && (out1 || Phys::V == 1));
-    if (per_lane <= 3 && both) {
-      k3 = k_assemble_v3<P, Phys, RHO, 3, 0>;
-    } else if (per_lane <= 5 && both) {
-      k3 = k_assemble_v3<P, Phys, RHO, 5, 0>;
-#ifdef PF_EXPERIMENTS
-      if constexpr (P == 4 && Phys::V == 4 && !RHO) {
-        if (abl == 1) k3 = k_assemble_v3<P, Phys, RHO, 5, 1>;
-        else if (abl == 4) k3 = k_assemble_v3<P, Phys, RHO, 5, 4>;
-        else if (abl == 5) k3 = k_assemble_v3<P, Phys, RHO, 5, 5>;
-        else if (abl == 8) k3 = k_assemble_v3<P, Phys, RHO, 5, 8>;
-        else if (abl == 9) k3 = k_assemble_v3<P, Phys, RHO, 5, 9>;
-        else if (abl == 12) k3 = k_assemble_v3<P, Phys, RHO, 5, 12>;
-        else if (abl == 13) k3 = k_assemble_v3<P, Phys, RHO, 5, 13>;
-        else if (abl == 16) k3 = k_assemble_v3<P, Phys, RHO, 5, 16>;
-        else if (abl == 25) k3 = k_assemble_v3<P, Phys, RHO, 5, 25>;
-        else if (abl == 29) k3 = k_assemble_v3<P, Phys, RHO, 5, 29>;
-      }
-#endif
-    } else if (per_lane <= 10 && both) {
-      k3 = k_assemble_v3<P, Phys, RHO, 10, 0>;
-    }
-    if (lds3 > 48 * 1024)
-      PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-    const int64_t nt = ctx->ntiles;
-    int wpc = 24;  // persistent waves per CU (tools/abl_v3.py sweep: 24-32 best)
-    const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
-    if (g3 && atoi(g3) > 0) wpc = atoi(g3);
-    const unsigned grid3 = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
-    // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
-    const char* to = pf_exp_env("PF_TILE_ORDER");
-    int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
-    if (tile_order == 2 && (grid3 & 7)) tile_order = 1;
-    hipLaunchKernelGGL(k3, dim3(grid3), dim3(64), lds3, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks, ctx->X,
-                       ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc), reinterpret_cast<const int4*>(ctx->vis_rec), (int32_t)(ctx->nelems * ctx->P), tile_order, pr, out0, out1,
-                       ctx->scal + (size_t)PF_NPART * PF_NPART_ARRAYS /* 16 spare doubles: trash line */);
-    PF_LAUNCH_CHECK();
-    return PF_OK;
-  }
-  return pf_fail(ctx, PF_E_INVALID, "unknown PF_GATHER_IMPL");
+  if (ctx->npt == 0 || !ctx->vis_rec || !ctx->tile_desc)
+    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: this pattern has no assembly tiles (node valence above 64)");
+  if (ctx->nnodes >= ((int64_t)1 << 28))
+    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: more than 2^28 nodes do not fit the 32-bit buffer offsets of the gathers");
+  // stores per lane of the copy-out: from the largest tile the greedy pass actually made (tiles stop at 64 incident
+  // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
+  const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
+  const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
+  auto k4 = k_assemble_v4<P, Phys, RHO, 0>;
+  int nout = 0;
+  if (per_lane <= 3) { k4 = k_assemble_v4<P, Phys, RHO, 3>; nout = 3; }
+  else if (per_lane <= 5) { k4 = k_assemble_v4<P, Phys, RHO, 5>; nout = 5; }
+  else if (per_lane <= 10) { k4 = k_assemble_v4<P, Phys, RHO, 10>; nout = 10; }
+  else nout = per_lane;
+  // image + the run-over of the copy-out's LDS reads (pieces past the segment end are read and then dropped)
+  const size_t plane = (size_t)ctx->npt * ctx->max_row_blocks + 1;
+  const size_t lds4 = (((plane * Phys::V + 127) & ~(size_t)127) + (size_t)64 * nout + 2) * 8;
+  if (lds4 > 160 * 1024)
+    return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node rows too long for the LDS image of a tile");
+  if (lds4 > 48 * 1024)
+    PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+  const int64_t nt = ctx->ntiles;
+  int wpc = 24;  // persistent waves per CU (tools/abl_v3.py sweep: 24-32 best)
+  const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
+  if (g3 && atoi(g3) > 0) wpc = atoi(g3);
+  const unsigned grid = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
+  // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
+  const char* to = pf_exp_env("PF_TILE_ORDER");
+  int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
+  if (tile_order == 2 && (grid & 7)) tile_order = 1;
+  hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks,
+                     ctx->X, ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc),
+                     reinterpret_cast<const int4*>(ctx->vis_rec), tile_order, pr, out0, out1);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
 }
 
 int pf_launch_assemble_elasticity(pf_ctx* ctx, double E, double nu, double p, const double* rho, int mode,

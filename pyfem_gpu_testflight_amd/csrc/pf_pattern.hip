@@ -184,10 +184,15 @@ __global__ void k_row_fill_tab(int P, int64_t nnodes, const int32_t* __restrict_
   }
 }
 
-// visit-ordered element records for the assembly kernel, ONE 16-byte load per incident pair jj of
-// node n:  {o0, o1, o2, w}  where o* are the element's node ids other than n (ascending local index) and
-//   w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | (slot of n in its tile)<<26
-// (pos_b = position of element node b in n's row, a = local index of n in the element).
+// visit-ordered element records for the assembly kernel, ONE 16-byte load per incident pair jj of node n.
+// The element is ROTATED so that n is its local node 0 (a cyclic rotation of a triangle or quad keeps orientation
+// and geometry, and the 1-point / 2x2 Gauss rules are invariant under it: only the order in which the quadrature
+// points are visited changes).  With k counting from n around the element, (a + k) mod P being the original index:
+//   {o1, o2, o3, w}   o_k = node id of rotated node k (k = 1..P-1; unused slots 0)
+//   w = pos_0 | pos_1<<6 | pos_2<<12 | pos_3<<18 | a<<24 | (slot of n in its tile)<<26
+// (pos_k = position of rotated node k in n's row; a = original local index of n, kept for readers that want it).
+// The kernel then never selects on a: the lane's own node is always local node 0 (constant shape-function signs,
+// no index shuffling of the gathered coordinates).
 template <int P>
 __global__ void k_build_visits(int64_t nnodes, const uint8_t* __restrict__ slot, const int32_t* __restrict__ conn,
                                const int32_t* __restrict__ n2e_ptr, const int32_t* __restrict__ n2e,
@@ -199,11 +204,11 @@ __global__ void k_build_visits(int64_t nnodes, const uint8_t* __restrict__ slot,
     const int32_t e = ea / P;
     const int a = ea - e * P;
     int32_t o[3] = {0, 0, 0};
-    int k = 0;
     uint32_t w = ((uint32_t)a << 24) | ((uint32_t)slot[n] << 26);
-    for (int b = 0; b < P; ++b) {
-      if (b != a) o[k++] = conn[(int64_t)e * P + b];
-      w |= (uint32_t)n2e_pos[(int64_t)jj * 4 + b] << (6 * b);
+    for (int k = 0; k < P; ++k) {
+      const int b = (a + k) % P;
+      if (k > 0) o[k - 1] = conn[(int64_t)e * P + b];
+      w |= (uint32_t)n2e_pos[(int64_t)jj * 4 + b] << (6 * k);
     }
     vis_rec[jj] = make_int4(o[0], o[1], o[2], (int32_t)w);
   }

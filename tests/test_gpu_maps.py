@@ -1,12 +1,14 @@
 """Replay of the fused assembly kernel's index arithmetic on the host (run with -m gpu; the maps are built on the
 device by pf_pattern_build).
 
-k_assemble_v3 (csrc/pf_assemble.hip) prefetches UNCONDITIONALLY with clamped indices: every lane of every tile loads a
-visit record, a row pointer, four coordinate pairs and four densities whether or not the lane has a pair to integrate
-(commit 7bf4609 fixed a gather 15 nodes past the end of X that such a lane produced).  This test downloads
-tile_desc / vis_rec / n2e_ptr / nptr through pf_pattern_get_tiles and re-derives, in numpy, every index the kernel
-forms -- v3_load_tile, v3_load_rec, v3_load_visit, the LDS adds of v3_tile and its copy-out -- for all 64 lanes of all
-tiles plus the pipeline's look-ahead tiles, asserting that each one lies inside its array.  Meshes: ragged sizes around
+k_assemble_v4 (csrc/pf_assemble.hip) prefetches UNCONDITIONALLY: every lane of every tile loads a visit record, a row
+pointer, P coordinate pairs and P densities whether or not the lane has a pair to integrate (round 1, commit 7bf4609,
+fixed a gather 15 nodes past the end of X that such a lane produced).  Records and row pointers are read through
+per-tile buffer resources (lanes past the tile's pairs get zeros from the hardware's range check), the gathers
+through resources over X / rho.  This test downloads tile_desc / vis_rec / n2e_ptr / nptr through
+pf_pattern_get_tiles and re-derives, in numpy, every index the kernel forms -- v4_load_tile, v4_load_rec,
+v4_load_visit, the LDS adds of v4_tile and its copy-out -- for all 64 lanes of all tiles, asserting that each one lies
+inside its array and that the rotated records describe the mesh they were built from.  Meshes: ragged sizes around
 the 16-node / 64-pair tile limits, shuffled triangles, a valence-63 hub, runs of unused nodes, a last tile whose
 slots reach past the last node."""
 import numpy as np
@@ -25,12 +27,14 @@ def pf():
     return pyfem
 
 
-def _replay(maps, nnodes, P, max_row_blocks, d):
+def _replay(maps, nnodes, P, max_row_blocks, d, conn):
     td, vr, n2e, nptr, npt = maps["tile_desc"], maps["vis_rec"], maps["n2e_ptr"], maps["nptr"], maps["npt"]
     ntiles, nvis = td.shape[0], vr.shape[0]
     assert nvis == n2e[-1]
-    plane = npt * max_row_blocks + 1  # doubles per value plane of the LDS image (k_assemble_v3: `plane`)
+    plane = npt * max_row_blocks + 1  # doubles per value plane of the LDS image (k_assemble_v4: `plane`)
     lanes = np.arange(64)
+    radix = nnodes ** np.arange(P, dtype=np.int64)  # test meshes are small: nnodes**P fits int64
+    conn_keys = conn.astype(np.int64) @ radix
     covered_nodes = covered_vis = covered_blocks = 0
     # the kernel reads descriptors min(t, t1 - 1) for t up to 4 tiles ahead: always inside [0, ntiles)
     for t in range(ntiles):
@@ -41,42 +45,37 @@ def _replay(maps, nnodes, P, max_row_blocks, d):
         assert base == nptr[n0] and base + nblk == nptr[n0 + nn_t] and nblk <= npt * max_row_blocks
         assert n0 == covered_nodes and vb == covered_vis and base == covered_blocks  # tiles partition everything
         covered_nodes, covered_vis, covered_blocks = n0 + nn_t, vb + nv_t, base + nblk
-        # v3_load_rec: all 64 lanes
+        # v4_load_rec: all 64 lanes; the record resource covers [vb, vb + nv_t), the pointer resource nn_t + 1 entries
         jj = vb + lanes
-        active = jj < vb + nv_t
-        rec = vr[np.minimum(jj, nvis - 1)]
-        assert (np.minimum(jj, nvis - 1) >= 0).all()
-        rp_idx = np.minimum(n0 + lanes, nnodes)
-        assert ((rp_idx >= 0) & (rp_idx <= nnodes)).all()  # nptr has nnodes + 1 entries
-        rp = nptr[rp_idx]
-        # v3_load_visit: all 64 lanes (gathers are unconditional)
+        active = lanes < nv_t
+        rec = np.where(active[:, None], vr[np.minimum(jj, nvis - 1)], 0)  # out of range: the hardware returns zeros
+        rp = np.where(lanes <= nn_t, nptr[np.minimum(n0 + lanes, nnodes)], 0)
+        # v4_load_visit: all 64 lanes (gathers are unconditional): own node first, then the rotated element's others
         wv = rec[:, 3].astype(np.int64) & 0xFFFFFFFF
         a, ln = (wv >> 24) & 3, (wv >> 26) & 15
-        n = np.minimum(n0 + ln, nnodes - 1)
-        o = rec[:, :3].astype(np.int64)
-        nd = np.stack([np.where(a == 0, n, o[:, 0]),
-                       np.where(a == 1, n, np.where(a < 1, o[:, 0], o[:, 1])),
-                       np.where(a == 2, n, np.where(a < 2, o[:, 1], o[:, 2])),
-                       np.where(a == 3, n, o[:, 2])], axis=1)
+        n = n0 + ln
+        nd = np.concatenate([n[:, None], rec[:, :3].astype(np.int64)], axis=1)[:, :P]
         assert ((nd >= 0) & (nd < nnodes)).all(), f"tile {t}: gather outside X / rho"
+        assert (ln <= nn_t).all()  # the __shfl source lane holds a row pointer of this tile
         # lanes with a pair: the record belongs to node n0 + ln of this tile, positions stay inside the tile's image
         la = np.flatnonzero(active)
         assert (ln[la] < nn_t).all()
         own = n0 + ln[la]
         assert ((n2e[own] <= jj[la]) & (jj[la] < n2e[own + 1])).all(), "visit record filed under the wrong node"
         assert (a[la] < P).all()
-        roff = rp[ln[la]] - rp[0]
+        # the rotated record is the element: (n, o1, .., o_{P-1}) is a cyclic rotation by a of a row of conn
+        elem = nd[la][:, :P]
+        back = np.stack([elem[np.arange(la.size), (k - a[la]) % P] for k in range(P)], axis=1)
+        assert np.isin(back @ radix, conn_keys).all(), "record is not a rotation of an element"
+        roff = rp[ln[la]] - base
         for b in range(P):
             pos = (wv[la] >> (6 * b)) & 63
             blk = roff + pos
             assert ((blk >= 0) & (blk < nblk)).all(), f"tile {t}: LDS add outside the tile's segment"
             assert (pos < nptr[own + 1] - nptr[own]).all(), "position byte beyond the node's row"
             assert (blk < plane).all()
-        # copy-out: pieces min(lane + 64 u, np - 1) of a segment of np = nblk * (2 if d == 2 else 1) pieces
-        np_ = nblk * (2 if d == 2 else 1)
-        if np_:
-            q = np.minimum(lanes[:, None] + 64 * np.arange(10)[None, :], np_ - 1)
-            assert (q >= 0).all() and ((q >> (1 if d == 2 else 0)) < nblk).all()
+        # copy-out: the store resource ends with the segment (nblk blocks); LDS reads run over by < 32 NOUT doubles,
+        # which the launcher allocates (pf_assemble.hip launch_gather)
     assert covered_nodes == nnodes and covered_vis == nvis and covered_blocks == nptr[-1]
 
 
@@ -124,5 +123,5 @@ def test_every_index_the_assembly_kernel_forms_is_in_range(pf, d):
             conn[-1, 2] = X.shape[0] - 1
         h = HipContext(X, conn, d)
         maps = h.assembly_maps()
-        _replay(maps, h.nnodes, h.P, h.max_row_blocks, d)
+        _replay(maps, h.nnodes, h.P, h.max_row_blocks, d, conn)
         h.close()
