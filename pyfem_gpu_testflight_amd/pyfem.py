@@ -28,11 +28,14 @@ from .utils import time_this
 
 # tolerance used by the device PCG wherever the reference asks scipy/pyamg for tol=1e-8
 # (pyfem.py:1827, 2107, 2418).  Tighter than the reference so that ||u - u_direct||_inf stays
-# below 1e-8 ||u||_inf (BASELINE.json north_star) on ill-conditioned large meshes.
-DEFAULT_RTOL = 1e-10
+# below 1e-8 ||u||_inf (BASELINE.json north_star) on ill-conditioned large meshes: measured against a
+# manufactured solution on the 2048x1024 mesh with a RAMP density field in [1e-3, 1], p = 5
+# (tests/test_gpu_scale.py), 1e-10 leaves 2.6e-8, 1e-11 one more AMG-PCG iteration and 2e-9.
+DEFAULT_RTOL = 1e-11
 # method="direct": relative residual the device PCG is driven to in place of the reference's sparse LU
 DIRECT_RTOL = 1e-13
 DIRECT_ACCEPT = 1e-10   # true relative residual up to which method="direct" accepts (with a warning) what PCG reached
+DIRECT_QUIET = 1e-11    # ... and below which it says nothing: a sparse LU of these systems sits at 1e-13 .. 1e-12 itself
 DIRECT_BURST = 500      # iterations per refinement round of method="direct" with the AMG preconditioner
 DIRECT_ROUNDS = 4
 
@@ -883,7 +886,9 @@ class Assembler:
                 x, it, rr = hctx.cg(K.vals, b, x0=x, rtol=DIRECT_RTOL, maxiter=burst, precond=_PRECOND[self.precond],
                                     allow_maxiter=True)
                 total += it
-                if rr <= DIRECT_RTOL or not np.isfinite(rr):
+                # it == 0: the TRUE residual of the restart was already below the target; a run that converged by its
+                # recurrence is restarted once more, because the recurrence drifts from b - K x on ill-conditioned K
+                if it == 0 or not np.isfinite(rr):
                     break
         for w in {str(c.message) for c in caught}:
             warnings.warn(w, RuntimeWarning, stacklevel=4)
@@ -894,7 +899,7 @@ class Assembler:
                 f"direct failed with code {total}: no factorisation is built on the device and PCG stopped at "
                 f"||b - K x|| / ||b|| = {true_rr:.3e} (the matrix may be indefinite or singular); "
                 "scipy.sparse.linalg.spsolve(K, rhs) factorises the returned matrix on the host")
-        if true_rr > 10 * DIRECT_RTOL:
+        if true_rr > DIRECT_QUIET:
             warnings.warn(f'method="direct": PCG with refinement reached ||b - K x|| / ||b|| = {true_rr:.3e} '
                           f"(target {DIRECT_RTOL:g}) after {total} iterations; accepted", RuntimeWarning, stacklevel=4)
         return x, total, true_rr
