@@ -261,6 +261,45 @@ int pf_cgcg_reduce(pf_ctx* ctx, double* red_out, double* zero, int64_t nzero);
 int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, const double* red,
                       int first, const double* z, const double* w, double* p, double* s);
 
+/* ---- peer-store halo exchange + native distributed CG (one process per GPU of ONE node; no counterpart in the
+ *      reference, which is single process).  BASELINE north_star: "all-reduce over xGMI for the CG dot-products and
+ *      halo residual sum".  Every rank owns a window in fine-grained device memory that its peers map through HIP
+ *      IPC; an exchange is two kernels on the ctx stream: pack + store into the peers' windows + release flag, then
+ *      wait (acquire, bounded by a timeout) + sum in ascending rank order (bitwise identical on every sharer).
+ *        pf_halo_create:   window for `world` ranks with message slots of cap_doubles doubles (the same on all ranks)
+ *        pf_halo_handle:   HOST out, PF_HALO_HANDLE_BYTES bytes: the IPC handle of this rank's window
+ *        pf_halo_connect:  map peer `peer`'s window from its handle (all peers must be connected before an exchange)
+ *        pf_halo_plan_create (all HOST arrays): neighbours nbr_rank[nnbr] ascending, their packed local indices
+ *                          send_idx[nbr_ptr[k]:nbr_ptr[k+1]]; the n_if interface entries if_idx (local vector index)
+ *                          with, per entry, the contributing ranks src_rank (ascending, this rank included) and the
+ *                          position src_pos of the entry inside that rank's message to this rank (ignored for the own
+ *                          rank); returns a plan id
+ *        pf_halo_exchange: v[interface entries] <- sum over the sharing ranks (plan >= 0; plan < 0: no vector) and
+ *                          scal_out[0..ns) <- sum over all ranks of scal_in[0..ns)  (device pointers, ns <= PF_HALO_NSCAL)
+ *        pf_halo_status:   synchronises; HOST out 1 if a wait timed out since creation (then every later exchange
+ *                          returns at once and the results are garbage: the caller must raise)
+ *        pf_dist_cg:       Chronopoulos-Gear single-reduction Jacobi-PCG over the partition, x0 = 0, entirely in C:
+ *                          per iteration 3 compute launches + 1 exchange (interface sums of K z and the scalars
+ *                          r.z, z.Kz, r.r); stops at ||r|| <= max(rtol ||b||, atol), read back every check_every
+ *                          iterations.  dinv: inverse of the ASSEMBLED diagonal; own_w: 1 on the dofs this rank owns
+ *                          (each dof owned once).  PF_E_NOCONV like pf_cg; PF_E_HIP if a peer never arrived.      */
+#define PF_HALO_NSCAL 8
+#define PF_HALO_HANDLE_BYTES 64
+typedef struct pf_halo pf_halo;
+int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doubles, pf_halo** out);
+int pf_halo_handle(pf_halo* halo, void* handle_out);
+int pf_halo_connect(pf_halo* halo, int peer, const void* handle);
+int pf_halo_plan_create(pf_halo* halo, int nnbr, const int32_t* nbr_rank, const int32_t* nbr_ptr,
+                        const int32_t* send_idx, int64_t n_if, const int32_t* if_idx, const int32_t* src_ptr,
+                        const int32_t* src_rank, const int32_t* src_pos, int32_t* plan_id);
+int pf_halo_exchange(pf_halo* halo, int plan, double* v, const double* scal_in, int ns, double* scal_out);
+int pf_halo_status(pf_halo* halo, int32_t* err_host);
+int pf_halo_set_timeout(pf_halo* halo, double seconds);
+int pf_halo_destroy(pf_halo* halo);
+int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
+               const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
+               int32_t* iters_host, double* relres_host);
+
 /* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
  *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */
 enum { PF_K_ASSEMBLE_ELASTICITY = 0, PF_K_SPMV = 1, PF_K_ASSEMBLE_HELMHOLTZ = 2 };

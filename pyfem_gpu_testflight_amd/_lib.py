@@ -76,6 +76,16 @@ SIGNATURES = {
     "pf_cgcg_update_xrz": (C.c_int, [_vp] * 9),
     "pf_cgcg_reduce": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pf_cgcg_update_ps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "pf_halo_create": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.POINTER(_vp)]),
+    "pf_halo_handle": (C.c_int, [_vp, _vp]),
+    "pf_halo_connect": (C.c_int, [_vp, C.c_int, _vp]),
+    "pf_halo_plan_create": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "pf_halo_exchange": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "pf_halo_status": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "pf_halo_set_timeout": (C.c_int, [_vp, _f64]),
+    "pf_halo_destroy": (C.c_int, [_vp]),
+    "pf_dist_cg": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32),
+                             C.POINTER(_f64)]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
     "pf_hbm_probe": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_f64)]),
 }

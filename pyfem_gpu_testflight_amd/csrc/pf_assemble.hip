@@ -404,13 +404,18 @@ __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const in
   const pf_rsrc rr = make_rsrc(vis_rec + T.vb, (uint32_t)T.nv * 16u);         // this tile's records only
   const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);      // and its nn + 1 row pointers
   const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
-  B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);
+  B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
   return B;
 }
 
 template <int P, bool RHO>
 __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C) {
+  // Triangles never read rec.z.  hipcc then hands that register of the in-flight 16-byte load to a temporary, and the
+  // write-after-write hazard makes it wait for the record right behind its issue (r02 ISA: s_waitcnt vmcnt(1) one
+  // instruction after the load -- a full memory latency per tile; 0.181 -> 0.212 ms on 4 M triangles).  Keeping the
+  // component alive until the record is consumed removes the wait.
+  if constexpr (P == 3) asm volatile("" ::"v"(B.rec.z));
   const uint32_t w = (uint32_t)B.rec.w;
   const int ln = (int)((w >> 26) & 15);
   C.w = w;
@@ -450,12 +455,17 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
                                         double* __restrict__ out0, double* __restrict__ out1) {
   constexpr int V = Phys::V;
   // clear the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
+#ifdef PF_V4_ZERO_TILE
+  for (int k = 0; k < V; ++k)   // experiment: clear only the blocks this tile uses, plane by plane
+    for (int32_t q = lane; q < Tcur.nblk; q += 64) img[k * plane + q] = 0.0;
+#else
   {  // whole 1 KiB wave stores, a wave-uniform trip count (scalar loop): the allocation is rounded up to that
     pf_f64x2* img2 = reinterpret_cast<pf_f64x2*>(img) + lane;
     const int nzit = (V * plane + 127) >> 7;
     const pf_f64x2 z = {0.0, 0.0};
     for (int it = 0; it < nzit; ++it) img2[64 * it] = z;
   }
+#endif
 
   if (Cuse.active) {
     double v[P][V];
@@ -827,10 +837,23 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if (lds4 > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
   const int64_t nt = ctx->ntiles;
-  int wpc = 24;  // persistent waves per CU (tools/abl_v3.py sweep: 24-32 best)
+  // persistent waves: exactly as many as are resident at once (registers and LDS decide: 16 per CU for the quad
+  // elasticity kernel, 24-32 for the others).  More than that and the surplus waves only start when the first ones
+  // have finished their share -- a second, half-empty round (r02: 24 launched / 16 resident cost the quad kernel a
+  // quarter of its time); fewer and latency is not covered.  Capped at 32 per CU (r01 sweep: no gain beyond).
+  static thread_local struct { size_t lds; int wpc; } occ[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};  // per copy-out variant
+  auto& oc = occ[nout == 3 ? 1 : nout == 5 ? 2 : nout == 10 ? 3 : 0];
+  if (oc.wpc == 0 || oc.lds != lds4) {
+    int q = 0;
+    PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(k4), 64, lds4));
+    oc.lds = lds4;
+    oc.wpc = std::max(1, std::min(q, 32));
+  }
+  int wpc = oc.wpc;
   const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
   if (g3 && atoi(g3) > 0) wpc = atoi(g3);
-  const unsigned grid = (unsigned)std::min<int64_t>(nt, (int64_t)256 * wpc);
+  const int ncu = ctx->ncu > 0 ? ctx->ncu : 256;
+  const unsigned grid = (unsigned)std::min<int64_t>(nt, (int64_t)ncu * wpc);
   // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
   const char* to = pf_exp_env("PF_TILE_ORDER");
   int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;

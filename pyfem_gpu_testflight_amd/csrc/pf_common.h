@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,7 @@ static inline const char* pf_exp_env(const char*) { return nullptr; }
 
 struct pf_ctx {
   int device = 0;
+  int ncu = 0;               // compute units of the device (pf_ctx_create)
   hipStream_t stream = nullptr;
   std::string err;
   std::string warn;          // last non-fatal condition (pf_last_warning), e.g. a preconditioner that was refused
@@ -107,6 +110,12 @@ static inline void pf_free(T*& p) {
   if (p) (void)hipFree(p);
   p = nullptr;
 }
+
+// peer-store halo exchange (pf_halo.hip)
+struct pf_halo;
+int pf_halo_exchange_impl(pf_halo* h, int plan, double* v, const double* scal_in, int ns, double* scal_out);
+int32_t* pf_halo_err_ptr(pf_halo* h);
+pf_ctx* pf_halo_ctx(pf_halo* h);
 
 // internal entry points shared between translation units
 int pf_pattern_free(pf_ctx* ctx);

@@ -302,6 +302,7 @@ extern "C" int pf_ctx_create(int device, pf_ctx** out) {
   ctx->device = device;
   if (const char* e = getenv("PF_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e));
   ctx->amg_verbose = getenv("PF_AMG_VERBOSE") != nullptr;
+  (void)hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device);
   hipError_t e = hipMalloc(&ctx->scal, ((size_t)PF_NPART * PF_NPART_ARRAYS + 32) * sizeof(double));  // + trash line [0,16) + AMG scalar [16]
   if (e != hipSuccess) {
     delete ctx;

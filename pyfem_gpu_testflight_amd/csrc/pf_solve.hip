@@ -877,6 +877,81 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
 }
 
 // ------------------------------------------------------------------------------------------
+// Distributed single-reduction PCG, the whole loop in C (dist.py dist_cg is the same algorithm driven from Python over
+// torch.distributed, kept for the gloo CPU tests and as the fallback transport).  Per iteration: k_cgcg_update_xrz,
+// k_spmv (+ partials of z.Kz), k_finalize, one pf_halo exchange (2 launches: interface sums of w = K z and the three
+// scalars), k_cgcg_update_ps.  Nothing touches the host except the residual read-back every check_every iterations.
+// ------------------------------------------------------------------------------------------
+extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
+                          const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
+                          int32_t* iters_host, double* relres_host) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(halo && pf_halo_ctx(halo) == ctx, "pf_dist_cg: the halo belongs to another context");
+  PF_REQUIRE(ctx->d && vals && b && x && own_w, "pf_dist_cg: no pattern / NULL argument");
+  PF_HIP(hipSetDevice(ctx->device));
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
+  if (check_every <= 0) check_every = 50;
+  const int64_t need = 5 * n + 64;
+  if (ctx->cgw_cap < need) {
+    pf_free(ctx->cgw);
+    PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * need));
+    ctx->cgw_cap = need;
+  }
+  double *r = ctx->cgw, *z = r + n, *w = z + n, *p = w + n, *s = p + n;
+  double* small = s + n;  // [0..2] state a, [8..10] state b, [16..23] local scalars, [24..31] reduced scalars
+  double *stA = small, *stB = small + 8, *red = small + 16, *redg = small + 24;
+  hipStream_t st = ctx->stream;
+  const unsigned vg = vec_grid(n);
+  const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
+  PF_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, st));
+  PF_HIP(hipMemsetAsync(p, 0, sizeof(double) * 2 * n + sizeof(double) * 64, st));  // p, s and the small block
+  PF_HIP(hipMemcpyAsync(r, b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  // ||b||^2 over the owned dofs, summed over ranks
+  k_dot<<<vg, 256, 0, st>>>(n, b, b, own_w, part(ctx, PA_BB));
+  k_finalize<<<1, 256, 0, st>>>(1, part(ctx, PA_BB), (int)vg, nullptr, 0, nullptr, 0, red, nullptr, 0);
+  int rc = pf_halo_exchange_impl(halo, -1, nullptr, red, 1, redg);
+  if (rc) return rc;
+  double h[8];
+  int32_t herr = 0;
+  PF_HIP(hipMemcpyAsync(h, redg, sizeof(double), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(halo), sizeof(herr), hipMemcpyDeviceToHost, st));
+  PF_HIP(hipStreamSynchronize(st));
+  if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_cg: a peer did not arrive at the halo exchange (timeout)");
+  const double bnorm = sqrt(h[0]);
+  const double tol = std::max(rtol * bnorm, atol);
+  double rnorm = INFINITY;
+  int it = 0;
+  double *state = stA, *state_next = stB;
+  while (it < maxiter) {
+    k_cgcg_update_xrz<<<vg, 256, 0, st>>>(n, state, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
+    rc = pf_launch_spmv(ctx, vals, z, w, part(ctx, PA_DELTA));
+    if (rc) return rc;
+    k_finalize<<<1, 256, 0, st>>>(3, part(ctx, PA_GAMMA), (int)vg, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), (int)vg, red,
+                                  nullptr, 0);
+    rc = pf_halo_exchange_impl(halo, plan, w, red, 3, redg);
+    if (rc) return rc;
+    // redg[2] = r.r of the residual after `it` updates
+    if (it % check_every == 0 || it + 1 == maxiter) {
+      PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+      PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(halo), sizeof(herr), hipMemcpyDeviceToHost, st));
+      PF_HIP(hipStreamSynchronize(st));
+      if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_cg: a peer did not arrive at the halo exchange (timeout)");
+      rnorm = sqrt(h[2]);
+      if (!(rnorm == rnorm) || rnorm <= tol) break;
+    }
+    k_cgcg_update_ps<<<vg, 256, 0, st>>>(n, state, state_next, redg, it == 0, z, w, p, s);
+    std::swap(state, state_next);
+    ++it;
+  }
+  PF_LAUNCH_CHECK();
+  if (iters_host) *iters_host = it;
+  if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;
+  if (!(rnorm <= tol)) return pf_fail(ctx, PF_E_NOCONV, "cg failed with code " + std::to_string(it));  // pyfem.py:2421-2422
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // BiCGStab for nonsymmetric matrices on the ctx pattern: the Newton tangent of NonlinearPoisson2D and any K whose
 // Dirichlet conditions were applied to the rows only (enforce_symmetric_K=False) -- the systems the reference hands to
 // scipy gmres / spsolve (pyfem.py:2340-2349, 2414-2420).  Right-preconditioned with the Jacobi diagonal of vals or with
@@ -1023,27 +1098,34 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
 template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, const double2* __restrict__ b, int64_t n2,
                                                    double* __restrict__ sink) {
+  // four independent 16-byte accesses per lane and trip (what torch's fill / reduce kernels keep in flight too)
+  constexpr int U = 4;
   double s = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-    if constexpr (MODE == PF_HBM_FILL) {
-      const double2 v = make_double2((double)i, 1.0);
-      if constexpr (NT) { __builtin_nontemporal_store(v.x, &a[i].x); __builtin_nontemporal_store(v.y, &a[i].y); }
-      else a[i] = v;
-    } else if constexpr (MODE == PF_HBM_READ) {
-      double2 v;
-      if constexpr (NT) { v.x = __builtin_nontemporal_load(&b[i].x); v.y = __builtin_nontemporal_load(&b[i].y); }
-      else v = b[i];
-      s += v.x + v.y;
-    } else {
-      double2 v;
-      if constexpr (NT) { v.x = __builtin_nontemporal_load(&b[i].x); v.y = __builtin_nontemporal_load(&b[i].y); }
-      else v = b[i];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n2; i0 += U * stride) {
+    double2 v[U];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double2 w = make_double2(v.x + k, v.y - k);
-        double2* dst = a + i + k * n2;
-        if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
-        else *dst = w;
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = min(i0 + u * stride, n2 - 1);
+      if constexpr (MODE == PF_HBM_FILL) v[u] = make_double2((double)u, 1.0);
+      else if constexpr (NT) { v[u].x = __builtin_nontemporal_load(&b[i].x); v[u].y = __builtin_nontemporal_load(&b[i].y); }
+      else v[u] = b[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      if (i >= n2) continue;
+      if constexpr (MODE == PF_HBM_READ) {
+        s += v[u].x + v[u].y;
+      } else {
+        constexpr int NW = MODE == PF_HBM_MIX ? 3 : 1;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          const double2 w = make_double2(v[u].x + k, v[u].y - k);
+          double2* dst = a + i + k * n2;
+          if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
+          else *dst = w;
+        }
       }
     }
   }

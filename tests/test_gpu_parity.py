@@ -370,13 +370,20 @@ def test_isolated_nodes_and_kernel_variants(pf, orc):
         del os.environ["PF_ABLATE"], os.environ["PF_GATHER_IMPL"]
     assert bool((a == bvals).all())
     # solve with the Jacobi preconditioner: the 32 unused nodes have empty rows and no diagonal entry
+    fixed = [0, 1, 2, 3, 18, 19]  # two corners of the left edge: no rigid-body mode left
+    model = pf.LinearElasticity(X2, conn2, fixed, None, {int(conn2.max()): [0.0, -1.0]}, q, b, p=2.0)
     asm = pf.Assembler(model)
     asm.precond = "jacobi"
     u = asm.solve(method="cg")
-    uo, *_ = orc.solve_elasticity(X2, conn2, "quad", np.array([0, 1]), {int(conn2.max()): [0.0, -1.0]})
-    used = np.unique(conn2)
-    ud = np.concatenate([2 * used, 2 * used + 1])
-    assert np.abs(u[ud] - uo[ud]).max() <= U_TOL * np.abs(uo[ud]).max()
+    # the oracle on the mesh without the gap (a direct solve of the gapped matrix would meet its zero rows)
+    unshift = lambda i: i - (gap if i >= 20 else 0)  # noqa: E731
+    fixed0 = [2 * unshift(f // 2) + f % 2 for f in fixed]
+    uo, *_ = orc.solve_elasticity(X, conn, "quad", np.array(fixed0), {int(conn.max()): [0.0, -1.0]})
+    used = np.arange(X.shape[0]) + shift
+    ud = np.stack([2 * used, 2 * used + 1], axis=1).ravel()
+    assert np.abs(u[ud] - uo).max() <= U_TOL * np.abs(uo).max()
+    unused = np.setdiff1d(np.arange(X2.shape[0]), used)
+    assert np.all(u[2 * unused] == 0.0) and np.all(u[2 * unused + 1] == 0.0)
 
 
 @pytest.mark.parametrize("name,etype", [("sens24x17_quad", "quad"), ("sens21x16_tri", "tri")])
@@ -470,7 +477,7 @@ def test_direct_method_is_a_device_solve_to_lu_grade_residual(pf, monkeypatch):
     model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
     asm = pf.Assembler(model)
     u = asm.solve(method="direct")
-    assert asm.last_relres <= pf.DIRECT_RTOL and asm.last_iters > 0
+    assert asm.last_relres <= 1e-12 and asm.last_iters > 0  # TRUE residual ||b - K x|| / ||b||: what a sparse LU leaves
     K = model.compute_jacobian()
     K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs(), True)
     Ks = K.to_scipy()
@@ -963,8 +970,8 @@ def test_returned_matrix_is_a_scipy_matrix_for_host_code(pf, orc):
                                      np.array(left), np.ones(len(left)), False)
     assert relmax(u, spsolve(Kb.tocsc(), rb)) < U_TOL
     assert isinstance(K - K, sparse.csr_matrix) and (K - K).nnz == 0
-    with pytest.raises(TypeError):
-        model.apply_dirichlet_bcs(K - K, rhs)       # a host-only result has no device side
+    Kz, _ = model.apply_dirichlet_bcs(K - K, rhs.copy())  # a host-only result is uploaded (pyfem.py:781 takes any CSR)
+    assert Kz.hctx is not None and abs(Kz.diagonal()[np.array(left)] - 1.0).max() == 0.0
 
 
 def test_reference_example_flows_run_through_the_mirror(pf, orc, tmp_path):
