@@ -283,6 +283,24 @@ int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, co
  *                          r.z, z.Kz, r.r); stops at ||r|| <= max(rtol ||b||, atol), read back every check_every
  *                          iterations.  dinv: inverse of the ASSEMBLED diagonal; own_w: 1 on the dofs this rank owns
  *                          (each dof owned once).  PF_E_NOCONV like pf_cg; PF_E_HIP if a peer never arrived.      */
+/* ---- the AMG hierarchy's pieces for a DISTRIBUTED finest level (dist.py; counterpart of the reference's pyamg
+ *      preconditioner, pyfem.py:2393-2400, when the mesh is split over ranks).  Every rank sets the SAME hierarchy up
+ *      with pf_amg_prepare on a context that holds the whole mesh (the numeric setup is ~10 ms; replicating it costs
+ *      less than distributing it at these sizes); the finest level's smoothing and residuals then run on each rank's
+ *      rows with pf_halo interface sums, and only these four calls touch the replicated part:
+ *        pf_amg_level0:       the finest level's two Chebyshev-Jacobi factors per dof (device out, nrows each; may be
+ *                             NULL) and the number of level-1 dofs (HOST out)
+ *        pf_amg_restrict0:    b1 = P0^T res      (res: nrows, zero outside the caller's owned dofs; b1: level-1 dofs)
+ *        pf_amg_coarse_solve: x1 = one V-cycle of levels >= 1 applied to b1 (b1 summed over ranks by the caller)
+ *        pf_amg_prolong0:     c += P0 x1         (c: nrows)
+ *      pf_vec_smooth: out = x + d .* (b - w) on any vectors of length n (x, d, w may be NULL: 0, 1, 0): the sweeps of
+ *      the distributed finest level between two interface sums.  PF_E_UNSUPPORTED: single-level hierarchy.          */
+int pf_amg_level0(pf_ctx* ctx, double* dinv1, double* dinv2, int64_t* n1_dofs_host);
+int pf_amg_restrict0(pf_ctx* ctx, const double* res, double* b1);
+int pf_amg_coarse_solve(pf_ctx* ctx, const double* b1, double* x1);
+int pf_amg_prolong0(pf_ctx* ctx, const double* x1, double* c);
+int pf_vec_smooth(pf_ctx* ctx, int64_t n, const double* x, const double* d, const double* b, const double* w, double* out);
+
 #define PF_HALO_NSCAL 8
 #define PF_HALO_HANDLE_BYTES 64
 typedef struct pf_halo pf_halo;

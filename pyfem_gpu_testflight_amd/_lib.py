@@ -76,6 +76,11 @@ SIGNATURES = {
     "pf_cgcg_update_xrz": (C.c_int, [_vp] * 9),
     "pf_cgcg_reduce": (C.c_int, [_vp, _vp, _vp, _i64]),
     "pf_cgcg_update_ps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "pf_amg_level0": (C.c_int, [_vp, _vp, _vp, C.POINTER(_i64)]),
+    "pf_amg_restrict0": (C.c_int, [_vp, _vp, _vp]),
+    "pf_amg_coarse_solve": (C.c_int, [_vp, _vp, _vp]),
+    "pf_amg_prolong0": (C.c_int, [_vp, _vp, _vp]),
+    "pf_vec_smooth": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pf_halo_create": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.POINTER(_vp)]),
     "pf_halo_handle": (C.c_int, [_vp, _vp]),
     "pf_halo_connect": (C.c_int, [_vp, C.c_int, _vp]),

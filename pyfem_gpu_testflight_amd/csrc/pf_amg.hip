@@ -1591,7 +1591,12 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 // Jacobi sweeps are fused into the products (x_out = x_in + dinv (b - A x_in)), so the iterate ping-pongs
 // between the level's x and t buffers: it changes buffer 2 nsmooth - 1 times per level (always odd), so
 // it starts in t and the level's result lands in x (= z on the fine level).
-int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
+static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out);
+static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c);
+
+// l0 = 0: the whole cycle on (r, z).  l0 = 1: levels >= 1 only, from L[1].b to L[1].x (r, z unused): the part of the
+// cycle every rank runs redundantly when the finest level is distributed (dist.py).
+static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0) {
   pf_amg* H = ctx->amg;
   if (!H) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: no hierarchy");
   hipStream_t st = ctx->stream;
@@ -1601,7 +1606,7 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
   double* oth[AMG_MAX_LEVELS];
   int rc;
   // down
-  for (int l = 0; l < Lc; ++l) {
+  for (int l = l0; l < Lc; ++l) {
     AmgLevel& Lv = H->L[l];
     AmgLevel& Nx = H->L[l + 1];
     const double* b = (l == 0) ? r : Lv.b;
@@ -1622,28 +1627,7 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
       std::swap(c, o);
     }
     if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
-    const unsigned g = (unsigned)cdiv(Lv.nc, 128);
-    if (Lv.sa) {
-#define PF_SAR(DR_, DC_)                                                                                    \
-  do {                                                                                                      \
-    if (Lv.np >= 48 * Lv.nc) /* long columns, few of them: a wave per coarse row */                          \
-      k_sa_restrict_wave<DR_, DC_><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, Nx.b); \
-    else                                                                                                    \
-      k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, st>>>(Lv.nc, Lv.tptr, Lv.tnode, \
-                                                                                                       Lv.ptvals, o, Nx.b); \
-  } while (0)
-      if (Lv.dr == 1) PF_SAR(1, 1);
-      else if (H->dim == 3 && Lv.dr == 3) PF_SAR(3, 6);
-      else if (H->dim == 3) PF_SAR(6, 6);
-      else if (Lv.dr == 2) PF_SAR(2, 3);
-      else PF_SAR(3, 3);
-#undef PF_SAR
-    } else
-    if (Lv.dr == 1) k_amg_restrict<2, 1, 1><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else if (H->dim == 3 && Lv.dr == 3) k_amg_restrict<3, 3, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else if (H->dim == 3) k_amg_restrict<3, 6, 6><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else if (Lv.dr == 2) k_amg_restrict<2, 2, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
-    else k_amg_restrict<2, 3, 3><<<g, 128, 0, st>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, Nx.b);
+    if ((rc = amg_restrict_level(ctx, H, l, o, Nx.b))) return rc;
     PF_LAUNCH_CHECK();
     cur[l] = c;
     oth[l] = o;
@@ -1668,28 +1652,13 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
     PF_LAUNCH_CHECK();
   }
   // up
-  for (int l = Lc - 1; l >= 0; --l) {
+  for (int l = Lc - 1; l >= l0; --l) {
     AmgLevel& Lv = H->L[l];
     AmgLevel& Nx = H->L[l + 1];
     const double* b = (l == 0) ? r : Lv.b;
     double* c = cur[l];
     double* o = oth[l];
-    const unsigned g = (unsigned)cdiv(Lv.n, 256);
-    const double over = Lv.sa ? H->over_sa : H->over;
-    if (Lv.sa) {
-#define PF_SAO(DR_, DC_) k_sa_prolong<DR_, DC_><<<g, 256, 0, st>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, Nx.x, c, over)
-      if (Lv.dr == 1) PF_SAO(1, 1);
-      else if (H->dim == 3 && Lv.dr == 3) PF_SAO(3, 6);
-      else if (H->dim == 3) PF_SAO(6, 6);
-      else if (Lv.dr == 2) PF_SAO(2, 3);
-      else PF_SAO(3, 3);
-#undef PF_SAO
-    } else
-    if (Lv.dr == 1) k_amg_prolong<2, 1, 1><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
-    else if (H->dim == 3 && Lv.dr == 3) k_amg_prolong<3, 3, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
-    else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
-    else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
-    else k_amg_prolong<2, 3, 3><<<g, 256, 0, st>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, Nx.x, c, over);
+    if ((rc = amg_prolong_level(ctx, H, l, Nx.x, c))) return rc;
     for (int s = H->nsmooth - 1; s >= 0; --s) {  // ... and the reverse order on the way up: the cycle stays symmetric
       if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1))) return rc;
       std::swap(c, o);
@@ -1699,6 +1668,62 @@ int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) {
   }
   return PF_OK;
 }
+
+static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out) {
+  AmgLevel& Lv = H->L[l];
+  AmgLevel& Nx = H->L[l + 1];
+  (void)Nx;
+    const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+    if (Lv.sa) {
+#define PF_SAR(DR_, DC_)                                                                                    \
+  do {                                                                                                      \
+    if (Lv.np >= 48 * Lv.nc) /* long columns, few of them: a wave per coarse row */                          \
+      k_sa_restrict_wave<DR_, DC_><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
+    else                                                                                                    \
+      k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, \
+                                                                                                       Lv.ptvals, o, out); \
+  } while (0)
+      if (Lv.dr == 1) PF_SAR(1, 1);
+      else if (H->dim == 3 && Lv.dr == 3) PF_SAR(3, 6);
+      else if (H->dim == 3) PF_SAR(6, 6);
+      else if (Lv.dr == 2) PF_SAR(2, 3);
+      else PF_SAR(3, 3);
+#undef PF_SAR
+    } else
+    if (Lv.dr == 1) k_amg_restrict<2, 1, 1><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, out);
+    else if (H->dim == 3 && Lv.dr == 3) k_amg_restrict<3, 3, 6><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, out);
+    else if (H->dim == 3) k_amg_restrict<3, 6, 6><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, out);
+    else if (Lv.dr == 2) k_amg_restrict<2, 2, 3><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, out);
+    else k_amg_restrict<2, 3, 3><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.aptr, Lv.amem, Lv.iso, Lv.xy, Nx.xy, o, out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c) {
+  AmgLevel& Lv = H->L[l];
+  AmgLevel& Nx = H->L[l + 1];
+  (void)Nx;
+    const unsigned g = (unsigned)cdiv(Lv.n, 256);
+    const double over = Lv.sa ? H->over_sa : H->over;
+    if (Lv.sa) {
+#define PF_SAO(DR_, DC_) k_sa_prolong<DR_, DC_><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, xc, c, over)
+      if (Lv.dr == 1) PF_SAO(1, 1);
+      else if (H->dim == 3 && Lv.dr == 3) PF_SAO(3, 6);
+      else if (H->dim == 3) PF_SAO(6, 6);
+      else if (Lv.dr == 2) PF_SAO(2, 3);
+      else PF_SAO(3, 3);
+#undef PF_SAO
+    } else
+    if (Lv.dr == 1) k_amg_prolong<2, 1, 1><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, xc, c, over);
+    else if (H->dim == 3 && Lv.dr == 3) k_amg_prolong<3, 3, 6><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, xc, c, over);
+    else if (H->dim == 3) k_amg_prolong<3, 6, 6><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, xc, c, over);
+    else if (Lv.dr == 2) k_amg_prolong<2, 2, 3><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, xc, c, over);
+    else k_amg_prolong<2, 3, 3><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.agg, Lv.iso, Lv.xy, Nx.xy, xc, c, over);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) { return amg_cycle(ctx, r, z, 0); }
 
 int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap) {
   pf_amg* H = ctx->amg;
@@ -1736,4 +1761,63 @@ extern "C" int pf_amg_vcycle(pf_ctx* ctx, const double* r, double* z) {
   PF_REQUIRE(r && z && r != z, "pf_amg_vcycle: NULL argument or z aliases r");
   PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok, "pf_amg_vcycle: call pf_amg_prepare first");
   return pf_amg_apply(ctx, r, z);
+}
+
+// ---- the hierarchy's pieces for a DISTRIBUTED finest level (dist.py: every rank holds the same hierarchy, set up
+// redundantly from the assembled matrix; smoothing and residuals on the finest level run on the rank's rows only, with
+// the interface sums of pf_halo; the transfer to level 1 and everything below run redundantly on every rank) ----------
+extern "C" int pf_amg_level0(pf_ctx* ctx, double* dinv1, double* dinv2, int64_t* n1_dofs_host) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok, "pf_amg_level0: call pf_amg_prepare first");
+  pf_amg* H = ctx->amg;
+  if (H->nlevels < 2) return pf_fail(ctx, PF_E_UNSUPPORTED, "pf_amg_level0: the hierarchy has a single level");
+  const int64_t n0 = H->L[0].n * H->L[0].dr;
+  if (dinv1) PF_HIP(hipMemcpyAsync(dinv1, H->L[0].dinv, sizeof(double) * n0, hipMemcpyDeviceToDevice, ctx->stream));
+  if (dinv2) PF_HIP(hipMemcpyAsync(dinv2, H->L[0].dinv2, sizeof(double) * n0, hipMemcpyDeviceToDevice, ctx->stream));
+  if (n1_dofs_host) *n1_dofs_host = H->L[1].n * H->L[1].dr;
+  return PF_OK;
+}
+
+extern "C" int pf_amg_restrict0(pf_ctx* ctx, const double* res, double* b1) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok && ctx->amg->nlevels >= 2 && res && b1, "pf_amg_restrict0: no hierarchy / NULL argument");
+  return amg_restrict_level(ctx, ctx->amg, 0, res, b1);
+}
+
+extern "C" int pf_amg_coarse_solve(pf_ctx* ctx, const double* b1, double* x1) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok && ctx->amg->nlevels >= 2 && b1 && x1, "pf_amg_coarse_solve: no hierarchy / NULL argument");
+  pf_amg* H = ctx->amg;
+  const size_t bytes = sizeof(double) * (size_t)(H->L[1].n * H->L[1].dr);
+  PF_HIP(hipMemcpyAsync(H->L[1].b, b1, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  int rc = amg_cycle(ctx, nullptr, nullptr, 1);
+  if (rc) return rc;
+  PF_HIP(hipMemcpyAsync(x1, H->L[1].x, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return PF_OK;
+}
+
+extern "C" int pf_amg_prolong0(pf_ctx* ctx, const double* x1, double* c) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok && ctx->amg->nlevels >= 2 && x1 && c, "pf_amg_prolong0: no hierarchy / NULL argument");
+  return amg_prolong_level(ctx, ctx->amg, 0, x1, c);
+}
+
+// out = x + d .* (b - w)   (x == NULL: out = d .* b; w == NULL: out = x + d .* b; d == NULL: unit factors)
+__global__ __launch_bounds__(256) void k_vec_smooth(int64_t n, const double* __restrict__ x, const double* __restrict__ d,
+                                                    const double* __restrict__ b, const double* __restrict__ w,
+                                                    double* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double res = b[i] - (w ? w[i] : 0.0);
+    out[i] = (x ? x[i] : 0.0) + (d ? d[i] : 1.0) * res;
+  }
+}
+
+extern "C" int pf_vec_smooth(pf_ctx* ctx, int64_t n, const double* x, const double* d, const double* b, const double* w,
+                             double* out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(n >= 0 && b && out, "pf_vec_smooth: NULL argument");
+  if (n == 0) return PF_OK;
+  k_vec_smooth<<<(unsigned)std::min<int64_t>(cdiv(n, 256), 2048), 256, 0, ctx->stream>>>(n, x, d, b, w, out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
 }

@@ -396,21 +396,28 @@ __device__ __forceinline__ V4Tile v4_load_tile(int64_t t, int64_t t1, const int4
 }
 
 __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const int4* __restrict__ vis_rec,
-                                             const int32_t* __restrict__ nptr) {
+                                             const int32_t* __restrict__ nptr, int64_t g_nvis = 0, int64_t g_nnodes = 0) {
   V4Rec B;
   B.active = lane < T.nv;
   B.n0 = T.n0;
   B.base = T.base;
+#ifdef PF_V4_GLOBAL_REC  // experiment: plain global loads with clamped indices (the v3 form)
+  B.rec = vis_rec[min((int64_t)T.vb + lane, g_nvis - 1)];
+  if (!B.active) B.rec = make_int4(0, 0, 0, 0);
+  B.rp = nptr[min((int64_t)T.n0 + lane, g_nnodes)];
+#else
   const pf_rsrc rr = make_rsrc(vis_rec + T.vb, (uint32_t)T.nv * 16u);         // this tile's records only
   const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);      // and its nn + 1 row pointers
   const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
   B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
+#endif
   return B;
 }
 
 template <int P, bool RHO>
-__device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C) {
+__device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C,
+                                              const double* __restrict__ g_X = nullptr) {
   // Triangles never read rec.z.  hipcc then hands that register of the in-flight 16-byte load to a temporary, and the
   // write-after-write hazard makes it wait for the record right behind its issue (r02 ISA: s_waitcnt vmcnt(1) one
   // instruction after the load -- a full memory latency per tile; 0.181 -> 0.212 ms on 4 M triangles).  Keeping the
@@ -423,14 +430,24 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
   C.roff = __shfl(B.rp, ln) - B.base;
   // a lane without a pair holds an all-zero record: its gathers read node n0 and node 0, both in range
   const uint32_t n = (uint32_t)(B.n0 + ln);
+#ifdef PF_V4_GLOBAL_GATHER  // experiment: 64-bit global addressing (the v3 form)
+  const double2 p0 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)n);
+  const double2 p1 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.x);
+  const double2 p2 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.y);
+#else
   const double2 p0 = buf_ld_f64x2(RX, n * 16u);
   const double2 p1 = buf_ld_f64x2(RX, (uint32_t)B.rec.x * 16u);
   const double2 p2 = buf_ld_f64x2(RX, (uint32_t)B.rec.y * 16u);
+#endif
   C.el.x[0] = p0.x; C.el.y[0] = p0.y;
   C.el.x[1] = p1.x; C.el.y[1] = p1.y;
   C.el.x[2] = p2.x; C.el.y[2] = p2.y;
   if constexpr (P == 4) {
+#ifdef PF_V4_GLOBAL_GATHER
+    const double2 p3 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.z);
+#else
     const double2 p3 = buf_ld_f64x2(RX, (uint32_t)B.rec.z * 16u);
+#endif
     C.el.x[3] = p3.x; C.el.y[3] = p3.y;
   }
   if constexpr (RHO) {
@@ -444,12 +461,25 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
   }
 }
 
+// one step of the segmented inclusive scan of v4_tile: x[k] += x[k] of the lane SH places down the row if that lane
+// works for the same node (keys are sorted along the lanes, so equal keys SH apart mean one run)
+template <int SH, int V>
+__device__ __forceinline__ void v4_seg_step(int key, double x[V]) {
+  const bool same = __builtin_amdgcn_update_dpp(-1, key, 0x110 + SH, 0xf, 0xf, false) == key;  // row_shr:SH
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x[k]), 0x110 + SH, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x[k]), 0x110 + SH, 0xf, 0xf, true);
+    x[k] += same ? __hiloint2double(hi, lo) : 0.0;
+  }
+}
+
 // integrate tile Tcur from Cuse into the LDS image and copy the finished segment out.
 // Image layout: V planes of `plane` doubles, value k of the tile's block B at img[k*plane + B].  With the
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
 // 8 of the 32 banks (PMC counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
 // touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
-template <int P, class Phys, bool RHO, int NOUT>
+template <int P, class Phys, bool RHO, int NOUT, bool COMB>
 __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V4Tile& Tcur,
                                         const V4Visit<P, RHO>& Cuse, double* img, int plane, int lane,
                                         double* __restrict__ out0, double* __restrict__ out1) {
@@ -471,12 +501,30 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
     double v[P][V];
     element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, 0, v);  // the lane's node is local node 0 (rotated record)
     double* row = img + Cuse.roff;
+    bool add_diag = true;
+    if constexpr (COMB) {
+      // The incident pairs of a node are consecutive lanes and, with the rotated records, every one of them holds a
+      // contribution to the node's DIAGONAL block in v[0]: valence-many adds to the same LDS address in one
+      // instruction, which the LDS serialises (r02: this, not instruction issue, bounds the triangle kernel -- the
+      // v3 kernel spread the same adds over its P instructions by accident of the local index).  Sum them across the
+      // lanes first: a segmented scan over the node slot inside each row of 16 lanes (DPP row shifts: plain VALU,
+      // no LDS), after which only the last lane of a node's run adds.  A run that crosses a row boundary adds twice.
+      // Fixed lane order, so the result stays bitwise reproducible.
+      const int key = (int)((Cuse.w >> 26) & 15);
+      v4_seg_step<1, V>(key, v[0]);
+      v4_seg_step<2, V>(key, v[0]);
+      v4_seg_step<4, V>(key, v[0]);
+      v4_seg_step<8, V>(key, v[0]);
+      add_diag = __builtin_amdgcn_update_dpp(-1, key, 0x101, 0xf, 0xf, false) != key;  // row_shl:1: the next lane's node
+    }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       double* dst = row + (int)((Cuse.w >> (6 * b)) & 63);
+      if (b > 0 || add_diag) {
 #pragma unroll
-      for (int k = 0; k < V; ++k)
-        __hip_atomic_fetch_add(dst + k * plane, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int k = 0; k < V; ++k)
+          __hip_atomic_fetch_add(dst + k * plane, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
   }
 
@@ -490,11 +538,24 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
     const double* a0 = img + (lane & 1) * 2 * plane + (lane >> 1);
     const double* a1 = a0 + plane;
     if constexpr (NOUT > 0) {
+#ifdef PF_V4_GLOBAL_STORE  // experiment: clamped global stores (the v3 form)
+      const int32_t np = nblk * 2;
+      double2* d4 = reinterpret_cast<double2*>(out0) + 2 * (int64_t)Tcur.base;
+      if (np > 0) {
+#pragma unroll
+        for (int u = 0; u < NOUT; ++u) {
+          const int32_t q = min(lane + 64 * u, np - 1);
+          const int32_t tb = q >> 1, h2 = (q & 1) * 2;
+          d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
+        }
+      }
+#else
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
       }
+#endif
     } else {
       for (int u = 0; 32 * u < nblk; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
@@ -525,12 +586,18 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #ifndef PF_V4_WPE
 #define PF_V4_WPE 3
 #endif
-template <int P, class Phys, bool RHO, int NOUT>
+#ifndef PF_V4_COMB_QUAD
+#define PF_V4_COMB_QUAD 0
+#endif
+#ifndef PF_V4_COMB_TRI
+#define PF_V4_COMB_TRI 1
+#endif
+template <int P, class Phys, bool RHO, int NOUT, bool COMB = (P == 3 ? PF_V4_COMB_TRI : PF_V4_COMB_QUAD) != 0>
 __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int4* __restrict__ tile_desc,
-                                                    const int4* __restrict__ vis_rec, int32_t strided,
+                                                    const int4* __restrict__ vis_rec, int64_t nvis, int32_t strided,
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -555,10 +622,10 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   V4Tile T0 = v4_load_tile(t0, t1, tile_desc);
   V4Tile T1 = v4_load_tile(t0 + tstride, t1, tile_desc);
   V4Tile T2 = v4_load_tile(t0 + 2 * tstride, t1, tile_desc);
-  V4Rec Ba = v4_load_rec(T0, lane, vis_rec, nptr);
-  V4Rec Bb = v4_load_rec(T1, lane, vis_rec, nptr);
+  V4Rec Ba = v4_load_rec(T0, lane, vis_rec, nptr, nvis, nnodes);
+  V4Rec Bb = v4_load_rec(T1, lane, vis_rec, nptr, nvis, nnodes);
   V4Visit<P, RHO> Ca, Cb;
-  v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca);
+  v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca, X);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -573,17 +640,17 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
     const V4Tile T3 = v4_load_tile(t + 3 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO>(Bb, RX, Rrho, Cb);
-    Ba = v4_load_rec(T2, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT>(pr, T0, Ca, img, plane, lane, out0, out1);
+    v4_load_visit<P, RHO>(Bb, RX, Rrho, Cb, X);
+    Ba = v4_load_rec(T2, lane, vis_rec, nptr, nvis, nnodes);
+    v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T0, Ca, img, plane, lane, out0, out1);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V4Tile T4 = v4_load_tile(t + 4 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca);
-    Bb = v4_load_rec(T3, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT>(pr, T1, Cb, img, plane, lane, out0, out1);
+    v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca, X);
+    Bb = v4_load_rec(T3, lane, vis_rec, nptr, nvis, nnodes);
+    v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T1, Cb, img, plane, lane, out0, out1);
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (t < t1) v4_tile<P, Phys, RHO, NOUT>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
+  if (t < t1) v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -860,7 +927,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if (tile_order == 2 && (grid & 7)) tile_order = 1;
   hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks,
                      ctx->X, ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc),
-                     reinterpret_cast<const int4*>(ctx->vis_rec), tile_order, pr, out0, out1);
+                     reinterpret_cast<const int4*>(ctx->vis_rec), (int64_t)(ctx->nelems * ctx->P), tile_order, pr, out0, out1);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

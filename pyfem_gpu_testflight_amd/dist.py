@@ -66,12 +66,26 @@ class ElementBlockPartition:
         count = np.zeros(nnodes, dtype=np.int32)
         owner = np.full(nnodes, world, dtype=np.int32)
         mine = None
+        nodes_of = []
         for r in range(world):
             nodes_r = np.unique(conn[bounds[r]:bounds[r + 1]])
+            nodes_of.append(nodes_r)
             count[nodes_r] += 1
             owner[nodes_r] = np.minimum(owner[nodes_r], r)
             if r == rank:
                 mine = nodes_r
+        # neighbours: the ranks this one shares nodes with, and the shared nodes (ascending GLOBAL id: both sides of
+        # a pair list them in the same order, which is what makes the packed messages line up without any handshake)
+        self.neighbours = []
+        self.shared_nodes = {}
+        for r in range(world):
+            if r == rank:
+                continue
+            sh = np.intersect1d(mine, nodes_of[r], assume_unique=True)
+            if sh.size:
+                self.neighbours.append(r)
+                self.shared_nodes[r] = sh
+        del nodes_of
         self.nodes = mine  # ascending global node ids of this rank
         self.nnodes_local = mine.size
         self.conn_local = np.searchsorted(mine, conn[bounds[rank]:bounds[rank + 1]]).astype(np.int32)
@@ -87,6 +101,65 @@ class ElementBlockPartition:
         self.owned_mask_nodes = owner[mine] == rank
         self.own_weight = np.repeat(self.owned_mask_nodes.astype(np.float64), d)  # per local dof
         self.multiplicity = np.repeat(count[mine].astype(np.float64), d)
+
+    def exchange_tables(self, d=None):
+        """Index tables of the neighbour exchange for vectors with d entries per node (default: the partition's dofs).
+        Returns a dict of int32 numpy arrays:
+          nbr_rank (nnbr) ascending; nbr_ptr (nnbr+1); send_idx: local vector index of every value packed for
+          neighbour k, in message order (shared nodes ascending, d entries per node);
+          if_idx (n_if): local vector indices on an interface, ascending; src_ptr (n_if+1), src_rank, src_pos: for each
+          entry the ranks that hold it, ASCENDING and including this rank, and the entry's position inside the message
+          that rank sends to this one (0 for this rank's own value).  Summing in that order gives every sharer of a dof
+          the same floating-point sum."""
+        d = self.d if d is None else int(d)
+        k = np.arange(d)
+        nbr_rank = np.asarray(self.neighbours, dtype=np.int32)
+        nbr_ptr = np.zeros(nbr_rank.size + 1, dtype=np.int32)
+        send = []
+        pos_in_msg = {}  # rank -> position of each of MY local nodes in the message exchanged with that rank (-1: absent)
+        for i, r in enumerate(self.neighbours):
+            loc = np.searchsorted(self.nodes, self.shared_nodes[r])
+            send.append((loc[:, None] * d + k).ravel())
+            nbr_ptr[i + 1] = nbr_ptr[i] + loc.size * d
+            pm = np.full(self.nnodes_local, -1, dtype=np.int64)
+            pm[loc] = np.arange(loc.size)
+            pos_in_msg[r] = pm
+        send_idx = np.concatenate(send).astype(np.int32) if send else np.zeros(0, dtype=np.int32)
+        if_nodes = np.flatnonzero(self.multiplicity[::self.d] > 1) if self.d else np.zeros(0, dtype=np.int64)
+        ranks_sorted = sorted(self.neighbours + [self.rank])
+        # per interface node: the sharers in ascending rank order
+        cols_rank = np.full((if_nodes.size, len(ranks_sorted)), -1, dtype=np.int64)
+        cols_pos = np.zeros((if_nodes.size, len(ranks_sorted)), dtype=np.int64)
+        for j, r in enumerate(ranks_sorted):
+            if r == self.rank:
+                cols_rank[:, j] = r
+            else:
+                pm = pos_in_msg[r][if_nodes]
+                has = pm >= 0
+                cols_rank[has, j] = r
+                cols_pos[has, j] = pm[has]
+        has = cols_rank >= 0
+        cnt = has.sum(axis=1)
+        # expand nodes -> d entries each (entry k of node i: message position pos * d + k)
+        n_if = if_nodes.size * d
+        if_idx = (if_nodes[:, None] * d + k).ravel().astype(np.int32)
+        src_ptr = np.zeros(n_if + 1, dtype=np.int32)
+        src_ptr[1:] = np.cumsum(np.repeat(cnt, d))
+        flat_rank = cols_rank[has]  # row-major: node by node, sharers ascending
+        flat_pos = cols_pos[has]
+        # order the expanded list entry-major: for node i, entry k: all its sharers
+        start = np.zeros(if_nodes.size + 1, dtype=np.int64)
+        start[1:] = np.cumsum(cnt)
+        out_rank = np.empty(int(src_ptr[-1]), dtype=np.int32)
+        out_pos = np.empty(int(src_ptr[-1]), dtype=np.int32)
+        for kk in range(d):
+            dst0 = src_ptr[np.arange(if_nodes.size) * d + kk]  # first slot of entry (i, kk)
+            dst = np.repeat(dst0, cnt) + (np.arange(flat_rank.size) - np.repeat(start[:-1], cnt))
+            out_rank[dst] = flat_rank
+            out_pos[dst] = flat_pos * d + kk
+        max_msg = int(np.diff(nbr_ptr).max()) if nbr_rank.size else 0
+        return {"nbr_rank": nbr_rank, "nbr_ptr": nbr_ptr, "send_idx": send_idx, "if_idx": if_idx, "src_ptr": src_ptr,
+                "src_rank": out_rank, "src_pos": out_pos, "max_message": max_msg}
 
     def local_dofs_of(self, global_dofs):
         """Map global dof ids to local ones; returns (local_ids, mask_present)."""
@@ -156,18 +229,24 @@ class HipLocalOps:
     def spmv(self, K, x, y):
         self._call("pf_spmv", self._p(K), self._p(x), self._p(y))
 
-    def amg_prepare(self, K, reuse=False):
-        self._call("pf_amg_prepare", self._p(K), int(bool(reuse)))
-
-    def add_to_diag(self, K, add):
-        self._call("pf_add_to_diag", self._p(K), self._p(add))
-
-    def amg_vcycle(self, r, z):
-        self._call("pf_amg_vcycle", self._p(r), self._p(z))
-
     def cgcg_update_ps(self, state_in, state_out, red, first, z, w, p, s):
         self._call("pf_cgcg_update_ps", self._p(state_in), self._p(state_out), self._p(red), int(first),
                    self._p(z), self._p(w), self._p(p), self._p(s))
+
+    def vec_smooth(self, x, d, b, w, out):
+        """out = x + d .* (b - w); x, d, w may be None (0, 1, 0)."""
+        self._call("pf_vec_smooth", self._lib._i64(out.numel()), self._p(x), self._p(d), self._p(b), self._p(w), self._p(out))
+
+    def dist_cg_native(self, iface, K, b, dinv, own_w, rtol, atol, maxiter, check_every):
+        """pf_dist_cg: the whole single-reduction PCG loop in C over the peer-store exchange."""
+        x = self.zeros(self.n)
+        iters, relres = self._lib._i32(), self._lib._f64()
+        self.begin()
+        rc = self.lib.pf_dist_cg(self.h._ctx, iface.halo._h, int(iface.plan), self._p(K), self._p(b), self._p(dinv),
+                                 self._p(own_w), self._p(x), float(rtol), float(atol), int(maxiter or 0), int(check_every or 0),
+                                 C.byref(iters), C.byref(relres))
+        self._lib.check(self.h._ctx, rc, "pf_dist_cg")
+        return x, iters.value, relres.value
 
 
 # ------------------------------------------------------------------------------------------
@@ -180,46 +259,324 @@ def _all_reduce(t, group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
+def _dist_on(group):
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 class Interface:
-    """Packed interface vector of the job + this rank's (local dof, slot) lists on the device."""
+    """Neighbour exchange of this rank's interface entries: v[interface] <- sum over the ranks that share the entry,
+    optionally with a few scalars all-reduced in the same step (`exchange`).
 
-    def __init__(self, ops, part, group=None):
+    Each rank talks to the ranks it shares nodes with, and only about those nodes (one node row per cut for strip
+    partitions); the sum of every entry runs over its sharers in ascending rank order, so all copies of an interface
+    dof end up bitwise identical.  Two transports behind the same interface:
+      "peer"  the native one (csrc/pf_halo.hip): kernels store into the neighbours' windows over xGMI (HIP IPC,
+              fine-grained memory, sequence flags); scalars are reduced the same way.  Two launches per exchange,
+              nothing on the host -- and pf_dist_cg runs the whole CG loop in C on top of it.  Needs every rank on one
+              node and a GPU per rank (ranks may share a GPU: that is how it is tested on a 1-GPU box).
+      "p2p"   torch.distributed: batched isend/irecv of the packed messages per neighbour + one small all-reduce for
+              the scalars.  Works with gloo on CPU (tests/test_dist_cpu.py) and is the fallback when the windows
+              cannot be shared (several nodes, IPC refused).
+    transport=None picks "peer" when it can be set up AND passes a self-test on every rank, else "p2p"."""
+
+    def __init__(self, ops, part, group=None, d=None, transport=None, halo=None):
+        import os
+
         torch = ops.torch
-        self.ops, self.group = ops, group
-        self.G = part.n_iface_dofs
-        self.n = part.iface_local_dofs.size
-        self.local = ops.from_numpy(part.iface_local_dofs, torch.int32)
-        self.slots = ops.from_numpy(part.iface_slots, torch.int32)
-        self.buf = ops.zeros(self.G + 3)  # [interface partial sums | gamma, delta, rr]
+        self.ops, self.group, self.part = ops, group, part
+        self.rank, self.world = part.rank, part.world
+        self.d = part.d if d is None else int(d)
+        t = part.exchange_tables(self.d)
+        self.tables = t
+        self.n = t["if_idx"].size              # interface entries of this rank
+        self.nbr = [int(r) for r in t["nbr_rank"]]
+        self.max_message = t["max_message"]
+        self.local = ops.from_numpy(t["if_idx"], torch.int32)
+        self.halo = None
+        self.plan = -1
+        want = transport or os.environ.get("PF_DIST_TRANSPORT") or None
+        native_possible = hasattr(ops, "h") and _dist_on(group)
+        if halo is not None:  # share an existing window (another vector shape on the same partition)
+            self.halo = halo
+            self.plan = halo.add_plan(t)
+            self.transport = "peer"
+        elif want in (None, "peer") and native_possible:
+            h = PeerHalo.try_create(ops, part, group, cap=self._agree_cap(group))
+            if h is not None:
+                self.halo = h
+                self.plan = h.add_plan(t)
+                self.transport = "peer"
+                if not h.self_test(self, group):
+                    self.halo, self.plan = None, -1
+            if self.halo is None:
+                if want == "peer":
+                    raise RuntimeError("PF_DIST_TRANSPORT=peer, but the peer-store windows could not be set up")
+                self.transport = "p2p"
+        else:
+            self.transport = "p2p"
+        if self.transport == "p2p":
+            self._setup_p2p()
 
-    def sum(self, v):
-        """v[interface dofs] <- sum over ranks (in place); other entries untouched."""
-        if hasattr(self.ops, "begin"):
-            self.ops.begin()
-        self.buf.zero_()
-        self.ops.copy_indexed(self.n, self.local, self.slots, v, self.buf)
-        _all_reduce(self.buf, self.group)
-        self.ops.copy_indexed(self.n, self.slots, self.local, self.buf, v)
+    # -- p2p (torch.distributed) ------------------------------------------------------------------
+    def _agree_cap(self, group):
+        """Largest message of the job for vectors with up to 3 entries per node (dof and nodal plans share a window)."""
+        import torch.distributed as dist
+
+        per_node = max((self.part.shared_nodes[r].size for r in self.part.neighbours), default=0)
+        caps = [None] * dist.get_world_size(group)
+        dist.all_gather_object(caps, int(per_node), group=group)
+        return 3 * max(caps)
+
+    def _setup_p2p(self):
+        torch = self.ops.torch
+        t = self.tables
+        self._send_idx = self.ops.from_numpy(t["send_idx"], torch.int64)
+        self._nbr_ptr = [int(x) for x in t["nbr_ptr"]]
+        nsend = self._nbr_ptr[-1] if self._nbr_ptr else 0
+        self._sendbuf = self.ops.zeros(nsend)
+        self._recvbuf = self.ops.zeros(nsend)  # messages are symmetric: as much comes back from each neighbour
+        # ordered sum: slot 0.. of `cat` = [own interface values | recvbuf | 0]; column j of `order` = j-th sharer
+        src_ptr, src_rank, src_pos = t["src_ptr"], t["src_rank"], t["src_pos"]
+        cnt = np.diff(src_ptr)
+        m = int(cnt.max()) if cnt.size else 0
+        zero_slot = self.n + nsend
+        order = np.full((self.n, max(m, 1)), zero_slot, dtype=np.int64)
+        base = {r: self._nbr_ptr[i] for i, r in enumerate(self.nbr)}
+        ent = np.repeat(np.arange(self.n), cnt)
+        col = np.arange(src_rank.size) - np.repeat(src_ptr[:-1], cnt)
+        own = src_rank == self.rank
+        slot = np.where(own, ent, 0)
+        for r in self.nbr:
+            sel = src_rank == r
+            slot[sel] = self.n + base[r] + src_pos[sel]
+        order[ent, col] = slot
+        self._order = [self.ops.from_numpy(order[:, j].copy(), torch.int64) for j in range(order.shape[1])]
+        self._cat = self.ops.zeros(zero_slot + 1)
+        self._local64 = self.local.to(torch.int64)
+        self._cpu_stage = None
+
+    def _p2p_sum(self, v):
+        import torch.distributed as dist
+
+        torch = self.ops.torch
+        if not _dist_on(self.group) or not self.nbr:
+            return v
+        torch.index_select(v, 0, self._send_idx, out=self._sendbuf)
+        send, recv = self._sendbuf, self._recvbuf
+        stage = send.is_cuda and dist.get_backend(self.group) == "gloo"  # gloo moves host memory only
+        if stage:
+            send = send.cpu()
+            recv = torch.empty_like(send)
+        ops_ = []
+        for i, r in enumerate(self.nbr):
+            a, b = self._nbr_ptr[i], self._nbr_ptr[i + 1]
+            peer = r if self.group is None else dist.get_global_rank(self.group, r)
+            ops_.append(dist.P2POp(dist.isend, send[a:b], peer, self.group))
+            ops_.append(dist.P2POp(dist.irecv, recv[a:b], peer, self.group))
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        if stage:
+            self._recvbuf.copy_(recv)
+        cat = self._cat
+        cat[:self.n] = v[self._local64]
+        cat[self.n:self.n + self._recvbuf.numel()] = self._recvbuf
+        acc = cat[self._order[0]].clone()
+        for idx in self._order[1:]:
+            acc += cat[idx]
+        v[self._local64] = acc
         return v
 
+    # -- public -------------------------------------------------------------------------------------
+    def sum(self, v):
+        """v[interface entries] <- sum over the sharing ranks (in place); other entries untouched."""
+        if hasattr(self.ops, "begin"):
+            self.ops.begin()
+        if self.transport == "peer":
+            self.halo.exchange(self.plan, v)
+            return v
+        return self._p2p_sum(v)
 
-def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, check_every=50):
+    def exchange(self, v, scal):
+        """Interface sums of v (in place) and the sum over ALL ranks of the small tensor `scal`; returns the reduced
+        scalars as a new tensor (peer transport: no host involvement; p2p: one extra all-reduce)."""
+        if self.transport == "peer":
+            return self.halo.exchange(self.plan, v, scal)
+        self._p2p_sum(v)
+        out = scal.clone()
+        _all_reduce(out, self.group)
+        return out
+
+    def allreduce_scalars(self, scal):
+        if self.transport == "peer":
+            return self.halo.exchange(-1, None, scal)
+        out = scal.clone()
+        _all_reduce(out, self.group)
+        return out
+
+    def sibling(self, d):
+        """The same partition's interface for vectors with d entries per node, sharing this one's window."""
+        return Interface(self.ops, self.part, self.group, d=d, transport=self.transport, halo=self.halo)
+
+    def check(self):
+        """Raise if a peer never arrived at an exchange (peer transport; synchronises)."""
+        if self.halo is not None:
+            self.halo.check()
+
+
+class PeerHalo:
+    """ctypes face of csrc/pf_halo.hip: this rank's window, its peers' windows mapped through HIP IPC, exchange plans."""
+
+    def __init__(self, ops, world, rank, cap):
+        self.ops, self.world, self.rank = ops, world, rank
+        self.lib, self._lib = ops.lib, ops._lib
+        self._h = C.c_void_p()
+        ops.begin()
+        self._lib.check(ops.h._ctx, self.lib.pf_halo_create(ops.h._ctx, world, rank, self._lib._i64(int(cap)), C.byref(self._h)),
+                        "pf_halo_create")
+        self._scal_out = ops.zeros(8)
+        self._scal_in = ops.zeros(8)
+
+    @classmethod
+    def try_create(cls, ops, part, group, cap):
+        """Window + connections to every other rank, or None (with the reason in PeerHalo.last_failure) when any rank
+        cannot: all ranks agree on the outcome."""
+        import torch.distributed as dist
+
+        world, rank = part.world, part.rank
+        h, handle, why = None, None, ""
+        try:
+            h = cls(ops, world, rank, cap)
+            buf = C.create_string_buffer(64)
+            h._check(h.lib.pf_halo_handle(h._h, buf), "pf_halo_handle")
+            handle = buf.raw
+        except Exception as e:  # no fine-grained memory, IPC refused, ...
+            why = f"{type(e).__name__}: {e}"
+        import socket
+
+        info = [None] * world
+        dist.all_gather_object(info, (handle, socket.gethostname(), why), group=group)
+        ok = all(i[0] is not None for i in info) and len({i[1] for i in info}) == 1
+        if ok:
+            try:
+                for r in range(world):
+                    if r != rank:
+                        h._check(h.lib.pf_halo_connect(h._h, r, C.c_char_p(info[r][0])), "pf_halo_connect")
+            except Exception as e:
+                ok, why = False, f"{type(e).__name__}: {e}"
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        if not all(flags):
+            cls.last_failure = why or next((i[2] for i in info if i[2]), "ranks on different hosts")
+            if h is not None:
+                h.close()
+            return None
+        dist.barrier(group=group)  # every window is mapped everywhere before anybody stores into one
+        return h
+
+    last_failure = ""
+
+    def _check(self, rc, what):
+        self._lib.check(self.ops.h._ctx, rc, what)
+
+    def add_plan(self, t):
+        pid = self._lib._i32()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        arrs = {k: np.ascontiguousarray(t[k], dtype=np.int32) for k in ("nbr_rank", "nbr_ptr", "send_idx", "if_idx", "src_ptr",
+                                                                       "src_rank", "src_pos")}
+        self._check(self.lib.pf_halo_plan_create(self._h, int(arrs["nbr_rank"].size), p(arrs["nbr_rank"]), p(arrs["nbr_ptr"]),
+                                                 p(arrs["send_idx"]), self._lib._i64(int(arrs["if_idx"].size)), p(arrs["if_idx"]),
+                                                 p(arrs["src_ptr"]), p(arrs["src_rank"]), p(arrs["src_pos"]), C.byref(pid)),
+                    "pf_halo_plan_create")
+        return pid.value
+
+    def exchange(self, plan, v, scal=None):
+        ns = 0 if scal is None else int(scal.numel())
+        if ns:
+            self._scal_in[:ns] = scal
+        self.ops.begin()
+        self._check(self.lib.pf_halo_exchange(self._h, int(plan), C.c_void_p(0 if v is None else v.data_ptr()),
+                                              C.c_void_p(self._scal_in.data_ptr()), ns, C.c_void_p(self._scal_out.data_ptr())),
+                    "pf_halo_exchange")
+        return self._scal_out[:ns].clone() if ns else None
+
+    def check(self):
+        err = self._lib._i32()
+        self._check(self.lib.pf_halo_status(self._h, C.byref(err)), "pf_halo_status")
+        if err.value:
+            raise RuntimeError("halo exchange: a peer did not arrive (timeout); results of this solve are invalid")
+
+    def self_test(self, iface, group):
+        """One exchange with known values against torch.distributed's own all-reduce; every rank must pass."""
+        import torch.distributed as dist
+
+        torch = self.ops.torch
+        part = iface.part
+        ok = True
+        try:
+            d = iface.d
+            gd = self.ops.from_numpy((part.nodes[:, None] * d + np.arange(d)).ravel().astype(np.float64), torch.float64)
+            v = 1e-3 * gd + (self.rank + 1.0)  # a value that depends on the global entry and on the rank
+            scal = torch.tensor([self.rank + 1.0, 2.0, -0.5 * self.rank], dtype=torch.float64, device=self.ops.device)
+            out = self.exchange(iface.plan, v, scal)
+            self.check()
+            ref = scal.clone()
+            dist.all_reduce(ref, group=group)
+            ok = bool(torch.allclose(out, ref, rtol=1e-15, atol=0))
+            # interface entries: sum over the sharers s of (1e-3 gd + s + 1)
+            t = iface.tables
+            cnt = np.diff(t["src_ptr"])
+            if cnt.size:
+                ranks_sum = np.add.reduceat(t["src_rank"] + 1.0, t["src_ptr"][:-1])
+                loc = iface.local.long()
+                exp = 1e-3 * gd[loc].cpu().numpy() * cnt + ranks_sum
+                ok = ok and bool(np.allclose(v[loc].cpu().numpy(), exp, rtol=1e-14, atol=0))
+        except Exception as e:
+            PeerHalo.last_failure = f"self-test: {type(e).__name__}: {e}"
+            ok = False
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok), group=group)
+        if not all(flags):
+            if not PeerHalo.last_failure:
+                PeerHalo.last_failure = "self-test: wrong sums on some rank"
+            self.close()
+            return False
+        return True
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.pf_halo_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, check_every=50, native=None):
     """Chronopoulos-Gear single-reduction Jacobi-PCG over ranks, x0 = 0.
     Stops when ||r||_2 <= max(rtol ||b||_2, atol)  (the reference's convention, pyfem.py:2418).
     Returns (x_local, iters, relres); raises RuntimeError("cg failed with code <iters>") at maxiter
-    (pyfem.py:2421-2422)."""
+    (pyfem.py:2421-2422).
+    Per iteration ONE exchange: the interface sums of w = K z with the three scalars gamma = r.z, delta = z.w, r.r
+    riding along.  With the peer transport the whole loop runs in C (pf_dist_cg: no Python, no host work between
+    launches); otherwise this Python loop drives the same kernels through `ops` and torch.distributed."""
     n = ops.n
-    G = iface.G
-    buf = iface.buf
-    red = buf[G:]  # gamma, delta, rr
+    if native is None:
+        native = iface.transport == "peer" and hasattr(ops, "dist_cg_native")
+    if native:
+        return ops.dist_cg_native(iface, K, b, dinv, own_w, rtol, atol, maxiter, check_every)
     if hasattr(ops, "begin"):
         ops.begin()
     x, r, z, w, p, s = ops.zeros(n), b.clone(), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
     state, state_next = ops.zeros(3), ops.zeros(3)  # [alpha, beta, gamma], ping-pong
+    red = ops.zeros(3)
     bb = ops.zeros(1)
     ops.dot(b, b, own_w, bb)
-    _all_reduce(bb, iface.group)
-    bnorm = float(bb.item()) ** 0.5
+    bnorm = float(iface.allreduce_scalars(bb).item()) ** 0.5
     tol = max(rtol * bnorm, atol)
     if maxiter is None:
         maxiter = 10 * n
@@ -227,242 +584,149 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
     while it < maxiter:
         ops.cgcg_update_xrz(state, p, s, dinv, own_w, x, r, z)
         ops.spmv_dot(K, z, w)
-        ops.cgcg_reduce(red, buf, G)  # clear the interface part; local [gamma, delta, rr] into the tail
-        ops.copy_indexed(iface.n, iface.local, iface.slots, w, buf)
-        _all_reduce(buf, iface.group)
-        ops.copy_indexed(iface.n, iface.slots, iface.local, buf, w)
-        # r.r in `red` belongs to the residual after `it` updates
+        ops.cgcg_reduce(red, None, 0)  # local [gamma, delta, rr]
+        redg = iface.exchange(w, red)
+        # r.r in `redg` belongs to the residual after `it` updates
         if it % check_every == 0 or it + 1 == maxiter:
-            rnorm = float(red[2].item()) ** 0.5
+            rnorm = float(redg[2].item()) ** 0.5
             if not rnorm == rnorm or rnorm <= tol:
                 break
-        ops.cgcg_update_ps(state, state_next, red, it == 0, z, w, p, s)
+        ops.cgcg_update_ps(state, state_next, redg, it == 0, z, w, p, s)
         state, state_next = state_next, state
         it += 1
+    iface.check()
     relres = rnorm / bnorm if bnorm > 0 else rnorm
     if not rnorm <= tol:
         raise RuntimeError(f"cg failed with code {it}")
     return x, it, relres
 
 
-class BinCoarseSpace:
-    """Global coarse space for the Schwarz preconditioner: the rigid-body modes (two translations and the rotation
-    about the bin centre) of the nodes in each cell of a uniform bx x by grid over the mesh's bounding box.
+class ReplicatedHierarchy:
+    """The single-GPU smoothed-aggregation hierarchy (csrc/pf_amg.hip), set up REDUNDANTLY on every rank from the
+    assembled matrix of the whole mesh, with a DISTRIBUTED finest level -- the preconditioner of the partitioned
+    solves (counterpart of the reference's pyamg V-cycle, pyfem.py:2393-2400, 2098).
 
-    The bin of a node follows from its coordinates alone, so every rank builds the same basis Z for the nodes it
-    shares with others without any communication, and Z^T applied to the un-summed local product K_loc p adds up
-    over ranks to Z^T (K p).  E = Z^T K Z (3 bx by square, dense) is found with 27 local products: bins of one of
-    the 3 x 3 colours are three cells apart and K couples adjacent cells only (cells are at least two elements wide),
-    so one product per colour and mode separates all their columns.  E is summed over ranks once per matrix and
-    pseudo-inverted redundantly; applying Z E^+ Z^T then needs no communication of its own (Z^T r is updated from
-    Z^T (K p), which rides along with the interface sums)."""
+    Why replicate: at the sizes of BASELINE's configurations the whole numeric setup takes ~10 ms on one MI355X and
+    assembling the whole matrix 0.4 ms, against 288 GB of HBM per rank; distributing the setup would need interface
+    sums of prolongator rows and an all-reduce of the level-1 operator (300 MB at 4M quads) to save a few ms.  What
+    costs time per ITERATION is the finest level -- five products with the 1.2 GB matrix -- and that is what is
+    split: every rank smooths and forms residuals on its own rows (K_local, interface sums through `iface`), restricts
+    its owned part of the residual, the level-1 right-hand side is summed over ranks (one all-reduce of n/3 doubles),
+    levels >= 1 run redundantly (0.4-0.6 ms), and each rank prolongs back to its rows.  The V-cycle is, operation for
+    operation, the one pf_cg applies on one GPU (same aggregates, same Chebyshev factors, same transfers), so the
+    iteration counts are the single-GPU ones -- not the 10-20x of the one-level Schwarz method this replaces.
+    Limit (stated in DESIGN.md): the replicated levels bound the speed-up of an AMG-PCG iteration at ~2x on 8 GPUs;
+    distributing level 1 as well is the next step."""
 
-    def __init__(self, ops, X_local, free_mask, bbox, nelems_global, target_bins=512):
+    def __init__(self, ops, part, gctx, group=None):
         torch = ops.torch
-        self.ops = ops
-        (x0, y0), (x1, y1) = bbox
-        lx, ly = max(x1 - x0, 1e-300), max(y1 - y0, 1e-300)
-        h = (lx * ly / max(nelems_global, 1)) ** 0.5  # typical element size
-        bx = int(max(1, min(round((target_bins * lx / ly) ** 0.5), lx / (2.5 * h))))
-        by = int(max(1, min(round(target_bins / max(bx, 1)), ly / (2.5 * h))))
-        self.bx, self.by, self.nb = bx, by, bx * by
-        Xl = np.asarray(X_local, dtype=float)
-        ix = np.clip(((Xl[:, 0] - x0) / lx * bx).astype(np.int64), 0, bx - 1)
-        iy = np.clip(((Xl[:, 1] - y0) / ly * by).astype(np.int64), 0, by - 1)
-        self.bin = ops.from_numpy(ix + bx * iy, torch.int64)
-        self.colour = ops.from_numpy((ix % 3) + 3 * (iy % 3), torch.int64)
-        self.dx = ops.from_numpy(Xl[:, 0] - (x0 + (ix + 0.5) * lx / bx), torch.float64)
-        self.dy = ops.from_numpy(Xl[:, 1] - (y0 + (iy + 0.5) * ly / by), torch.float64)
-        fm = free_mask.to(torch.float64).view(-1, 2)
-        self.fx, self.fy = fm[:, 0].contiguous(), fm[:, 1].contiguous()  # Z vanishes on fixed dofs
-        self.ncoarse = 3 * self.nb
-        # neighbour of bin b with colour c inside b's 3 x 3 neighbourhood (-1: outside the grid)
-        b = np.arange(self.nb)
-        bix, biy = b % bx, b // bx
-        nbr = np.full((9, self.nb), -1, dtype=np.int64)
-        for c in range(9):
-            jx = bix + ((c % 3 - bix % 3 + 4) % 3 - 1)
-            jy = biy + ((c // 3 - biy % 3 + 4) % 3 - 1)
-            ok = (jx >= 0) & (jx < bx) & (jy >= 0) & (jy < by)
-            nbr[c, ok] = (jx + bx * jy)[ok]
-        self.nbr = ops.from_numpy(nbr, torch.int64)
-        self.Einv = None
+        self.ops, self.part, self.g, self.group = ops, part, gctx, group
+        d = part.d
+        gd = (part.nodes[:, None] * d + np.arange(d)).ravel()
+        self.gdofs = ops.from_numpy(gd.astype(np.int32), torch.int32)
+        self.gdofs64 = self.gdofs.to(torch.int64)
+        self.res_g = ops.zeros(gctx.nrows)
+        self.cor_g = ops.zeros(gctx.nrows)
+        n = ops.n
+        self.c, self.c2, self.w, self.t = ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
+        self.d1 = self.d2 = self.b1 = self.x1 = None
 
-    def ZT(self, v):
-        """Z^T v for a local vector (un-summed product, or a consistent vector times the ownership weights)."""
+    def _gcall(self, name, *a):
+        g = self.g
+        g._sync_stream()
+        g._call(name, *a)
+
+    def setup(self, Kg_vals, reuse=False):
+        """Numeric setup from the assembled, BC-applied matrix of the WHOLE mesh (values on the global context)."""
         torch = self.ops.torch
-        vx, vy = v[0::2] * self.fx, v[1::2] * self.fy
-        out = torch.zeros(self.nb, 3, dtype=torch.float64, device=v.device)
-        out[:, 0].index_add_(0, self.bin, vx)
-        out[:, 1].index_add_(0, self.bin, vy)
-        out[:, 2].index_add_(0, self.bin, self.dx * vy - self.dy * vx)
-        return out.view(-1)
-
-    def Z(self, y, out):
-        """out = Z y (consistent local vector)."""
-        yb = y.view(self.nb, 3)[self.bin]
-        out[0::2] = (yb[:, 0] - self.dy * yb[:, 2]) * self.fx
-        out[1::2] = (yb[:, 1] + self.dx * yb[:, 2]) * self.fy
-        return out
-
-    def setup(self, K, group):
-        """E = Z^T K Z summed over ranks, pseudo-inverted (empty bins and bins whose nodes do not span the three
-        modes give zero eigenvalues, which are dropped)."""
-        ops, torch = self.ops, self.ops.torch
-        n = self.bin.numel() * 2
-        E = torch.zeros(self.ncoarse, self.ncoarse, dtype=torch.float64, device=self.bin.device)
-        v, w = ops.zeros(n), ops.zeros(n)
-        rows = torch.arange(self.nb, device=self.bin.device)
-        for c in range(9):
-            sel = (self.colour == c).to(torch.float64)
-            col = self.nbr[c]
-            ok = col >= 0
-            for k in range(3):
-                v.zero_()
-                if k == 0:
-                    v[0::2] = sel * self.fx
-                elif k == 1:
-                    v[1::2] = sel * self.fy
-                else:
-                    v[0::2] = -self.dy * sel * self.fx
-                    v[1::2] = self.dx * sel * self.fy
-                ops.spmv(K, v, w)
-                t = self.ZT(w).view(self.nb, 3)
-                for kp in range(3):
-                    E[3 * rows[ok] + kp, 3 * col[ok] + k] += t[ok, kp]
-        _all_reduce(E, group)
-        E = 0.5 * (E + E.T)
-        lam, Q = torch.linalg.eigh(E)
-        keep = lam > 1e-10 * lam.max()
-        self.Einv = (Q[:, keep] / lam[keep]) @ Q[:, keep].T
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        self._gcall("pf_amg_prepare", p(Kg_vals), int(bool(reuse)))
+        n1 = self.ops._lib._i64()
+        d1g, d2g = self.ops.zeros(self.g.nrows), self.ops.zeros(self.g.nrows)
+        self._gcall("pf_amg_level0", p(d1g), p(d2g), C.byref(n1))
+        self.d1, self.d2 = d1g[self.gdofs64].contiguous(), d2g[self.gdofs64].contiguous()
+        if self.b1 is None or self.b1.numel() != n1.value:
+            self.b1, self.x1 = self.ops.zeros(n1.value), self.ops.zeros(n1.value)
         return self
 
+    def vcycle(self, K, r, z, iface, own_w):
+        """z = M^-1 r with r, z consistent local vectors; K: this rank's (sub-assembled) matrix values."""
+        ops = self.ops
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        c, c2, w, t = self.c, self.c2, self.w, self.t
+        n = ops.n
+        ops.vec_smooth(None, self.d1, r, None, c)           # first sweep from a zero guess
+        ops.spmv(K, c, w)
+        iface.sum(w)
+        ops.vec_smooth(c, self.d2, r, w, c2)                # second sweep (second Chebyshev factor)
+        ops.spmv(K, c2, w)
+        iface.sum(w)
+        ops.vec_smooth(None, own_w, r, w, t)                # owned part of the residual
+        ops.copy_indexed(n, None, self.gdofs, t, self.res_g)
+        self._gcall("pf_amg_restrict0", p(self.res_g), p(self.b1))
+        _all_reduce(self.b1, self.group)
+        self._gcall("pf_amg_coarse_solve", p(self.b1), p(self.x1))
+        self.cor_g.zero_()
+        self._gcall("pf_amg_prolong0", p(self.x1), p(self.cor_g))
+        ops.copy_indexed(n, self.gdofs, None, self.cor_g, t)
+        ops.vec_smooth(c2, None, t, None, c)                # c = c2 + correction
+        ops.spmv(K, c, w)
+        iface.sum(w)
+        ops.vec_smooth(c, self.d2, r, w, c2)                # post-smoothing in reverse order: the cycle stays symmetric
+        ops.spmv(K, c2, w)
+        iface.sum(w)
+        ops.vec_smooth(c2, self.d1, r, w, z)
+        return z
 
-def schwarz_prepare(ops, K, iface):
-    """Numeric AMG setup of this rank's block for dist_pcg_schwarz: the local matrix with a tenth of the missing part of
-    its interface diagonals added (assembled minus local value), which pins floating pieces and costs compact
-    partitions nothing (tools/dist_schwarz_rehearsal.py: 0.01 .. 0.1 give the same counts, 1.0 twice as many, 0 fails
-    on floating pieces).  Returns the shifted copy (it must stay alive while the hierarchy is in use)."""
-    import os
 
-    dloc = ops.diag(K)
-    dsum = iface.sum(dloc.clone())
-    Kp = K.clone()
-    ops.add_to_diag(Kp, (dsum - dloc) * float(os.environ.get("PF_SCHWARZ_EPS", "0.1")))
-    ops.amg_prepare(Kp)
-    return Kp
-
-
-def dist_pcg_schwarz(ops, K, b, inv_mult, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, check_every=1,
-                     coarse=None, prepared=False):
-    """PCG over ranks with a one-level additive Schwarz preconditioner whose subdomain solves are the LOCAL AMG
-    V-cycles:  M^-1 = sum_i R_i^T D A_i~^-1 D R_i,  D = 1/multiplicity on interface dofs (symmetric, so CG applies),
-    A_i~^-1 = one V-cycle on rank i's block with a fraction of the missing part of its interface DIAGONALS added
-    (assembled minus local value): the raw block is a Neumann-type problem and is singular whenever a piece of the
-    rank's mesh touches no Dirichlet node (always the case for scattered element blocks); the shifted diagonal makes
-    every local problem definite without any communication in the cycle.  There is no global coarse level yet, so
-    the iteration count grows with the number of ranks (strips of the 512x256 cantilever: 16 / 165 / ~300 iterations
-    for 1 / 2 / 4 ranks against 3600 for Jacobi).  Jacobi-PCG needs ~10^4 iterations on the 2048x1024 plane-stress
-    system; a V-cycle per rank brings that to tens, at TWO all-reduces per iteration:
-      1. interface partial sums of w = K p, with delta = p.w riding along (p_loc.(K_loc p_loc) summed over ranks);
-      2. interface sums of z = M^-1 r, with gamma = r.z (sum of (D r_loc).z_loc before the interface sum) and r.r.
-    Scalars stay on the device; the residual is read back every `check_every` iterations.  x0 = 0.
-    coarse: a BinCoarseSpace -- adds the global correction Z E^+ Z^T (two-level method); its Z^T (K p) rides along
-    with all-reduce 1, so the number of collectives per iteration stays two.
-    prepared: schwarz_prepare was already called for this matrix on ops' context (constant matrices: the filter).
-    Returns (x_local, iters, relres); raises RuntimeError("cg failed with code <iters>") at maxiter."""
-    torch = ops.torch
-    n, G = ops.n, iface.G
-    nc = coarse.ncoarse if coarse is not None else 0
-    buf = ops.zeros(G + 3 + nc) if nc else iface.buf
-    tail = buf[G:G + 3]  # three scalars ride along with the interface sums
-    ctail = buf[G + 3:]  # and the coarse-space moments of the un-summed product
+def dist_pcg_amg(ops, K, b, own_w, iface, hier, rtol=1e-8, atol=0.0, maxiter=None, check_every=1):
+    """Single-reduction PCG over ranks preconditioned with the replicated hierarchy's V-cycle (hier.setup was called for
+    the matrix K belongs to).  Per iteration: the V-cycle (four products with interface sums, one all-reduce of the
+    level-1 right-hand side) and one exchange carrying the interface sums of w = K z with gamma = r.z, delta = z.w and
+    r.r.  Same stopping rule and errors as dist_cg.  Returns (x_local, iters, relres)."""
+    n = ops.n
     if hasattr(ops, "begin"):
         ops.begin()
-    Kp = None if prepared else schwarz_prepare(ops, K, iface)  # prepared: the caller did it for this (constant) matrix
-    x, r = ops.zeros(n), b.clone()
-    w, z, zl, rs = ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
-    cr = None
-    if coarse is not None:
-        coarse.setup(K, iface.group)
-        cr = coarse.ZT(b * own_w)  # Z^T r, kept up to date from Z^T (K p)
-        _all_reduce(cr, iface.group)
-        zc = ops.zeros(n)
-
-    def precond():  # z = M^-1 r;  returns (gamma, rr) as 0-dim device tensors
-        torch.mul(r, inv_mult, out=rs)
-        ops.amg_vcycle(rs, zl)
-        gamma_loc = torch.dot(rs, zl)
-        torch.mul(zl, inv_mult, out=z)
-        buf.zero_()
-        ops.copy_indexed(iface.n, iface.local, iface.slots, z, buf)
-        tail[0] = gamma_loc
-        tail[1] = torch.dot(r * own_w, r)
-        _all_reduce(buf, iface.group)
-        ops.copy_indexed(iface.n, iface.slots, iface.local, buf, z)
-        g = tail[0].clone()
-        if coarse is not None:  # + Z E^+ Z^T r: redundant on every rank, no communication
-            y = coarse.Einv @ cr
-            z.add_(coarse.Z(y, zc))
-            g = g + torch.dot(cr, y)
-        return g, tail[1].clone()
-
-    gamma, rr = precond()
-    bnorm = float(rr.item()) ** 0.5
+    x, r, z, w, p, s, zt = ops.zeros(n), b.clone(), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
+    state, state_next = ops.zeros(3), ops.zeros(3)
+    red, g = ops.zeros(3), ops.zeros(1)
+    bb = ops.zeros(1)
+    ops.dot(b, b, own_w, bb)
+    bnorm = float(iface.allreduce_scalars(bb).item()) ** 0.5
     tol = max(rtol * bnorm, atol)
-    p = z.clone()
     if maxiter is None:
         maxiter = 10 * n
-    it, rnorm = 0, bnorm
-    while it < maxiter and rnorm > tol:
-        ops.spmv(K, p, w)
-        delta_loc = torch.dot(p, w)
-        buf.zero_()
-        ops.copy_indexed(iface.n, iface.local, iface.slots, w, buf)
-        tail[0] = delta_loc
-        if coarse is not None:
-            ctail.copy_(coarse.ZT(w))
-        _all_reduce(buf, iface.group)
-        ops.copy_indexed(iface.n, iface.slots, iface.local, buf, w)
-        alpha = gamma / tail[0]
-        x.add_(p * alpha)
-        r.sub_(w * alpha)
-        if coarse is not None:
-            cr.sub_(ctail * alpha)
-        gamma_new, rr = precond()
-        p.mul_(gamma_new / gamma).add_(z)
-        gamma = gamma_new
-        it += 1
-        if it % check_every == 0 or it == maxiter:
-            rnorm = float(rr.item()) ** 0.5
-            if rnorm != rnorm:
+    it, rnorm = 0, float("inf")
+    while it < maxiter:
+        ops.cgcg_update_xrz(state, p, s, None, own_w, x, r, zt)   # x += alpha p; r -= alpha s; partials of r.r
+        hier.vcycle(K, r, z, iface, own_w)
+        ops.spmv_dot(K, z, w)
+        ops.cgcg_reduce(red, None, 0)
+        ops.dot(r, z, own_w, g)
+        red[0:1] = g
+        redg = iface.exchange(w, red)
+        if it % check_every == 0 or it + 1 == maxiter:
+            rnorm = float(redg[2].item()) ** 0.5
+            if not rnorm == rnorm or rnorm <= tol:
                 break
+        ops.cgcg_update_ps(state, state_next, redg, it == 0, z, w, p, s)
+        state, state_next = state_next, state
+        it += 1
+    iface.check()
     relres = rnorm / bnorm if bnorm > 0 else rnorm
     if not rnorm <= tol:
         raise RuntimeError(f"cg failed with code {it}")
     return x, it, relres
-
-
-# ------------------------------------------------------------------------------------------
-# the model-level wrappers
-# ------------------------------------------------------------------------------------------
-class _NodeView:
-    """The interface of an ElementBlockPartition seen per node instead of per dof."""
-
-    def __init__(self, part):
-        d = part.d
-        self.n_iface_dofs = part.n_iface_dofs // d
-        self.iface_local_dofs = (part.iface_local_dofs[::d] // d).astype(np.int32)
-        self.iface_slots = (part.iface_slots[::d] // d).astype(np.int32)
 
 
 class PartitionedHelmholtz:
     """The Helmholtz filter (pyfem.py:2071-2177) over the same element-block partition as the model it serves:
-    K = r0^2 A + M and R = M assembled from the rank's elements, `apply` / `apply_gradient` as distributed PCG solves
-    (additive Schwarz with the local AMG cycle).  Inputs and outputs are this rank's nodal values (device tensors,
-    consistent on shared nodes)."""
+    K = r0^2 A + M and R = M assembled from the rank's elements, `apply` / `apply_gradient` as distributed AMG-PCG
+    solves (ReplicatedHierarchy; the filter matrix never changes, so its hierarchy is set up once).  Inputs and outputs
+    are this rank's nodal values (device tensors, consistent on shared nodes)."""
 
-    def __init__(self, r0, X, conn, quadrature, basis, group=None, rank=None, world=None, device=None, elem_order="index"):
+    def __init__(self, r0, X, conn, quadrature, basis, group=None, rank=None, world=None, device=None, elem_order="index",
+                 transport=None):
         import torch.distributed as dist
 
         from . import pyfem
@@ -472,23 +736,25 @@ class PartitionedHelmholtz:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group, self.rank, self.world = group, rank, world
         X = np.asarray(X, dtype=float)
+        if X.shape[1] != 2:
+            raise ValueError("the partitioned models cover 2-D meshes (3-node triangles, 4-node quads)")
         self.nnodes_global = X.shape[0]
         perm = centroid_element_order(X, conn) if elem_order == "centroid" else None
         self.part = ElementBlockPartition(conn, X.shape[0], world, rank, 1, elem_perm=perm)
         pt = self.part
         self.model = pyfem.Helmholtz(r0, X[pt.nodes], pt.conn_local, quadrature, basis, device=device)
         self.ops = HipLocalOps(self.model.hctx)
-        self.iface = Interface(self.ops, pt, group)
+        self.iface = Interface(self.ops, pt, group, transport=transport)
         torch = self.ops.torch
         self.own_w = self.ops.from_numpy(pt.own_weight, torch.float64)
-        self.inv_mult = self.ops.from_numpy(1.0 / pt.multiplicity, torch.float64)
-        self.rtol = 1e-10
+        self.rtol = 1e-11
         self.last_iters = None
-        self._Kp = schwarz_prepare(self.ops, self.model.K.vals, self.iface)  # the filter matrix never changes
+        # the whole-mesh filter matrix, assembled redundantly (0.25 ms at 4M quads), only to set the hierarchy up
+        self._gmodel = pyfem.Helmholtz(r0, X, conn, quadrature, basis, device=device)
+        self.hier = ReplicatedHierarchy(self.ops, pt, self._gmodel.hctx, group).setup(self._gmodel.K.vals)
 
     def _solve(self, b):
-        x, it, rr = dist_pcg_schwarz(self.ops, self.model.K.vals, b, self.inv_mult, self.own_w, self.iface, rtol=self.rtol,
-                                     prepared=True)
+        x, it, rr = dist_pcg_amg(self.ops, self.model.K.vals, b, self.own_w, self.iface, self.hier, rtol=self.rtol)
         self.last_iters = it
         return x
 
@@ -517,7 +783,6 @@ class PartitionedHelmholtz:
         return out
 
 
-
 class PartitionedElasticity:
     """LinearElasticity (pyfem.py:1667-2068) over an element-block partition.
 
@@ -526,7 +791,7 @@ class PartitionedElasticity:
     returns the local solution and `gather_global` assembles the global vector on every rank."""
 
     def __init__(self, X, conn, dof_fixed, dof_fixed_vals, nodal_force, quadrature, basis, E=10.0, nu=0.3, p=0.0,
-                 group=None, rank=None, world=None, device=None, elem_order="index"):
+                 group=None, rank=None, world=None, device=None, elem_order="index", transport=None):
         import torch.distributed as dist
 
         from . import pyfem
@@ -536,10 +801,9 @@ class PartitionedElasticity:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group, self.rank, self.world = group, rank, world
         X = np.asarray(X, dtype=float)
+        if X.shape[1] != 2:
+            raise ValueError("the partitioned models cover 2-D meshes (3-node triangles, 4-node quads)")
         self.nnodes_global = X.shape[0]
-        self._bbox = (tuple(X.min(axis=0)), tuple(X.max(axis=0)))
-        self._nelems_global = int(np.asarray(conn).shape[0])
-        self._coarse = None
         if elem_order not in ("index", "centroid"):
             raise ValueError("elem_order must be 'index' (contiguous element-index blocks) or 'centroid'")
         perm = centroid_element_order(X, conn) if elem_order == "centroid" else None
@@ -557,20 +821,27 @@ class PartitionedElasticity:
         if not force_local:  # compute_rhs of the reference indexes with the (possibly empty) key list
             self.model.compute_rhs = lambda: self.model.rhs
         self.ops = HipLocalOps(self.model.hctx)
-        self.iface = Interface(self.ops, pt, group)
+        self.iface = Interface(self.ops, pt, group, transport=transport)
         torch = self.ops.torch
         self.own_w = self.ops.from_numpy(pt.own_weight, torch.float64)
         self.inv_mult = self.ops.from_numpy(1.0 / pt.multiplicity, torch.float64)
         self._own_nodes = self.ops.from_numpy(pt.owned_mask_nodes.astype(np.float64), torch.float64)
         self._niface = None
         self.last_iters = None
+        self._global_args = (X, np.asarray(conn) if perm is None else np.asarray(conn)[perm], dof_fixed, dof_fixed_vals,
+                             nodal_force, quadrature, basis, E, nu, p, device)
+        self._gmodel = None
+        self._hier = None
 
     @property
     def nelems_local(self):
         return self.part.conn_local.shape[0]
 
     def compute_jacobian(self, rho=1.0, out=None):
-        """Local block of K; rho is the GLOBAL nodal density (or a scalar)."""
+        """Local block of K; rho is the GLOBAL nodal density (numpy), this rank's part (device tensor) or a scalar."""
+        torch = self.ops.torch
+        if isinstance(rho, torch.Tensor):
+            return self.model.compute_jacobian(rho, out=out)
         if hasattr(rho, "__len__"):
             rho = np.asarray(rho)[self.part.nodes]
         return self.model.compute_jacobian(rho, out=out)
@@ -587,66 +858,80 @@ class PartitionedElasticity:
             b[fixed] = 0.0 if m._fixed_vals is None else m._fixed_vals[fixed]
         return K, b
 
-    def solve(self, rho=1.0, rtol=1e-10, maxiter=None, check_every=None, precond="jacobi"):
+    # -- the replicated hierarchy (precond="amg") ---------------------------------------------------------------------
+    def _hierarchy_for(self, rho):
+        """Assemble the whole mesh's matrix on THIS rank (0.4 ms at 4M quads), apply the conditions, set the hierarchy
+        up.  rho: global nodal density (numpy / device tensor over all nodes) or a scalar."""
+        from . import pyfem
+
+        torch = self.ops.torch
+        if self._gmodel is None:
+            X, conn, dof_fixed, vals, force, q, b, E, nu, p, device = self._global_args
+            self._gmodel = pyfem.LinearElasticity(X, conn, dof_fixed, vals, force, q, b, E=E, nu=nu, p=p, device=device)
+            self._hier = ReplicatedHierarchy(self.ops, self.part, self._gmodel.hctx, self.group)
+        g = self._gmodel
+        Kg = g.compute_jacobian(rho)
+        rhs = g.hctx.zeros(g.hctx.nrows)
+        g.apply_dirichlet_bcs(Kg, rhs, enforce_symmetric_K=True)
+        self._Kg = Kg  # the hierarchy reads these values during the solve
+        return self._hier.setup(Kg.vals)
+
+    def _global_rho(self, rho):
+        """Density over ALL nodes from what the caller gave (global numpy, this rank's device part, or a scalar)."""
+        torch = self.ops.torch
+        if isinstance(rho, torch.Tensor):
+            return rho if rho.numel() == self.nnodes_global else self.gather_nodal(rho)
+        return rho
+
+    def solve(self, rho=1.0, rtol=1e-11, maxiter=None, check_every=None, precond="jacobi"):
         """Assembler.solve(method="cg") over the partition (pyfem.py:2299-2317).  precond: "jacobi" (single-reduction
-        PCG, one all-reduce per iteration) or "amg" (additive Schwarz with one local AMG V-cycle per rank, two
-        all-reduces per iteration) or "amg2" (the same plus a global rigid-body coarse space on a uniform grid of bins:
-        a third fewer iterations for a 27-product setup and a dense 3 nbins eigen-decomposition per matrix)."""
+        PCG, one neighbour exchange per iteration; the whole loop runs in C when the peer-store transport is up) or
+        "amg" (the same hierarchy pf_cg uses on one GPU, replicated, with a distributed finest level: single-GPU
+        iteration counts)."""
         K = self.compute_jacobian(rho)
         rhs = self.ops.from_numpy(self.model.compute_rhs(), self.ops.torch.float64)
         K, b = self.apply_dirichlet_bcs(K, rhs)
-        if precond in ("amg", "amg2"):
-            coarse = None
-            if precond == "amg2" and self.world > 1:  # two-level: global rigid-body coarse space on a uniform grid
-                if self._coarse is None:
-                    free = 1 - self.model._fixed_mask.to(self.ops.torch.int32)
-                    self._coarse = BinCoarseSpace(self.ops, self.model.X, free, self._bbox, self._nelems_global)
-                coarse = self._coarse
-            x, it, rr = dist_pcg_schwarz(self.ops, K.vals, b, self.inv_mult, self.own_w, self.iface, rtol=rtol,
-                                         maxiter=maxiter, check_every=check_every or 1, coarse=coarse)
+        if precond == "amg":
+            hier = self._hierarchy_for(self._global_rho(rho))
+            x, it, rr = dist_pcg_amg(self.ops, K.vals, b, self.own_w, self.iface, hier, rtol=rtol, maxiter=maxiter,
+                                     check_every=check_every or 1)
             self.last_iters, self.last_relres = it, rr
             return x
         if precond != "jacobi":
-            raise ValueError("precond must be 'jacobi', 'amg' (one-level Schwarz) or 'amg2' (with the bin coarse space)")
-        check_every = check_every or 50
+            raise ValueError("precond must be 'jacobi' or 'amg' (replicated hierarchy, distributed finest level)")
         dinv = 1.0 / self.iface.sum(self.ops.diag(K.vals))
         x, it, rr = dist_cg(self.ops, K.vals, b, dinv, self.own_w, self.iface, rtol=rtol, maxiter=maxiter,
-                            check_every=check_every)
+                            check_every=check_every or 50)
         self.last_iters, self.last_relres = it, rr
         return x
 
     # -- topology-optimisation callbacks over the partition (BASELINE configuration 5; pyfem.py:1798-1870) ------------
     def _node_iface(self):
-        """Interface sums of NODAL vectors (densities, sensitivities): the dof interface reduced to one slot per node."""
+        """Interface sums of NODAL vectors (densities, sensitivities): one entry per node, same window."""
         if self._niface is None:
-            self._niface = Interface(self.ops, _NodeView(self.part), self.group)
+            self._niface = self.iface.sibling(1)
         return self._niface
 
     def local_nodal(self, v_global):
         """This rank's entries of a global nodal vector, as a device tensor."""
         return self.ops.from_numpy(np.asarray(v_global, dtype=float)[self.part.nodes], self.ops.torch.float64)
 
-    def compliance(self, rho, precond="amg", rtol=1e-10):
+    def compliance(self, rho, precond="amg", rtol=1e-11):
         """(c, u_local): c = f.u summed over the owned dofs of every rank (one scalar all-reduce); rho is the global
         nodal density (numpy) or this rank's part (device tensor)."""
         torch = self.ops.torch
-        if isinstance(rho, torch.Tensor):
-            self._rho_local = rho
-            K = self.model.compute_jacobian(rho)
-        else:
-            self._rho_local = None
-            K = self.compute_jacobian(rho)
+        K = self.compute_jacobian(rho)
         rhs = self.ops.from_numpy(self.model.compute_rhs(), torch.float64)
         K, b = self.apply_dirichlet_bcs(K, rhs)
         if precond == "jacobi":
             dinv = 1.0 / self.iface.sum(self.ops.diag(K.vals))
             u, it, rr = dist_cg(self.ops, K.vals, b, dinv, self.own_w, self.iface, rtol=rtol)
         else:
-            u, it, rr = dist_pcg_schwarz(self.ops, K.vals, b, self.inv_mult, self.own_w, self.iface, rtol=rtol)
+            hier = self._hierarchy_for(self._global_rho(rho))
+            u, it, rr = dist_pcg_amg(self.ops, K.vals, b, self.own_w, self.iface, hier, rtol=rtol)
         self.last_iters, self.last_relres = it, rr
         c = torch.dot(b * self.own_w, u).reshape(1)
-        _all_reduce(c, self.group)
-        return float(c.item()), u
+        return float(self.iface.allreduce_scalars(c).item()), u
 
     def compliance_grad(self, rho, u_local):
         """-d(u^T K u)/d rho on this rank's nodes (pyfem.py:1837-1848): sensitivities of the local elements, summed over
@@ -659,8 +944,7 @@ class PartitionedElasticity:
     def volume(self, rho_local):
         """rho.sum() / nnodes over the whole mesh (pyfem.py:1851-1859) from this rank's nodes: one scalar all-reduce."""
         v = (rho_local * self._own_nodes).sum().reshape(1)
-        _all_reduce(v, self.group)
-        return float(v.item()) / self.nnodes_global
+        return float(self.iface.allreduce_scalars(v).item()) / self.nnodes_global
 
     def gather_nodal(self, v_local):
         """Global nodal vector on every rank from consistent local ones (one all-reduce of nnodes values)."""

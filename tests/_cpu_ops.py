@@ -47,7 +47,8 @@ class NumpyLocalOps:
         self._rr = float((ww * r * r).sum())
 
     def cgcg_reduce(self, red, zero, nzero):
-        zero[:nzero] = 0.0
+        if zero is not None:
+            zero[:nzero] = 0.0
         red[0], red[1], red[2] = self._gamma, self._delta, self._rr
 
     def cgcg_update_ps(self, state_in, state_out, red, first, z, w, p, s):
