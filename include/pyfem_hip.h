@@ -83,6 +83,10 @@ int pf_pattern_build(pf_ctx* ctx, int ndof_per_node /* 1 or the space dimension 
 int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks, int32_t* max_row_blocks);
 /* node graph (device out): nptr int32[nnodes+1], nidx int32[nblocks]; either may be NULL */
 int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx);
+/* The compact 8-byte visit records, if this mesh's numbering allows them (HOST out nvisits: 0 if not; DEVICE out
+ * rec8 uint32[2*nvisits], may be NULL): d0 = off1 | off2<<13 | (off3&63)<<26, d1 = off3>>6 | pos0<<7 | pos1<<12 |
+ * pos2<<17 | pos3<<22 | slot<<27 with 13-bit signed node offsets from the pair's own node.  For tests. */
+int pf_pattern_get_rec8(pf_ctx* ctx, int64_t* nvisits, uint32_t* rec8);
 /* scipy-layout CSR structure (device out): indptr int32[nrows+1], indices int32[nnz] */
 int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices);
 /* Gather maps of the fused assembly kernel (2-D meshes and 8-node blocks), for tests that replay its index

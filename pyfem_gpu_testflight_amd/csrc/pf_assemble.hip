@@ -358,6 +358,19 @@ __device__ __forceinline__ double buf_ld_f64(pf_rsrc r, uint32_t off) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
 }
 
+// packed word of a visit record: row positions of the rotated element's nodes and the node's slot in its tile.
+// 16-byte records: w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | slot<<26;  8-byte records: the second dword
+// d1 = (off3>>6)&127 | pos0<<7 | pos1<<12 | pos2<<17 | pos3<<22 | slot<<27   (pf_pattern.hip k_build_visits / k_build_rec8)
+template <bool REC8>
+__device__ __forceinline__ int rec_pos(uint32_t w, int k) {
+  if constexpr (REC8) return (int)((w >> (7 + 5 * k)) & 31u);
+  else return (int)((w >> (6 * k)) & 63u);
+}
+template <bool REC8>
+__device__ __forceinline__ int rec_slot(uint32_t w) {
+  return (int)((w >> (REC8 ? 27 : 26)) & 15u);
+}
+
 struct V4Rec {        // stage B: the lane's visit record + the tile's row pointers (one tile ahead)
   int4 rec;           // {o1, o2, o3, w}: rotated element, own node first (pf_pattern.hip k_build_visits)
   int32_t rp;         // lanes 0..nodes of the tile: nptr[n0 + lane]
@@ -395,12 +408,21 @@ __device__ __forceinline__ V4Tile v4_load_tile(int64_t t, int64_t t1, const int4
   return T;
 }
 
+template <bool REC8>
 __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const int4* __restrict__ vis_rec,
                                              const int32_t* __restrict__ nptr, int64_t g_nvis = 0, int64_t g_nnodes = 0) {
   V4Rec B;
   B.active = lane < T.nv;
   B.n0 = T.n0;
   B.base = T.base;
+  if constexpr (REC8) {  // 8-byte records: rec.x / rec.y hold the two dwords
+    const pf_rsrc rr = make_rsrc(reinterpret_cast<const uint2*>(vis_rec) + T.vb, (uint32_t)T.nv * 8u);
+    const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);
+    const pf_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, 0, 0);
+    B.rec = make_int4((int)r.x, (int)r.y, 0, 0);
+    B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
+    return B;
+  }
 #ifdef PF_V4_GLOBAL_REC  // experiment: plain global loads with clamped indices (the v3 form)
   B.rec = vis_rec[min((int64_t)T.vb + lane, g_nvis - 1)];
   if (!B.active) B.rec = make_int4(0, 0, 0, 0);
@@ -415,9 +437,41 @@ __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const in
   return B;
 }
 
-template <int P, bool RHO>
+template <int P, bool RHO, bool REC8>
 __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C,
                                               const double* __restrict__ g_X = nullptr) {
+  if constexpr (REC8) {
+    const uint32_t d0 = (uint32_t)B.rec.x, d1 = (uint32_t)B.rec.y;
+    const int ln = rec_slot<true>(d1);
+    C.w = d1;
+    C.active = B.active;
+    C.roff = __shfl(B.rp, ln) - B.base;
+    // a lane without a pair holds an all-zero record: offsets 0, i.e. node n0 four times -- in range
+    const int32_t n = B.n0 + ln;
+    const int32_t o1 = n + ((int32_t)(d0 << 19) >> 19);
+    const int32_t o2 = n + ((int32_t)(d0 << 6) >> 19);
+    const int32_t o3 = n + ((int32_t)(((d0 >> 26) | ((d1 & 127u) << 6)) << 19) >> 19);
+    const double2 p0 = buf_ld_f64x2(RX, (uint32_t)n * 16u);
+    const double2 p1 = buf_ld_f64x2(RX, (uint32_t)o1 * 16u);
+    const double2 p2 = buf_ld_f64x2(RX, (uint32_t)o2 * 16u);
+    C.el.x[0] = p0.x; C.el.y[0] = p0.y;
+    C.el.x[1] = p1.x; C.el.y[1] = p1.y;
+    C.el.x[2] = p2.x; C.el.y[2] = p2.y;
+    if constexpr (P == 4) {
+      const double2 p3 = buf_ld_f64x2(RX, (uint32_t)o3 * 16u);
+      C.el.x[3] = p3.x; C.el.y[3] = p3.y;
+    }
+    if constexpr (RHO) {
+      C.rho_e[0] = buf_ld_f64(Rrho, (uint32_t)n * 8u);
+      C.rho_e[1] = buf_ld_f64(Rrho, (uint32_t)o1 * 8u);
+      C.rho_e[2] = buf_ld_f64(Rrho, (uint32_t)o2 * 8u);
+      if constexpr (P == 4) C.rho_e[3] = buf_ld_f64(Rrho, (uint32_t)o3 * 8u);
+    } else {
+#pragma unroll
+      for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
+    }
+    return;
+  }
   // Triangles never read rec.z.  hipcc then hands that register of the in-flight 16-byte load to a temporary, and the
   // write-after-write hazard makes it wait for the record right behind its issue (r02 ISA: s_waitcnt vmcnt(1) one
   // instruction after the load -- a full memory latency per tile; 0.181 -> 0.212 ms on 4 M triangles).  Keeping the
@@ -479,7 +533,7 @@ __device__ __forceinline__ void v4_seg_step(int key, double x[V]) {
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
 // 8 of the 32 banks (PMC counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
 // touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
-template <int P, class Phys, bool RHO, int NOUT, bool COMB>
+template <int P, class Phys, bool RHO, int NOUT, bool COMB, bool REC8>
 __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V4Tile& Tcur,
                                         const V4Visit<P, RHO>& Cuse, double* img, int plane, int lane,
                                         double* __restrict__ out0, double* __restrict__ out1) {
@@ -510,7 +564,7 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
       // lanes first: a segmented scan over the node slot inside each row of 16 lanes (DPP row shifts: plain VALU,
       // no LDS), after which only the last lane of a node's run adds.  A run that crosses a row boundary adds twice.
       // Fixed lane order, so the result stays bitwise reproducible.
-      const int key = (int)((Cuse.w >> 26) & 15);
+      const int key = rec_slot<REC8>(Cuse.w);
       v4_seg_step<1, V>(key, v[0]);
       v4_seg_step<2, V>(key, v[0]);
       v4_seg_step<4, V>(key, v[0]);
@@ -519,7 +573,7 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
     }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      double* dst = row + (int)((Cuse.w >> (6 * b)) & 63);
+      double* dst = row + rec_pos<REC8>(Cuse.w, b);
       if (b > 0 || add_diag) {
 #pragma unroll
         for (int k = 0; k < V; ++k)
@@ -592,7 +646,7 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #ifndef PF_V4_COMB_TRI
 #define PF_V4_COMB_TRI 1
 #endif
-template <int P, class Phys, bool RHO, int NOUT, bool COMB = (P == 3 ? PF_V4_COMB_TRI : PF_V4_COMB_QUAD) != 0>
+template <int P, class Phys, bool RHO, int NOUT, bool REC8, bool COMB = (P == 3 ? PF_V4_COMB_TRI : PF_V4_COMB_QUAD) != 0>
 __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
@@ -622,10 +676,10 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   V4Tile T0 = v4_load_tile(t0, t1, tile_desc);
   V4Tile T1 = v4_load_tile(t0 + tstride, t1, tile_desc);
   V4Tile T2 = v4_load_tile(t0 + 2 * tstride, t1, tile_desc);
-  V4Rec Ba = v4_load_rec(T0, lane, vis_rec, nptr, nvis, nnodes);
-  V4Rec Bb = v4_load_rec(T1, lane, vis_rec, nptr, nvis, nnodes);
+  V4Rec Ba = v4_load_rec<REC8>(T0, lane, vis_rec, nptr, nvis, nnodes);
+  V4Rec Bb = v4_load_rec<REC8>(T1, lane, vis_rec, nptr, nvis, nnodes);
   V4Visit<P, RHO> Ca, Cb;
-  v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca, X);
+  v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca, X);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -640,17 +694,17 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
     const V4Tile T3 = v4_load_tile(t + 3 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO>(Bb, RX, Rrho, Cb, X);
-    Ba = v4_load_rec(T2, lane, vis_rec, nptr, nvis, nnodes);
-    v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T0, Ca, img, plane, lane, out0, out1);
+    v4_load_visit<P, RHO, REC8>(Bb, RX, Rrho, Cb, X);
+    Ba = v4_load_rec<REC8>(T2, lane, vis_rec, nptr, nvis, nnodes);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T0, Ca, img, plane, lane, out0, out1);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V4Tile T4 = v4_load_tile(t + 4 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO>(Ba, RX, Rrho, Ca, X);
-    Bb = v4_load_rec(T3, lane, vis_rec, nptr, nvis, nnodes);
-    v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T1, Cb, img, plane, lane, out0, out1);
+    v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca, X);
+    Bb = v4_load_rec<REC8>(T3, lane, vis_rec, nptr, nvis, nnodes);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T1, Cb, img, plane, lane, out0, out1);
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (t < t1) v4_tile<P, Phys, RHO, NOUT, COMB>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
+  if (t < t1) v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -890,11 +944,12 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
   const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
   const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
-  auto k4 = k_assemble_v4<P, Phys, RHO, 0>;
+  const bool r8 = ctx->vis_rec8 != nullptr;  // compact records whenever the symbolic phase could build them
+  auto k4 = r8 ? k_assemble_v4<P, Phys, RHO, 0, true> : k_assemble_v4<P, Phys, RHO, 0, false>;
   int nout = 0;
-  if (per_lane <= 3) { k4 = k_assemble_v4<P, Phys, RHO, 3>; nout = 3; }
-  else if (per_lane <= 5) { k4 = k_assemble_v4<P, Phys, RHO, 5>; nout = 5; }
-  else if (per_lane <= 10) { k4 = k_assemble_v4<P, Phys, RHO, 10>; nout = 10; }
+  if (per_lane <= 3) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 3, true> : k_assemble_v4<P, Phys, RHO, 3, false>; nout = 3; }
+  else if (per_lane <= 5) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 5, true> : k_assemble_v4<P, Phys, RHO, 5, false>; nout = 5; }
+  else if (per_lane <= 10) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 10, true> : k_assemble_v4<P, Phys, RHO, 10, false>; nout = 10; }
   else nout = per_lane;
   // image + the run-over of the copy-out's LDS reads (pieces past the segment end are read and then dropped)
   const size_t plane = (size_t)ctx->npt * ctx->max_row_blocks + 1;
@@ -908,8 +963,8 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   // elasticity kernel, 24-32 for the others).  More than that and the surplus waves only start when the first ones
   // have finished their share -- a second, half-empty round (r02: 24 launched / 16 resident cost the quad kernel a
   // quarter of its time); fewer and latency is not covered.  Capped at 32 per CU (r01 sweep: no gain beyond).
-  static thread_local struct { size_t lds; int wpc; } occ[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};  // per copy-out variant
-  auto& oc = occ[nout == 3 ? 1 : nout == 5 ? 2 : nout == 10 ? 3 : 0];
+  static thread_local struct { size_t lds; int wpc; } occ[8] = {};  // per copy-out variant and record width
+  auto& oc = occ[(nout == 3 ? 1 : nout == 5 ? 2 : nout == 10 ? 3 : 0) + (r8 ? 4 : 0)];
   if (oc.wpc == 0 || oc.lds != lds4) {
     int q = 0;
     PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(k4), 64, lds4));
@@ -927,7 +982,8 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   if (tile_order == 2 && (grid & 7)) tile_order = 1;
   hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks,
                      ctx->X, ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc),
-                     reinterpret_cast<const int4*>(ctx->vis_rec), (int64_t)(ctx->nelems * ctx->P), tile_order, pr, out0, out1);
+                     reinterpret_cast<const int4*>(r8 ? ctx->vis_rec8 : ctx->vis_rec), (int64_t)(ctx->nelems * ctx->P), tile_order,
+                     pr, out0, out1);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

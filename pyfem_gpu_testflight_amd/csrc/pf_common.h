@@ -59,6 +59,8 @@ struct pf_ctx {
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
                                //   (blocks: 3 x int4 = 8 node ids, 8 position bytes, local index, tile slot)
+  void* vis_rec8 = nullptr;    // (nelems*P) uint2: the same records in 8 bytes (13-bit node offsets, 5-bit positions) when
+                               //   the numbering allows it, else nullptr (pf_pattern.hip k_build_rec8)
   int npt = 0;                 // max nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
   void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | visits<<8 | blocks<<16}
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible

@@ -214,6 +214,42 @@ __global__ void k_build_visits(int64_t nnodes, const uint8_t* __restrict__ slot,
   }
 }
 
+// Compact 8-byte visit records (k_assemble_v4<.., REC8>): the same content as the 16-byte ones with the other nodes as
+// 13-bit signed offsets from the lane's own node and 5-bit row positions,
+//   d0 = off1 | off2 << 13 | (off3 & 63) << 26
+//   d1 = (off3 >> 6) & 127 | pos0 << 7 | pos1 << 12 | pos2 << 17 | pos3 << 22 | slot << 27
+// Half the record stream of the quad assembly (32 instead of 64 bytes per element; r01/r02: the kernel is HBM-bound and
+// moved 1.23x its algorithmic bytes, a third of the excess being this stream).  Usable when every neighbour is within
+// +-4095 node ids of the node (any banded numbering: +-2050 on the 2048^2 grid) and rows have at most 32 blocks;
+// otherwise flag[0] is raised and the 16-byte records stay in use.
+template <int P>
+__global__ void k_build_rec8(int64_t nnodes, const int32_t* __restrict__ n2e_ptr, const int4* __restrict__ vis_rec,
+                             uint2* __restrict__ rec8, int32_t* __restrict__ flag) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int4 r = vis_rec[jj];
+    const uint32_t w = (uint32_t)r.w;
+    const int32_t o[3] = {r.x, r.y, r.z};
+    uint32_t off[3] = {0, 0, 0};
+    bool ok = true;
+    for (int k = 0; k < P - 1; ++k) {
+      const int64_t d = (int64_t)o[k] - n;
+      ok = ok && d >= -4096 && d <= 4095;
+      off[k] = (uint32_t)d & 8191u;
+    }
+    uint32_t d1 = (off[2] >> 6) & 127u;
+    for (int k = 0; k < P; ++k) {
+      const uint32_t pos = (w >> (6 * k)) & 63u;
+      ok = ok && pos < 32u;
+      d1 |= pos << (7 + 5 * k);
+    }
+    d1 |= ((w >> 26) & 15u) << 27;
+    if (!ok) { flag[0] = 1; return; }
+    rec8[jj] = make_uint2(off[0] | (off[1] << 13) | ((off[2] & 63u) << 26), d1);
+  }
+}
+
 // 8-node blocks: three int4 per incident pair jj of node n:
 //   {id0..id3}, {id4..id7}  (all element nodes, n included) and {pos0..3 bytes, pos4..7 bytes, a | slot<<8, 0}
 __global__ void k_build_visits8(int64_t nnodes, const uint8_t* __restrict__ slot, const int32_t* __restrict__ conn,
@@ -324,6 +360,7 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->diagpos);
   pf_free(ctx->e2pos);
   pf_free(ctx->vis_rec);
+  pf_free(ctx->vis_rec8);
   pf_free(ctx->tile_desc);
   pf_free(ctx->tab_order);
   ctx->tab_color_ptr.clear();
@@ -587,6 +624,21 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     else
       k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     PF_LAUNCH_CHECK();
+    if (ctx->P != 8) {  // compact records when the numbering allows them
+      int32_t* f8 = nullptr;
+      PF_HIP(hipMalloc(&ctx->vis_rec8, sizeof(uint2) * (size_t)total));
+      PF_HIP(hipMalloc(&f8, sizeof(int32_t)));
+      PF_HIP(hipMemsetAsync(f8, 0, sizeof(int32_t), ctx->stream));
+      if (ctx->P == 4)
+        k_build_rec8<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
+      else
+        k_build_rec8<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
+      int32_t bad = 0;
+      PF_HIP(hipMemcpyAsync(&bad, f8, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+      PF_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(f8);
+      if (bad || pf_exp_env("PF_NO_REC8")) pf_free(ctx->vis_rec8);
+    }
     PF_HIP(hipStreamSynchronize(ctx->stream));  // the host staging vectors go out of scope
     (void)hipFree(dslot);
   }
@@ -637,6 +689,15 @@ extern "C" int pf_pattern_get_tiles(pf_ctx* ctx, int64_t* ntiles, int32_t* npt, 
   if (tile_desc) PF_HIP(hipMemcpyAsync(tile_desc, ctx->tile_desc, sizeof(int32_t) * 4 * ctx->ntiles, hipMemcpyDeviceToDevice, ctx->stream));
   if (vis_rec) PF_HIP(hipMemcpyAsync(vis_rec, ctx->vis_rec, sizeof(int32_t) * 4 * nv * (ctx->P == 8 ? 3 : 1), hipMemcpyDeviceToDevice, ctx->stream));
   if (n2e_ptr) PF_HIP(hipMemcpyAsync(n2e_ptr, ctx->n2e_ptr, sizeof(int32_t) * (ctx->nnodes + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_get_rec8(pf_ctx* ctx, int64_t* nvisits, uint32_t* rec8) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_pattern_get_rec8: no pattern built");
+  if (nvisits) *nvisits = ctx->vis_rec8 ? ctx->nelems * ctx->P : 0;
+  if (rec8 && ctx->vis_rec8)
+    PF_HIP(hipMemcpyAsync(rec8, ctx->vis_rec8, sizeof(uint2) * (size_t)(ctx->nelems * ctx->P), hipMemcpyDeviceToDevice, ctx->stream));
   return PF_OK;
 }
 

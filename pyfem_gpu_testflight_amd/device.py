@@ -153,8 +153,8 @@ class HipContext:
 
     def assembly_maps(self):
         """Host copies of the fused assembly kernel's gather maps (pf_pattern_get_tiles): dict with npt, tile_desc
-        (ntiles,4), vis_rec (nvisits,4 | 12), n2e_ptr (nnodes+1), nptr (nnodes+1).  For tests that replay the kernel's
-        index arithmetic."""
+        (ntiles,4), vis_rec (nvisits,4 | 12), rec8 (nvisits,2) uint32 or None (the compact records, when the numbering allows them), n2e_ptr
+        (nnodes+1), nptr (nnodes+1).  For tests that replay the kernel's index arithmetic."""
         torch = self.torch
         nt, npt, nv = _lib._i64(), _lib._i32(), _lib._i64()
         self._sync_stream()
@@ -165,7 +165,14 @@ class HipContext:
         n2e = self.empty(self.nnodes + 1, torch.int32)
         self._call("pf_pattern_get_tiles", None, None, None, _ptr(td), _ptr(vr), _ptr(n2e))
         nptr, _ = self.graph()
-        return {"npt": npt.value, "tile_desc": td.cpu().numpy().reshape(-1, 4), "vis_rec": vr.cpu().numpy().reshape(-1, w),
+        n8 = _lib._i64()
+        self._call("pf_pattern_get_rec8", C.byref(n8), None)
+        rec8 = None
+        if n8.value:
+            r8 = self.empty(2 * n8.value, torch.int32)
+            self._call("pf_pattern_get_rec8", None, _ptr(r8))
+            rec8 = r8.cpu().numpy().view(np.uint32).reshape(-1, 2)
+        return {"npt": npt.value, "rec8": rec8, "tile_desc": td.cpu().numpy().reshape(-1, 4), "vis_rec": vr.cpu().numpy().reshape(-1, w),
                 "n2e_ptr": n2e.cpu().numpy(), "nptr": nptr.cpu().numpy()}
 
     # -- numeric --------------------------------------------------------------------------

@@ -297,7 +297,7 @@ class Interface:
         self.halo = None
         self.plan = -1
         want = transport or os.environ.get("PF_DIST_TRANSPORT") or None
-        native_possible = hasattr(ops, "h") and _dist_on(group)
+        native_possible = hasattr(ops, "h") and (part.world == 1 or _dist_on(group))
         if halo is not None:  # share an existing window (another vector shape on the same partition)
             self.halo = halo
             self.plan = halo.add_plan(t)
@@ -325,6 +325,8 @@ class Interface:
         import torch.distributed as dist
 
         per_node = max((self.part.shared_nodes[r].size for r in self.part.neighbours), default=0)
+        if self.part.world == 1:
+            return 8
         caps = [None] * dist.get_world_size(group)
         dist.all_gather_object(caps, int(per_node), group=group)
         return 3 * max(caps)
@@ -445,6 +447,12 @@ class PeerHalo:
         import torch.distributed as dist
 
         world, rank = part.world, part.rank
+        if world == 1:  # a window without peers: the native loop runs unchanged (one rank, no stores across xGMI)
+            try:
+                return cls(ops, 1, 0, cap)
+            except Exception as e:
+                cls.last_failure = f"{type(e).__name__}: {e}"
+                return None
         h, handle, why = None, None, ""
         try:
             h = cls(ops, world, rank, cap)
@@ -513,6 +521,8 @@ class PeerHalo:
 
         torch = self.ops.torch
         part = iface.part
+        if self.world == 1:
+            return True
         ok = True
         try:
             d = iface.d

@@ -77,6 +77,20 @@ def _replay(maps, nnodes, P, max_row_blocks, d, conn):
         # copy-out: the store resource ends with the segment (nblk blocks); LDS reads run over by < 32 NOUT doubles,
         # which the launcher allocates (pf_assemble.hip launch_gather)
     assert covered_nodes == nnodes and covered_vis == nvis and covered_blocks == nptr[-1]
+    # the compact 8-byte records (used whenever they exist) must decode to exactly the 16-byte ones
+    r8 = maps.get("rec8")
+    if r8 is not None:
+        d0, d1 = r8[:, 0].astype(np.int64), r8[:, 1].astype(np.int64)
+        own = np.repeat(np.arange(nnodes), np.diff(n2e))  # the node of every visit
+        sext = lambda v: ((v & 8191) ^ 4096) - 4096  # noqa: E731
+        offs = [sext(d0), sext(d0 >> 13), sext((d0 >> 26) | ((d1 & 127) << 6))]
+        w16 = vr[:, 3].astype(np.int64) & 0xFFFFFFFF
+        for k in range(P - 1):
+            assert np.array_equal(own + offs[k], vr[:, k].astype(np.int64)), f"rec8: node {k + 1} decodes differently"
+        for k in range(P):
+            assert np.array_equal((d1 >> (7 + 5 * k)) & 31, (w16 >> (6 * k)) & 63)
+        assert np.array_equal((d1 >> 27) & 15, (w16 >> 26) & 15)
+    return r8 is not None
 
 
 def _fan_mesh(k):
@@ -123,5 +137,12 @@ def test_every_index_the_assembly_kernel_forms_is_in_range(pf, d):
             conn[-1, 2] = X.shape[0] - 1
         h = HipContext(X, conn, d)
         maps = h.assembly_maps()
-        _replay(maps, h.nnodes, h.P, h.max_row_blocks, d, conn)
+        compact = _replay(maps, h.nnodes, h.P, h.max_row_blocks, d, conn)
+        assert compact == (name != "fan63")  # 64 blocks in the hub's row: positions need 6 bits -> 16-byte records
         h.close()
+    # a numbering that scatters neighbours more than 4095 node ids apart falls back to the 16-byte records
+    c = pf.ProblemCreator(nnodes_x=5000, nnodes_y=3)
+    conn, X, _, _ = c.create_linear_elasticity_problem()
+    h = HipContext(X, conn, d)
+    assert h.assembly_maps()["rec8"] is None
+    h.close()
