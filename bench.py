@@ -206,7 +206,7 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         model4m.p = 5.0
         rho = torch.rand(h.nnodes, dtype=torch.float64, device=dev) * 0.7 + 0.3
         ms = timer(lambda: model4m.compute_jacobian(rho, out=K4m), 20)
-        legs["rho"] = {"workload": "2048x2048 quads, nodal RAMP density p=5 (k_assemble_v3<4,Elasticity<4,true>>)",
+        legs["rho"] = {"workload": "2048x2048 quads, nodal RAMP density p=5 (k_assemble_v4<4,Elasticity<4,true>,..>)",
                        "elements_per_s": h.nelems / (ms * 1e-3),
                        **roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, with_rho=True), ms, ceil.get("mix"))}
         model4m.p = 0.0
@@ -465,14 +465,19 @@ def main():
     cg_rate = iters / t_cg
 
     # HBM traffic per launch: replayed from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
-    # passes of this command), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE of a 16-B/lane coalesced stream
-    # is under-reported x2 -- the whole SpMV stream, and of the assembly's reads the visit-record stream only (the
-    # half of its 16 B x 4 nelems the counter misses is added back; the gathers are left as counted).
+    # passes of this command), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE of a wide coalesced stream is
+    # tallied at half its bytes (128-byte requests counted as 64) -- the whole SpMV stream, and of the assembly's
+    # reads the visit-record stream (8 bytes per incident pair with the compact records: half of it is added back;
+    # the coordinate gathers are left as counted).
     traffic_asm = traffic_spmv = src_asm = src_spmv = None
     if nx == 2048 and world == 1:
-        t, _, src_asm = pmc_traffic("k_assemble_v3<4, Elasticity<4, false>")
+        t, _, src_asm = pmc_traffic("k_assemble_v4<4, Elasticity<4, false>")
         if t is not None:
-            traffic_asm = t + 0.5 * 16.0 * 4 * h.nelems
+            traffic_asm = t + 0.5 * 8.0 * 4 * h.nelems
+        else:  # this round's profile is not there yet: round 1's kernel (16-byte records)
+            t, _, src_asm = pmc_traffic("k_assemble_v3<4, Elasticity<4, false>")
+            if t is not None:
+                traffic_asm = t + 0.5 * 16.0 * 4 * h.nelems
         t, fetch_kb, src_spmv = pmc_traffic("k_spmv<2")
         if t is not None:
             traffic_spmv = t + 1024.0 * fetch_kb  # FETCH counted twice
@@ -486,7 +491,7 @@ def main():
                                f"{nelems_total} elements, ndof={2 * (nx + 1) ** 2}, element-block partition over "
                                f"{world} GPU(s)", "nelems": nelems_total, "cg_iters_timed": int(iters)},
         "cg_iter_per_sec": cg_rate, **cg_extra,
-        "roofline": {"bound": "hbm", "kernel": "k_assemble_v3<4,Elasticity<4,false>>", "achieved": asm_gbs,
+        "roofline": {"bound": "hbm", "kernel": "k_assemble_v4<4,Elasticity<4,false>,false,5,true>", "achieved": asm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
                      "traffic_source": None if src_asm is None else f"replay of {src_asm} (committed rocprofv3 --pmc "
                                                                    "passes of this command; not measured in this run)",

@@ -410,7 +410,7 @@ __device__ __forceinline__ V4Tile v4_load_tile(int64_t t, int64_t t1, const int4
 
 template <bool REC8>
 __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const int4* __restrict__ vis_rec,
-                                             const int32_t* __restrict__ nptr, int64_t g_nvis = 0, int64_t g_nnodes = 0) {
+                                             const int32_t* __restrict__ nptr) {
   V4Rec B;
   B.active = lane < T.nv;
   B.n0 = T.n0;
@@ -423,23 +423,16 @@ __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const in
     B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
     return B;
   }
-#ifdef PF_V4_GLOBAL_REC  // experiment: plain global loads with clamped indices (the v3 form)
-  B.rec = vis_rec[min((int64_t)T.vb + lane, g_nvis - 1)];
-  if (!B.active) B.rec = make_int4(0, 0, 0, 0);
-  B.rp = nptr[min((int64_t)T.n0 + lane, g_nnodes)];
-#else
   const pf_rsrc rr = make_rsrc(vis_rec + T.vb, (uint32_t)T.nv * 16u);         // this tile's records only
   const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);      // and its nn + 1 row pointers
   const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
   B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
-#endif
   return B;
 }
 
 template <int P, bool RHO, bool REC8>
-__device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C,
-                                              const double* __restrict__ g_X = nullptr) {
+__device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C) {
   if constexpr (REC8) {
     const uint32_t d0 = (uint32_t)B.rec.x, d1 = (uint32_t)B.rec.y;
     const int ln = rec_slot<true>(d1);
@@ -484,24 +477,14 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
   C.roff = __shfl(B.rp, ln) - B.base;
   // a lane without a pair holds an all-zero record: its gathers read node n0 and node 0, both in range
   const uint32_t n = (uint32_t)(B.n0 + ln);
-#ifdef PF_V4_GLOBAL_GATHER  // experiment: 64-bit global addressing (the v3 form)
-  const double2 p0 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)n);
-  const double2 p1 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.x);
-  const double2 p2 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.y);
-#else
   const double2 p0 = buf_ld_f64x2(RX, n * 16u);
   const double2 p1 = buf_ld_f64x2(RX, (uint32_t)B.rec.x * 16u);
   const double2 p2 = buf_ld_f64x2(RX, (uint32_t)B.rec.y * 16u);
-#endif
   C.el.x[0] = p0.x; C.el.y[0] = p0.y;
   C.el.x[1] = p1.x; C.el.y[1] = p1.y;
   C.el.x[2] = p2.x; C.el.y[2] = p2.y;
   if constexpr (P == 4) {
-#ifdef PF_V4_GLOBAL_GATHER
-    const double2 p3 = *reinterpret_cast<const double2*>(g_X + 2 * (int64_t)B.rec.z);
-#else
     const double2 p3 = buf_ld_f64x2(RX, (uint32_t)B.rec.z * 16u);
-#endif
     C.el.x[3] = p3.x; C.el.y[3] = p3.y;
   }
   if constexpr (RHO) {
@@ -539,17 +522,12 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
                                         double* __restrict__ out0, double* __restrict__ out1) {
   constexpr int V = Phys::V;
   // clear the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
-#ifdef PF_V4_ZERO_TILE
-  for (int k = 0; k < V; ++k)   // experiment: clear only the blocks this tile uses, plane by plane
-    for (int32_t q = lane; q < Tcur.nblk; q += 64) img[k * plane + q] = 0.0;
-#else
   {  // whole 1 KiB wave stores, a wave-uniform trip count (scalar loop): the allocation is rounded up to that
     pf_f64x2* img2 = reinterpret_cast<pf_f64x2*>(img) + lane;
     const int nzit = (V * plane + 127) >> 7;
     const pf_f64x2 z = {0.0, 0.0};
     for (int it = 0; it < nzit; ++it) img2[64 * it] = z;
   }
-#endif
 
   if (Cuse.active) {
     double v[P][V];
@@ -576,8 +554,9 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
       double* dst = row + rec_pos<REC8>(Cuse.w, b);
       if (b > 0 || add_diag) {
 #pragma unroll
-        for (int k = 0; k < V; ++k)
+        for (int k = 0; k < V; ++k) {
           __hip_atomic_fetch_add(dst + k * plane, v[b][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
       }
     }
   }
@@ -592,24 +571,11 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
     const double* a0 = img + (lane & 1) * 2 * plane + (lane >> 1);
     const double* a1 = a0 + plane;
     if constexpr (NOUT > 0) {
-#ifdef PF_V4_GLOBAL_STORE  // experiment: clamped global stores (the v3 form)
-      const int32_t np = nblk * 2;
-      double2* d4 = reinterpret_cast<double2*>(out0) + 2 * (int64_t)Tcur.base;
-      if (np > 0) {
-#pragma unroll
-        for (int u = 0; u < NOUT; ++u) {
-          const int32_t q = min(lane + 64 * u, np - 1);
-          const int32_t tb = q >> 1, h2 = (q & 1) * 2;
-          d4[q] = make_double2(img[h2 * plane + tb], img[(h2 + 1) * plane + tb]);
-        }
-      }
-#else
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
       }
-#endif
     } else {
       for (int u = 0; 32 * u < nblk; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
@@ -637,16 +603,9 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
   }
 }
 
-#ifndef PF_V4_WPE
-#define PF_V4_WPE 3
-#endif
-#ifndef PF_V4_COMB_QUAD
-#define PF_V4_COMB_QUAD 0
-#endif
-#ifndef PF_V4_COMB_TRI
-#define PF_V4_COMB_TRI 1
-#endif
-template <int P, class Phys, bool RHO, int NOUT, bool REC8, bool COMB = (P == 3 ? PF_V4_COMB_TRI : PF_V4_COMB_QUAD) != 0>
+// COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it takes 0.191 ms back
+// to 0.156 ms on 4 M elements; quads are HBM-bound and measured the same with and without it (profiles/r02_assembly_ab.md)
+template <int P, class Phys, bool RHO, int NOUT, bool REC8, bool COMB = (P == 3)>
 __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
@@ -676,10 +635,10 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   V4Tile T0 = v4_load_tile(t0, t1, tile_desc);
   V4Tile T1 = v4_load_tile(t0 + tstride, t1, tile_desc);
   V4Tile T2 = v4_load_tile(t0 + 2 * tstride, t1, tile_desc);
-  V4Rec Ba = v4_load_rec<REC8>(T0, lane, vis_rec, nptr, nvis, nnodes);
-  V4Rec Bb = v4_load_rec<REC8>(T1, lane, vis_rec, nptr, nvis, nnodes);
+  V4Rec Ba = v4_load_rec<REC8>(T0, lane, vis_rec, nptr);
+  V4Rec Bb = v4_load_rec<REC8>(T1, lane, vis_rec, nptr);
   V4Visit<P, RHO> Ca, Cb;
-  v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca, X);
+  v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -694,13 +653,13 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   for (; t + tstride < t1; t += 2 * tstride) {
     // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
     const V4Tile T3 = v4_load_tile(t + 3 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO, REC8>(Bb, RX, Rrho, Cb, X);
-    Ba = v4_load_rec<REC8>(T2, lane, vis_rec, nptr, nvis, nnodes);
+    v4_load_visit<P, RHO, REC8>(Bb, RX, Rrho, Cb);
+    Ba = v4_load_rec<REC8>(T2, lane, vis_rec, nptr);
     v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T0, Ca, img, plane, lane, out0, out1);
     // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
     const V4Tile T4 = v4_load_tile(t + 4 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca, X);
-    Bb = v4_load_rec<REC8>(T3, lane, vis_rec, nptr, nvis, nnodes);
+    v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca);
+    Bb = v4_load_rec<REC8>(T3, lane, vis_rec, nptr);
     v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T1, Cb, img, plane, lane, out0, out1);
     T0 = T2; T1 = T3; T2 = T4;
   }
@@ -944,7 +903,9 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
   const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
   const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
-  const bool r8 = ctx->vis_rec8 != nullptr;  // compact records whenever the symbolic phase could build them
+  // compact records whenever the symbolic phase built them (quads: r02 A/B on 4M elements -- triangles ran 2.5 % slower
+  // with them, the quad Helmholtz kernel 2.6 % faster, quad elasticity the same with 8 % less traffic)
+  const bool r8 = ctx->vis_rec8 != nullptr;
   auto k4 = r8 ? k_assemble_v4<P, Phys, RHO, 0, true> : k_assemble_v4<P, Phys, RHO, 0, false>;
   int nout = 0;
   if (per_lane <= 3) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 3, true> : k_assemble_v4<P, Phys, RHO, 3, false>; nout = 3; }

@@ -624,15 +624,12 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     else
       k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     PF_LAUNCH_CHECK();
-    if (ctx->P != 8) {  // compact records when the numbering allows them
+    if (ctx->P == 4) {  // compact records for quads when the numbering allows them
       int32_t* f8 = nullptr;
       PF_HIP(hipMalloc(&ctx->vis_rec8, sizeof(uint2) * (size_t)total));
       PF_HIP(hipMalloc(&f8, sizeof(int32_t)));
       PF_HIP(hipMemsetAsync(f8, 0, sizeof(int32_t), ctx->stream));
-      if (ctx->P == 4)
-        k_build_rec8<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
-      else
-        k_build_rec8<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
+      k_build_rec8<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
       int32_t bad = 0;
       PF_HIP(hipMemcpyAsync(&bad, f8, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
       PF_HIP(hipStreamSynchronize(ctx->stream));

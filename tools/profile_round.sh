@@ -3,13 +3,13 @@
 # command, then tools/summarize_prof.py writes the files that get copied to profiles/.
 #   gpurun -- 'bash tools/profile_round.sh r01'
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --cg-iters 100 --no-cpu-baseline"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py > $OUT/trace.log 2>&1 || exit 1
+BENCH="python3 $REPO/bench.py --cg-iters 100 --no-cpu-baseline --legs rho,c3,c4"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
 echo "pmc fetch done"
