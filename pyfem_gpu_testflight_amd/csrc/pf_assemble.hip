@@ -511,6 +511,16 @@ __device__ __forceinline__ void v4_seg_step(int key, double x[V]) {
   }
 }
 
+#ifdef PF_EXPERIMENTS
+// PF_ABL_WRAP_MB (experiments build only): every tile's copy-out lands inside the first N MB of the value array, so the
+// written lines are overwritten in cache instead of streaming to HBM -- wrong K, for one question only: how fast is the
+// kernel when its HBM write stream is (almost) taken away?
+__device__ int64_t g_abl_wrap_blocks = 0;
+// PF_ABL_MASK (experiments build only; wrong results, timing only): 1 no LDS adds, 2 no LDS clear, 4 no quadrature
+// (the values are the gathered coordinates), 8 no copy-out
+__device__ int g_abl_mask = 0;
+#endif
+
 // integrate tile Tcur from Cuse into the LDS image and copy the finished segment out.
 // Image layout: V planes of `plane` doubles, value k of the tile's block B at img[k*plane + B].  With the
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
@@ -522,6 +532,10 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
                                         double* __restrict__ out0, double* __restrict__ out1) {
   constexpr int V = Phys::V;
   // clear the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
+#ifdef PF_EXPERIMENTS
+  const int abl = g_abl_mask;
+  if (!(abl & 2))
+#endif
   {  // whole 1 KiB wave stores, a wave-uniform trip count (scalar loop): the allocation is rounded up to that
     pf_f64x2* img2 = reinterpret_cast<pf_f64x2*>(img) + lane;
     const int nzit = (V * plane + 127) >> 7;
@@ -531,6 +545,14 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 
   if (Cuse.active) {
     double v[P][V];
+#ifdef PF_EXPERIMENTS
+    if (abl & 4) {
+#pragma unroll
+      for (int b = 0; b < P; ++b)
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[b][k] = Cuse.el.x[b] + (double)k * Cuse.el.y[b];
+    } else
+#endif
     element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, 0, v);  // the lane's node is local node 0 (rotated record)
     double* row = img + Cuse.roff;
     bool add_diag = true;
@@ -552,6 +574,9 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #pragma unroll
     for (int b = 0; b < P; ++b) {
       double* dst = row + rec_pos<REC8>(Cuse.w, b);
+#ifdef PF_EXPERIMENTS
+      if (abl & 1) { if (v[b][0] == 1.2345e300) dst[0] = v[b][V > 1 ? 1 : 0] + v[b][V - 1]; continue; }  // keeps v alive, adds nothing
+#endif
       if (b > 0 || add_diag) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -565,8 +590,16 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
   // hardware, so the store COUNT is static (NOUT > 0: hipcc can then count what is in flight behind a prefetch and
   // keeps every s_waitcnt vmcnt partial) without clamps or branches; an empty tile (isolated nodes) stores nothing.
   const int32_t nblk = Tcur.nblk;
+#ifdef PF_EXPERIMENTS
+  if (abl & 8) return;
+#endif
   if constexpr (V == 4) {
+#ifdef PF_EXPERIMENTS
+    const int64_t wb = g_abl_wrap_blocks;
+    const pf_rsrc ro = make_rsrc(out0 + 4 * (wb ? (int64_t)Tcur.base % wb : (int64_t)Tcur.base), (uint32_t)nblk * 32u);
+#else
     const pf_rsrc ro = make_rsrc(out0 + 4 * (int64_t)Tcur.base, (uint32_t)nblk * 32u);
+#endif
     // piece q = lane + 64 u = values (2 (q & 1), 2 (q & 1) + 1) of block q >> 1:  (q >> 1) = (lane >> 1) + 32 u
     const double* a0 = img + (lane & 1) * 2 * plane + (lane >> 1);
     const double* a1 = a0 + plane;
@@ -919,6 +952,16 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node rows too long for the LDS image of a tile");
   if (lds4 > 48 * 1024)
     PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));
+#ifdef PF_EXPERIMENTS
+  {
+    const char* wm = pf_exp_env("PF_ABL_WRAP_MB");
+    const int64_t wrap_blocks = (wm && atoi(wm) > 0) ? (int64_t)atoi(wm) * 1024 * 1024 / 32 : 0;
+    PF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl_wrap_blocks), &wrap_blocks, sizeof(wrap_blocks), 0, hipMemcpyHostToDevice, ctx->stream));
+    const char* am = pf_exp_env("PF_ABL_MASK");
+    const int mask = am ? atoi(am) : 0;
+    PF_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_abl_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, ctx->stream));
+  }
+#endif
   const int64_t nt = ctx->ntiles;
   // persistent waves: exactly as many as are resident at once (registers and LDS decide: 16 per CU for the quad
   // elasticity kernel, 24-32 for the others).  More than that and the surplus waves only start when the first ones
