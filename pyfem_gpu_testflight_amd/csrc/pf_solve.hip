@@ -571,6 +571,66 @@ __global__ __launch_bounds__(256) void k_cgcg_update_ps(int64_t n, const double*
   }
 }
 
+// The two vector kernels of one single-reduction iteration in ONE pass (pf_dist_cg): from the reduced scalars
+// red = [gamma, delta, rr] and the previous state,  beta, alpha as in k_cgcg_update_ps;  p = z + beta p;  s = w + beta s;
+// x += alpha p;  r -= alpha s;  z = dinv r;  partials of sum own r z and sum own r r for the next reduction.
+// p, s, x, r are read and written once instead of twice, and the iteration has one launch less.
+__global__ __launch_bounds__(256) void k_cgcg_fused(int64_t n, const double* __restrict__ state_in, double* __restrict__ state_out,
+                                                    const double* __restrict__ red, int first,
+                                                    const double* __restrict__ w, const double* __restrict__ dinv,
+                                                    const double* __restrict__ own, double* __restrict__ z,
+                                                    double* __restrict__ p, double* __restrict__ s, double* __restrict__ x,
+                                                    double* __restrict__ r, double* __restrict__ gamma_part,
+                                                    double* __restrict__ rr_part) {
+  __shared__ double sh[4];
+  const double gamma_new = red[0], delta = red[1];
+  double alpha, beta;
+  if (first) {
+    beta = 0.0;
+    alpha = gamma_new / delta;
+  } else {
+    beta = gamma_new / state_in[2];
+    alpha = gamma_new / (delta - beta * gamma_new / state_in[0]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state_out[0] = alpha;
+    state_out[1] = beta;
+    state_out[2] = gamma_new;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  const int64_t n2 = n >> 1;
+  PF_VEC_LOOP(i, n2) {
+    const double2 zv = ld2(z, i), wv = ld2(w, i);
+    double2 pv = ld2(p, i), sv = ld2(s, i), xv = ld2(x, i), rv = ld2(r, i), zn;
+    pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
+    sv.x = wv.x + beta * sv.x; sv.y = wv.y + beta * sv.y;
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+    if (dinv) { const double2 dv = ld2(dinv, i); zn.x = dv.x * rv.x; zn.y = dv.y * rv.y; } else zn = rv;
+    st2(p, i, pv); st2(s, i, sv); st2(x, i, xv); st2(r, i, rv); st2(z, i, zn);
+    double2 ov = make_double2(1.0, 1.0);
+    if (own) ov = ld2(own, i);
+    s1 += ov.x * rv.x * zn.x + ov.y * rv.y * zn.y;
+    s2 += ov.x * rv.x * rv.x + ov.y * rv.y * rv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double pi = z[i] + beta * p[i], si = w[i] + beta * s[i];
+    p[i] = pi;
+    s[i] = si;
+    x[i] += alpha * pi;
+    const double ri = r[i] - alpha * si;
+    r[i] = ri;
+    const double zi = dinv ? dinv[i] * ri : ri;
+    z[i] = zi;
+    const double oi = own ? own[i] : 1.0;
+    s1 += oi * ri * zi;
+    s2 += oi * ri * ri;
+  }
+  block_store_partial(s1, gamma_part, sh);
+  block_store_partial(s2, rr_part, sh);
+}
+
 // ------------------------------------------------------------------------------------------
 static inline unsigned vec_grid(int64_t n) {
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 512), VEC_BLOCKS));
@@ -878,9 +938,10 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
 
 // ------------------------------------------------------------------------------------------
 // Distributed single-reduction PCG, the whole loop in C (dist.py dist_cg is the same algorithm driven from Python over
-// torch.distributed, kept for the gloo CPU tests and as the fallback transport).  Per iteration: k_cgcg_update_xrz,
-// k_spmv (+ partials of z.Kz), k_finalize, one pf_halo exchange (2 launches: interface sums of w = K z and the three
-// scalars), k_cgcg_update_ps.  Nothing touches the host except the residual read-back every check_every iterations.
+// torch.distributed, kept for the gloo CPU tests and as the fallback transport).  Per iteration: k_spmv (+ partials of
+// z.Kz), k_finalize, one pf_halo exchange (2 launches: interface sums of w = K z and the three scalars), k_cgcg_fused
+// (all vector updates of the iteration in one pass): five launches.  Nothing touches the host except the residual
+// read-back every check_every iterations.
 // ------------------------------------------------------------------------------------------
 extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
                           const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
@@ -923,8 +984,9 @@ extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* va
   double rnorm = INFINITY;
   int it = 0;
   double *state = stA, *state_next = stB;
+  // z = dinv r and the partials of r.z, r.r for the first reduction (alpha = 0 in the zeroed state: x, r unchanged)
+  k_cgcg_update_xrz<<<vg, 256, 0, st>>>(n, state, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
   while (it < maxiter) {
-    k_cgcg_update_xrz<<<vg, 256, 0, st>>>(n, state, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
     rc = pf_launch_spmv(ctx, vals, z, w, part(ctx, PA_DELTA));
     if (rc) return rc;
     k_finalize<<<1, 256, 0, st>>>(3, part(ctx, PA_GAMMA), (int)vg, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), (int)vg, red,
@@ -940,7 +1002,9 @@ extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* va
       rnorm = sqrt(h[2]);
       if (!(rnorm == rnorm) || rnorm <= tol) break;
     }
-    k_cgcg_update_ps<<<vg, 256, 0, st>>>(n, state, state_next, redg, it == 0, z, w, p, s);
+    // update_ps of this iteration and update_xrz of the next in one pass over the vectors
+    k_cgcg_fused<<<vg, 256, 0, st>>>(n, state, state_next, redg, it == 0, w, dinv, own_w, z, p, s, x, r, part(ctx, PA_GAMMA),
+                                     part(ctx, PA_RR2));
     std::swap(state, state_next);
     ++it;
   }
