@@ -128,7 +128,9 @@ def _worker(rank, world, port, etype, transport):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("etype,world,transport", [("quad", 2, "peer"), ("tri", 2, "p2p"), ("tri", 3, "peer")])
+@pytest.mark.parametrize("etype,world,transport", [("quad", 2, "peer"), ("tri", 2, "p2p"), ("tri", 3, "peer"),
+                                                   ("quad", 4, "peer")])  # 4 ranks: strips, then 2 x 2 Morton blocks
+                                                                          # whose centre node all four share
 def test_partitioned_ranks_sharing_one_gpu(etype, world, transport):
     """peer: kernels store into the other ranks' windows (HIP IPC); p2p: torch.distributed send/recv (gloo here)."""
     import torch.multiprocessing as mp
