@@ -577,7 +577,8 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     // copied out by one wave; neighbouring segments are written by different CUs, and a cache line shared by
     // two of them reaches HBM as two partial writes (tools/micro/wbench.hip: 4.0-4.4 TB/s instead of 5.5).
     // So a tile may stop up to 3 nodes early when that puts its end on a better-aligned block boundary
-    // (128 bytes = 128/(8 d d) blocks); interior rows then stay aligned until the next irregular row.
+    // (128 bytes = 128/(8 d d) blocks) without emptying more than a tenth of the wave's lanes; interior rows of
+    // quad meshes then stay aligned until the next irregular row.
     // Greedy and sequential, hence on the host: two int32 arrays down, 16 bytes per tile + 1 byte per node up.
     std::vector<int32_t> hp(nn + 1), hv(nn + 1);
     PF_HIP(hipMemcpyAsync(hp.data(), ctx->nptr, sizeof(int32_t) * (nn + 1), hipMemcpyDeviceToHost, ctx->stream));
@@ -595,8 +596,13 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
       while (emax > n0 + 1 && hv[emax] - hv[n0] > 64) --emax;  // at most 64 incident pairs per tile
       int64_t e = emax;
       if (emax < nn && !fixed) {
+        // stop early for alignment only while the wave stays >= 90 % as full as it could be: on valence-6 triangles
+        // the aligned choice (8 nodes, 48 of 64 lanes) measured 11 % SLOWER than 10 nodes ending mid-line (r02,
+        // tools/tri_tile_fixed.py); on quads the full tile is the aligned one anyway
+        const int32_t full = hv[emax] - hv[n0];
         int best = -1;
         for (int64_t c = emax; c > n0 && c > emax - 4; --c) {
+          if (10 * (hv[c] - hv[n0]) < 9 * full) break;
           const int score = std::min(hp[c] ? __builtin_ctz((unsigned)hp[c]) : 31, lgA);
           if (score > best) { best = score; e = c; }
         }

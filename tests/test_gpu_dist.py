@@ -220,3 +220,49 @@ def test_distributed_topology_loop_follows_the_single_gpu_one(tmp_path):
     hist = np.array([h[:2] for h in mod.main(["--nx", "96", "--ny", "48", "--iters", "5", "--r0", "0.04"])])
     assert np.abs(dist_hist[:, 0] / hist[:, 0] - 1).max() < 1e-6
     assert hist[-1, 0] < 0.8 * hist[0, 0]
+
+
+def _worker_c5(rank, world, port):
+    """One topology-optimisation solve at configuration 5's size over two ranks against the single-context model."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyfem_gpu_testflight_amd import pyfem
+        from pyfem_gpu_testflight_amd.dist import PartitionedElasticity
+
+        c = pyfem.ProblemCreator(2049, 1025)
+        conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+        q = pyfem.QuadratureBilinear2D()
+        b = pyfem.BasisBilinear2D(q)
+        xn = (X - X.min(axis=0)) / (X.max(axis=0) - X.min(axis=0))
+        rho = np.clip(0.5 + 0.6 * np.sin(11 * xn[:, 0]) * np.cos(7 * xn[:, 1]), 1e-3, 1.0)
+        pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=5.0)
+        assert pm.iface.transport == "peer"
+        c_dist, u_l = pm.compliance(rho)  # AMG-PCG, replicated hierarchy, distributed finest level
+        it_dist = pm.last_iters
+        u = pm.gather_global(u_l).cpu().numpy()
+        g = pm.gather_nodal(pm.compliance_grad(rho, u_l)).cpu().numpy()
+        if rank == 0:  # the single-context path on the same GPU
+            model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=5.0)
+            c_one, u_one = model.compliance(rho)
+            assert abs(c_dist / c_one - 1) < 1e-8, (c_dist, c_one)
+            assert np.abs(u - u_one).max() < 1e-8 * np.abs(u_one).max()
+            assert it_dist <= 1.3 * model.last_iters + 1, (it_dist, model.last_iters)
+            g_one = model.compliance_grad(rho, u_one)
+            assert np.abs(g - g_one).max() < 1e-7 * np.abs(g_one).max()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configuration5_solve_two_ranks_against_one():
+    """BASELINE configuration 5 (2048 x 1024, nodal density, RAMP p = 5) at FULL size: compliance, u, the compliance
+    gradient and the AMG-PCG iteration count of the two-rank path against the single-context one."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_c5, args=(2, _free_port()), nprocs=2, join=True)
