@@ -92,6 +92,15 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 //   VT = float reads an fp32 copy of the values (arithmetic stays fp64): the smoother sweeps of the AMG cycle, whose
 //   operator only has to be a fixed symmetric one.
 // ------------------------------------------------------------------------------------------
+// The value stream is read once per product while x is gathered again and again: for scalar matrices (d = 1) loading
+// the values NON-TEMPORALLY leaves the cache to x -- 0.0968 -> 0.0822 ms on the Helmholtz 2048^2 matrix (r02 A/B,
+// tools/spmv_ab.py); for 2x2 blocks the same change costs 11 % (0.261 -> 0.291 ms), so they keep plain loads.
+template <bool NT, typename T>
+__device__ __forceinline__ T spmv_ld(const T* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+#define PF_SPMV_LD(p) spmv_ld<D == 1>(p)
 template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
         if constexpr (D == 1) {
           double kv[U], xv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) kv[u] = (double)vals[g[u]];
+          for (int u = 0; u < U; ++u) kv[u] = (double)PF_SPMV_LD(vals + g[u]);
 #pragma unroll
           for (int u = 0; u < U; ++u) xv[u] = x[m[u]];
 #pragma unroll
@@ -148,8 +157,9 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if constexpr (sizeof(VT) == 8) {
-              k0[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u]);
-              k1[u] = *reinterpret_cast<const double2*>(vals + 4 * (int64_t)g[u] + 2);
+              const VT* vp = vals + 4 * (int64_t)g[u];
+              k0[u] = make_double2(PF_SPMV_LD(vp), PF_SPMV_LD(vp + 1));
+              k1[u] = make_double2(PF_SPMV_LD(vp + 2), PF_SPMV_LD(vp + 3));
             } else {  // fp32 copy of the operator (the AMG cycle's smoother): one 16-byte load per block
               const float4 f = *reinterpret_cast<const float4*>(vals + 4 * (int64_t)g[u]);
               k0[u] = make_double2((double)f.x, (double)f.y);
