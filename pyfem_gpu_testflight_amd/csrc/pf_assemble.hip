@@ -616,23 +616,42 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
       }
     }
   } else {
-    const pf_rsrc r0 = make_rsrc(out0 ? out0 + Tcur.base : nullptr, out0 ? (uint32_t)nblk * 8u : 0u);
-    const pf_rsrc r1 = make_rsrc((V == 2 && out1) ? out1 + Tcur.base : nullptr, (V == 2 && out1) ? (uint32_t)nblk * 8u : 0u);
-    const double* a0 = img + lane;
+    // scalar matrices: 16 bytes (two consecutive entries) per lane and store, like the 2x2 path -- 1 KiB per wave store
+    // instead of 512 B.  The resource of the wide stores ends at the last EVEN entry, so a piece that would straddle the
+    // segment's end starts exactly at that end and is dropped whole; the odd last entry goes out in one 8-byte store.
+    const uint32_t even_bytes = (uint32_t)(nblk & ~1) * 8u, all_bytes = (uint32_t)nblk * 8u;
+    const pf_rsrc r0 = make_rsrc(out0 ? out0 + Tcur.base : nullptr, out0 ? even_bytes : 0u);
+    const pf_rsrc r1 = make_rsrc((V == 2 && out1) ? out1 + Tcur.base : nullptr, (V == 2 && out1) ? even_bytes : 0u);
+    const pf_rsrc t0 = make_rsrc(out0 ? out0 + Tcur.base : nullptr, out0 ? all_bytes : 0u);
+    const pf_rsrc t1 = make_rsrc((V == 2 && out1) ? out1 + Tcur.base : nullptr, (V == 2 && out1) ? all_bytes : 0u);
+    const double* a0 = img + 2 * lane;
     if constexpr (NOUT > 0) {
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[64 * u]), r0, lane * 8 + 512 * u, 0, 0);
-        if constexpr (V == 2)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[plane + 64 * u]), r1, lane * 8 + 512 * u, 0, 0);
+        const pf_f64x2 v0 = {a0[128 * u], a0[128 * u + 1]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, 0);
+        if constexpr (V == 2) {
+          const pf_f64x2 v1 = {a0[plane + 128 * u], a0[plane + 128 * u + 1]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, 0);
+        }
       }
     } else {
-      for (int u = 0; 64 * u < nblk; ++u) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[64 * u]), r0, lane * 8 + 512 * u, 0, 0);
-        if constexpr (V == 2)
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, a0[plane + 64 * u]), r1, lane * 8 + 512 * u, 0, 0);
+      for (int u = 0; 128 * u < nblk; ++u) {
+        const pf_f64x2 v0 = {a0[128 * u], a0[128 * u + 1]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, 0);
+        if constexpr (V == 2) {
+          const pf_f64x2 v1 = {a0[plane + 128 * u], a0[plane + 128 * u + 1]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, 0);
+        }
       }
     }
+    // the odd tail (lane 0 only: every other lane's offset lies past the resource; an even segment has no tail and
+    // lane 0's offset nblk * 8 is past it too)
+    const uint32_t toff = (nblk & 1) ? (uint32_t)(nblk - 1) * 8u + (uint32_t)lane * 0x100000u : all_bytes;
+    const int32_t ti = (nblk & 1) ? nblk - 1 : 0;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[ti]), t0, (int)toff, 0, 0);
+    if constexpr (V == 2)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[plane + ti]), t1, (int)toff, 0, 0);
   }
 }
 
@@ -935,7 +954,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   // stores per lane of the copy-out: from the largest tile the greedy pass actually made (tiles stop at 64 incident
   // pairs, so on triangles they hold 10 of the npt = 16 nodes the valence rule allows: 3 stores, not 5)
   const int64_t tile_blocks = ctx->max_tile_blocks > 0 ? ctx->max_tile_blocks : (int64_t)ctx->npt * ctx->max_row_blocks;
-  const int per_lane = (int)cdiv(tile_blocks * (Phys::V == 4 ? 2 : 1), 64);
+  const int per_lane = Phys::V == 4 ? (int)cdiv(tile_blocks * 2, 64) : (int)cdiv(tile_blocks, 128);  // 16-byte pieces
   // compact records whenever the symbolic phase built them (quads: r02 A/B on 4M elements -- triangles ran 2.5 % slower
   // with them, the quad Helmholtz kernel 2.6 % faster, quad elasticity the same with 8 % less traffic)
   const bool r8 = ctx->vis_rec8 != nullptr;
@@ -947,7 +966,9 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   else nout = per_lane;
   // image + the run-over of the copy-out's LDS reads (pieces past the segment end are read and then dropped)
   const size_t plane = (size_t)ctx->npt * ctx->max_row_blocks + 1;
-  const size_t lds4 = (((plane * Phys::V + 127) & ~(size_t)127) + (size_t)64 * nout + 2) * 8;
+  // (2x2 blocks: piece u of a lane reads 32 u doubles past its base; scalar matrices: 128 u.  Keep it tight: with 2.5 KB
+  // more than needed the quad elasticity kernel dropped from 16 to 15 resident waves per CU and ran 25 % slower, r02.)
+  const size_t lds4 = (((plane * Phys::V + 127) & ~(size_t)127) + (size_t)(Phys::V == 4 ? 32 : 128) * nout + 2) * 8;
   if (lds4 > 160 * 1024)
     return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: node rows too long for the LDS image of a tile");
   if (lds4 > 48 * 1024)

@@ -155,3 +155,57 @@ def test_centroid_order_shortens_interfaces_of_shuffled_meshes():
     conn2, X2 = orc.structured_mesh(33, 33, "quad")
     assert ElementBlockPartition(conn2, X2.shape[0], 4, 1, 2, elem_perm=centroid_element_order(X2, conn2)).n_iface_dofs \
         <= 3 * ElementBlockPartition(conn2, X2.shape[0], 4, 1, 2).n_iface_dofs
+
+
+@pytest.mark.parametrize("kind,world,d", [("tri_shuffled", 3, 2), ("quad_morton", 4, 2), ("quad_strips", 5, 1)])
+def test_exchange_tables_line_up_without_a_handshake(kind, world, d):
+    """The neighbour-exchange tables of all ranks, built independently from the partition alone, must describe the same
+    messages from both ends: simulate every rank's pack -> the receiver's ordered sum in one process and compare with
+    the global sum.  Covers nodes shared by 3 and 4 ranks (scattered triangle blocks, the centre of 2 x 2 Morton
+    blocks) and the rank-ascending summation order that keeps interface copies bitwise identical."""
+    from oracle import pyfem_oracle as orc
+    from pyfem_gpu_testflight_amd.dist import ElementBlockPartition, centroid_element_order
+
+    rng = np.random.RandomState(11)
+    if kind == "tri_shuffled":
+        conn, X = orc.structured_mesh(13, 11, "tri")
+        conn = conn[rng.permutation(conn.shape[0])]
+        perm = None
+    else:
+        conn, X = orc.structured_mesh(18, 18, "quad")
+        perm = centroid_element_order(X, conn) if kind == "quad_morton" else None
+    parts = [ElementBlockPartition(conn, X.shape[0], world, r, d, elem_perm=perm) for r in range(world)]
+    tabs = [p.exchange_tables() for p in parts]
+    assert max(np.diff(t["src_ptr"]).max() for t in tabs) >= (2 if kind == "quad_strips" else 3)
+    glob = np.zeros((world, d * X.shape[0]))
+    loc = []
+    for r, p in enumerate(parts):
+        v = rng.rand(d * p.nnodes_local)
+        loc.append(v)
+        gd = (p.nodes[:, None] * d + np.arange(d)).ravel()
+        glob[r, gd] = v
+    results = []
+    for r, (p, t) in enumerate(zip(parts, tabs)):
+        msgs = {}
+        for i, s_ in enumerate(t["nbr_rank"]):
+            ts = tabs[s_]
+            k = list(ts["nbr_rank"]).index(r)  # r must be a neighbour of s_ as well
+            msgs[s_] = loc[s_][ts["send_idx"][ts["nbr_ptr"][k]:ts["nbr_ptr"][k + 1]]]
+            assert msgs[s_].size == t["nbr_ptr"][i + 1] - t["nbr_ptr"][i]  # symmetric message sizes
+        out = loc[r].copy()
+        for i, li in enumerate(t["if_idx"]):
+            ranks = t["src_rank"][t["src_ptr"][i]:t["src_ptr"][i + 1]]
+            assert np.all(np.diff(ranks) > 0) and r in ranks  # ascending, own rank included
+            acc = 0.0
+            for q in range(t["src_ptr"][i], t["src_ptr"][i + 1]):
+                sr = t["src_rank"][q]
+                acc += loc[r][li] if sr == r else msgs[sr][t["src_pos"][q]]
+            out[li] = acc
+        results.append(out)
+    # every rank's result equals the sum in ascending rank order -- bit for bit, on every sharer
+    expect = np.zeros(d * X.shape[0])
+    for r in range(world):
+        expect = expect + glob[r]  # adding exact zeros for non-sharers does not change the bits
+    for r, p in enumerate(parts):
+        gd = (p.nodes[:, None] * d + np.arange(d)).ravel()
+        assert np.array_equal(results[r], expect[gd]), r
