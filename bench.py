@@ -401,8 +401,9 @@ def main():
             ceil[name] = h.hbm_probe(mode, nb, reps=20)
             ceil[name + "_nt"] = h.hbm_probe(mode, nb, reps=20, nt=True)
         ceil["bytes_per_pass"] = nb
-        ceil["note"] = ("pf_hbm_probe: persistent waves, 16 B per lane; mix = 1/4 read + 3/4 written (the assembly's "
-                        "byte mix); GB/s")
+        ceil["note"] = ("pf_hbm_probe: every wave streams whole 64 KiB runs, 16 B per lane (the friendliest walk; the "
+                        "assembly writes 4.6 KB tile segments, which alone reach ~5.5 TB/s: tools/micro/fillpat.hip); "
+                        "mix = 1/4 read + 3/4 written (the assembly's byte mix); GB/s")
 
     # ---- assembly: W warm-up + exactly K timed steps ------------------------------------------
     K = model.compute_jacobian()

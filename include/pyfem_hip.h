@@ -329,8 +329,9 @@ int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const do
                    double* out0, double E, double nu, double p, double* ms_host);
 
 /* ---- HBM ceiling of THIS device in THIS process (bench.py: `frac_of_measured` next to the spec-sheet fraction).
- *      Streams `nbytes` of scratch (allocated and freed inside) `reps` times with persistent waves and 16-byte
- *      lane accesses; ms_host = average milliseconds per pass (HIP events).  No counterpart in the reference.
+ *      Streams `nbytes` of scratch (allocated and freed inside) `reps` times with persistent waves that each walk whole
+ *      64 KiB runs with 16-byte lane accesses (the friendliest walk: scattered 1 KiB pieces reach a third less);
+ *      ms_host = average milliseconds per pass (HIP events).  No counterpart in the reference.
  *      mode PF_HBM_FILL: write only;  PF_HBM_READ: read only;  PF_HBM_MIX: one quarter read, three quarters
  *      written (the byte mix of the quad assembly: K written once, records + coordinates read).
  *      nt != 0: non-temporal loads / stores. */

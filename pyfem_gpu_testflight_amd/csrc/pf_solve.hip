@@ -1172,33 +1172,42 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
 template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, const double2* __restrict__ b, int64_t n2,
                                                    double* __restrict__ sink) {
-  // four independent 16-byte accesses per lane and trip (what torch's fill / reduce kernels keep in flight too)
+  // Every WAVE streams whole 64 KiB chunks (dealt round-robin to the waves), 16 bytes per lane and access, four accesses
+  // in flight: the walk that gets the most out of the memory system (tools/micro/fillpat.hip, r02: a chip-wide store
+  // stream reaches 4.3 TB/s in 1 KiB pieces scattered by a grid-stride loop, 5.5 TB/s in the 4.6 KB pieces of the quad
+  // assembly's tile segments, 6.2 TB/s in 64 KiB runs per wave; hipMemset 6.5).
+  constexpr int64_t CH2 = 4096;  // double2 per chunk = 64 KiB
   constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   double s = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < n2; i0 += U * stride) {
-    double2 v[U];
+  for (int64_t c0 = wave * CH2; c0 < n2; c0 += nwaves * CH2) {
+    const int64_t c1 = min(n2, c0 + CH2);
+    for (int64_t i0 = c0 + lane; i0 < c1; i0 += 64 * U) {
+      double2 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = min(i0 + u * stride, n2 - 1);
-      if constexpr (MODE == PF_HBM_FILL) v[u] = make_double2((double)u, 1.0);
-      else if constexpr (NT) { v[u].x = __builtin_nontemporal_load(&b[i].x); v[u].y = __builtin_nontemporal_load(&b[i].y); }
-      else v[u] = b[i];
-    }
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = min(i0 + 64 * u, c1 - 1);
+        if constexpr (MODE == PF_HBM_FILL) v[u] = make_double2((double)u, 1.0);
+        else if constexpr (NT) { v[u].x = __builtin_nontemporal_load(&b[i].x); v[u].y = __builtin_nontemporal_load(&b[i].y); }
+        else v[u] = b[i];
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i = i0 + u * stride;
-      if (i >= n2) continue;
-      if constexpr (MODE == PF_HBM_READ) {
-        s += v[u].x + v[u].y;
-      } else {
-        constexpr int NW = MODE == PF_HBM_MIX ? 3 : 1;
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + 64 * u;
+        if (i >= c1) continue;
+        if constexpr (MODE == PF_HBM_READ) {
+          s += v[u].x + v[u].y;
+        } else {
+          constexpr int NW = MODE == PF_HBM_MIX ? 3 : 1;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) {
-          const double2 w = make_double2(v[u].x + k, v[u].y - k);
-          double2* dst = a + i + k * n2;
-          if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
-          else *dst = w;
+          for (int k = 0; k < NW; ++k) {
+            const double2 w = make_double2(v[u].x + k, v[u].y - k);
+            double2* dst = a + i + k * n2;
+            if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
+            else *dst = w;
+          }
         }
       }
     }
@@ -1221,7 +1230,7 @@ extern "C" int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int r
   hipEvent_t e0, e1;
   PF_HIP(hipEventCreate(&e0));
   PF_HIP(hipEventCreate(&e1));
-  const unsigned grid = 256 * 8;
+  const unsigned grid = 256 * 6;  // 24 waves per CU
   auto launch = [&]() {
 #define PF_PROBE(M_)                                                                                            \
     if (mode == M_) {                                                                                           \
