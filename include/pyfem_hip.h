@@ -304,6 +304,18 @@ int pf_amg_restrict0(pf_ctx* ctx, const double* res, double* b1);
 int pf_amg_coarse_solve(pf_ctx* ctx, const double* b1, double* x1);
 int pf_amg_prolong0(pf_ctx* ctx, const double* x1, double* c);
 int pf_vec_smooth(pf_ctx* ctx, int64_t n, const double* x, const double* d, const double* b, const double* w, double* out);
+/* The two transfers over the CALLER'S rows of P0 only, so that a rank does not stream the whole prolongator:
+ *   pf_amg_p0_pattern:     HOST out: entries np and coarse nodes nc of P0; DEVICE out (may be NULL): its row pattern
+ *                          pptr int32[nnodes+1], pidx int32[np] (coarse node ids, ascending per row)
+ *   pf_amg_prolong0_rows:  c_local[i] += P0[grow[i], :] x1 for the nl local nodes whose global ids are grow[i]
+ *   pf_amg_restrict0_rows: b1 = sum over the caller's OWNED rows of P0^T res_local, given the transpose pattern of
+ *                          those rows: ltptr int32[nc+1], ltnode (local node index, ascending per column), ltslot (the
+ *                          entry's index in P0's row-major storage) -- built by the caller from pf_amg_p0_pattern.
+ * 2-D problems (scalar or plane: the levels that store a smoothed prolongator).                                      */
+int pf_amg_p0_pattern(pf_ctx* ctx, int64_t* np_host, int64_t* nc_host, int32_t* pptr, int32_t* pidx);
+int pf_amg_prolong0_rows(pf_ctx* ctx, int64_t nl, const int32_t* grow, const double* x1, double* c_local);
+int pf_amg_restrict0_rows(pf_ctx* ctx, const int32_t* ltptr, const int32_t* ltnode, const int32_t* ltslot,
+                          const double* res_local, double* b1);
 
 #define PF_HALO_NSCAL 8
 #define PF_HALO_HANDLE_BYTES 64

@@ -81,6 +81,9 @@ SIGNATURES = {
     "pf_amg_restrict0": (C.c_int, [_vp, _vp, _vp]),
     "pf_amg_coarse_solve": (C.c_int, [_vp, _vp, _vp]),
     "pf_amg_prolong0": (C.c_int, [_vp, _vp, _vp]),
+    "pf_amg_p0_pattern": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
+    "pf_amg_prolong0_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "pf_amg_restrict0_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_vec_smooth": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pf_halo_create": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.POINTER(_vp)]),
     "pf_halo_handle": (C.c_int, [_vp, _vp]),

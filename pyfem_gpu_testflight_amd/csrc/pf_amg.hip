@@ -1802,6 +1802,101 @@ extern "C" int pf_amg_prolong0(pf_ctx* ctx, const double* x1, double* c) {
   return amg_prolong_level(ctx, ctx->amg, 0, x1, c);
 }
 
+// The same two transfers over the CALLER'S rows of P0 only (dist.py: a rank restricts and prolongs its own nodes
+// instead of streaming the whole prolongator):
+//   k_sa_prolong_rows:   x_local[i] += over * sum_J P[grow[i], J] e_J          (grow: global node of local node i)
+//   k_sa_restrict_rows:  bc[I] = sum over the entries e of column I that lie in rows the caller OWNS of
+//                        P[e]^T res_local[ltnode[e]]; (ltptr, ltnode, ltslot) is the transpose pattern of those rows,
+//                        ltslot the entry's index in pvals.  Columns without such entries get 0.  One thread per
+//                        coarse node, entries in ascending local node order: deterministic.
+template <int DR, int DC>
+__global__ void k_sa_prolong_rows(int64_t nl, const int32_t* __restrict__ grow, const int32_t* __restrict__ pptr,
+                                  const int32_t* __restrict__ pidx, const double* __restrict__ pvals,
+                                  const double* __restrict__ ec, double* __restrict__ x, double over) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nl) return;
+  const int64_t g = grow[i];
+  double s[DR];
+#pragma unroll
+  for (int r = 0; r < DR; ++r) s[r] = 0.0;
+  for (int32_t q = pptr[g]; q < pptr[g + 1]; ++q) {
+    const double* Pn = pvals + (int64_t)q * DR * DC;
+    const double* e = ec + DC * (int64_t)pidx[q];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+  }
+#pragma unroll
+  for (int r = 0; r < DR; ++r) x[DR * i + r] += over * s[r];
+}
+
+template <int DR, int DC>
+__global__ void k_sa_restrict_rows(int64_t nc, const int32_t* __restrict__ ltptr, const int32_t* __restrict__ ltnode,
+                                   const int32_t* __restrict__ ltslot, const double* __restrict__ pvals,
+                                   const double* __restrict__ res, double* __restrict__ bc) {
+  const int64_t I = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (I >= nc) return;
+  double acc[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) acc[c] = 0.0;
+  for (int32_t e = ltptr[I]; e < ltptr[I + 1]; ++e) {
+    const double* Pn = pvals + (int64_t)ltslot[e] * DR * DC;
+    const double* rv = res + DR * (int64_t)ltnode[e];
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) acc[c] += Pn[r * DC + c] * rv[r];
+  }
+#pragma unroll
+  for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
+}
+
+static int amg_level0_sa(pf_ctx* ctx, const char* who) {
+  PF_REQUIRE(ctx->amg && ctx->amg->numeric_ok && ctx->amg->nlevels >= 2, std::string(who) + ": call pf_amg_prepare first (and the hierarchy needs two levels)");
+  PF_REQUIRE(ctx->amg->L[0].sa && ctx->amg->dim == 2 && (ctx->amg->L[0].dr == 1 || ctx->amg->L[0].dr == 2),
+             std::string(who) + ": the finest level must carry a stored (smoothed) prolongator: 2-D scalar or plane problems");
+  return PF_OK;
+}
+
+extern "C" int pf_amg_p0_pattern(pf_ctx* ctx, int64_t* np_host, int64_t* nc_host, int32_t* pptr, int32_t* pidx) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (int rc = amg_level0_sa(ctx, "pf_amg_p0_pattern")) return rc;
+  AmgLevel& L0 = ctx->amg->L[0];
+  if (np_host) *np_host = L0.np;
+  if (nc_host) *nc_host = L0.nc;
+  if (pptr) PF_HIP(hipMemcpyAsync(pptr, L0.pptr, sizeof(int32_t) * (L0.n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+  if (pidx) PF_HIP(hipMemcpyAsync(pidx, L0.pidx, sizeof(int32_t) * L0.np, hipMemcpyDeviceToDevice, ctx->stream));
+  return PF_OK;
+}
+
+extern "C" int pf_amg_prolong0_rows(pf_ctx* ctx, int64_t nl, const int32_t* grow, const double* x1, double* c_local) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (int rc = amg_level0_sa(ctx, "pf_amg_prolong0_rows")) return rc;
+  PF_REQUIRE(nl >= 0 && grow && x1 && c_local, "pf_amg_prolong0_rows: NULL argument");
+  pf_amg* H = ctx->amg;
+  AmgLevel& L0 = H->L[0];
+  if (nl == 0) return PF_OK;
+  const unsigned g = (unsigned)cdiv(nl, 256);
+  if (L0.dr == 1) k_sa_prolong_rows<1, 1><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
+  else k_sa_prolong_rows<2, 3><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_amg_restrict0_rows(pf_ctx* ctx, const int32_t* ltptr, const int32_t* ltnode, const int32_t* ltslot,
+                                     const double* res_local, double* b1) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (int rc = amg_level0_sa(ctx, "pf_amg_restrict0_rows")) return rc;
+  PF_REQUIRE(ltptr && ltnode && ltslot && res_local && b1, "pf_amg_restrict0_rows: NULL argument");
+  AmgLevel& L0 = ctx->amg->L[0];
+  const unsigned g = (unsigned)cdiv(L0.nc, 256);
+  if (L0.dr == 1) k_sa_restrict_rows<1, 1><<<g, 256, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltslot, L0.pvals, res_local, b1);
+  else k_sa_restrict_rows<2, 3><<<g, 256, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltslot, L0.pvals, res_local, b1);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
 // out = x + d .* (b - w)   (x == NULL: out = d .* b; w == NULL: out = x + d .* b; d == NULL: unit factors)
 __global__ __launch_bounds__(256) void k_vec_smooth(int64_t n, const double* __restrict__ x, const double* __restrict__ d,
                                                     const double* __restrict__ b, const double* __restrict__ w,

@@ -633,22 +633,50 @@ class ReplicatedHierarchy:
         self.ops, self.part, self.g, self.group = ops, part, gctx, group
         d = part.d
         gd = (part.nodes[:, None] * d + np.arange(d)).ravel()
-        self.gdofs = ops.from_numpy(gd.astype(np.int32), torch.int32)
-        self.gdofs64 = self.gdofs.to(torch.int64)
-        self.res_g = ops.zeros(gctx.nrows)
-        self.cor_g = ops.zeros(gctx.nrows)
+        self.gdofs64 = ops.from_numpy(gd.astype(np.int64), torch.int64)
+        self.grow = ops.from_numpy(part.nodes.astype(np.int32), torch.int32)  # global node of every local node
         n = ops.n
         self.c, self.c2, self.w, self.t = ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
         self.d1 = self.d2 = self.b1 = self.x1 = None
+        self._lt = None  # transpose pattern of this rank's owned rows of P0 (graph only: built once)
 
     def _gcall(self, name, *a):
         g = self.g
         g._sync_stream()
         g._call(name, *a)
 
+    def _local_transpose(self):
+        """(ltptr, ltnode, ltslot) of the rows of P0 this rank OWNS: for every coarse node the entries of its column
+        that lie in owned local rows, ascending local node -- what pf_amg_restrict0_rows walks.  From the pattern of
+        the replicated hierarchy, once per mesh (host, numpy: a million entries for an eighth of the 4M-quad mesh)."""
+        torch = self.ops.torch
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        npn, ncn = self.ops._lib._i64(), self.ops._lib._i64()
+        self._gcall("pf_amg_p0_pattern", C.byref(npn), C.byref(ncn), None, None)
+        pptr_d = self.ops.zeros(self.g.nnodes + 1, torch.int32)
+        pidx_d = self.ops.zeros(max(npn.value, 1), torch.int32)
+        self._gcall("pf_amg_p0_pattern", None, None, p(pptr_d), p(pidx_d))
+        pptr, pidx = pptr_d.cpu().numpy().astype(np.int64), pidx_d.cpu().numpy()
+        nc = ncn.value
+        loc = np.flatnonzero(self.part.owned_mask_nodes)
+        rows = self.part.nodes[loc]
+        cnt = pptr[rows + 1] - pptr[rows]
+        start = np.repeat(pptr[rows], cnt)
+        slots = start + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+        cols = pidx[slots].astype(np.int64)
+        lnode = np.repeat(loc, cnt)
+        order = np.lexsort((lnode, cols))
+        ltptr = np.zeros(nc + 1, dtype=np.int64)
+        np.cumsum(np.bincount(cols, minlength=nc), out=ltptr[1:])
+        f = self.ops.from_numpy
+        self.nc = nc
+        self.coarse_nodes_touched = np.flatnonzero(np.diff(ltptr) > 0)  # the level-1 nodes this rank contributes to
+        self._lt = (f(ltptr.astype(np.int32), torch.int32), f(lnode[order].astype(np.int32), torch.int32),
+                    f(slots[order].astype(np.int32), torch.int32))
+        return self._lt
+
     def setup(self, Kg_vals, reuse=False):
         """Numeric setup from the assembled, BC-applied matrix of the WHOLE mesh (values on the global context)."""
-        torch = self.ops.torch
         p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
         self._gcall("pf_amg_prepare", p(Kg_vals), int(bool(reuse)))
         n1 = self.ops._lib._i64()
@@ -657,6 +685,8 @@ class ReplicatedHierarchy:
         self.d1, self.d2 = d1g[self.gdofs64].contiguous(), d2g[self.gdofs64].contiguous()
         if self.b1 is None or self.b1.numel() != n1.value:
             self.b1, self.x1 = self.ops.zeros(n1.value), self.ops.zeros(n1.value)
+        if self._lt is None:
+            self._local_transpose()
         return self
 
     def vcycle(self, K, r, z, iface, own_w):
@@ -664,28 +694,23 @@ class ReplicatedHierarchy:
         ops = self.ops
         p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
         c, c2, w, t = self.c, self.c2, self.w, self.t
-        n = ops.n
         ops.vec_smooth(None, self.d1, r, None, c)           # first sweep from a zero guess
         ops.spmv(K, c, w)
         iface.sum(w)
         ops.vec_smooth(c, self.d2, r, w, c2)                # second sweep (second Chebyshev factor)
         ops.spmv(K, c2, w)
         iface.sum(w)
-        ops.vec_smooth(None, own_w, r, w, t)                # owned part of the residual
-        ops.copy_indexed(n, None, self.gdofs, t, self.res_g)
-        self._gcall("pf_amg_restrict0", p(self.res_g), p(self.b1))
+        ops.vec_smooth(None, None, r, w, t)                 # residual; the restriction takes the rows this rank owns
+        self._gcall("pf_amg_restrict0_rows", p(self._lt[0]), p(self._lt[1]), p(self._lt[2]), p(t), p(self.b1))
         _all_reduce(self.b1, self.group)
         self._gcall("pf_amg_coarse_solve", p(self.b1), p(self.x1))
-        self.cor_g.zero_()
-        self._gcall("pf_amg_prolong0", p(self.x1), p(self.cor_g))
-        ops.copy_indexed(n, self.gdofs, None, self.cor_g, t)
-        ops.vec_smooth(c2, None, t, None, c)                # c = c2 + correction
-        ops.spmv(K, c, w)
-        iface.sum(w)
-        ops.vec_smooth(c, self.d2, r, w, c2)                # post-smoothing in reverse order: the cycle stays symmetric
+        self._gcall("pf_amg_prolong0_rows", ops._lib._i64(self.grow.numel()), p(self.grow), p(self.x1), p(c2))  # c2 += P x1
         ops.spmv(K, c2, w)
         iface.sum(w)
-        ops.vec_smooth(c2, self.d1, r, w, z)
+        ops.vec_smooth(c2, self.d2, r, w, c)                # post-smoothing in reverse order: the cycle stays symmetric
+        ops.spmv(K, c, w)
+        iface.sum(w)
+        ops.vec_smooth(c, self.d1, r, w, z)
         return z
 
 
