@@ -334,6 +334,36 @@ int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const d
                const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
                int32_t* iters_host, double* relres_host);
 
+/* ---- AMG-PCG over the partition, the whole loop in C (pf_dist.hip).  `local`: the rank's context (K, vectors, halo);
+ *      `global`: a context that holds the WHOLE mesh and the hierarchy pf_amg_prepare built for the assembled,
+ *      BC-applied matrix (replicated on every rank); both bound to one stream.  plan_dof: the halo plan of the dof
+ *      vectors (window `halo`); plan_coarse: a plan on a second window, `halo_coarse`, over the level-1 vector, in which
+ *      every rank sends the entries it contributes to to every other rank (dist.py builds both).  d1, d2: the finest level's Chebyshev-Jacobi factors on the rank's dofs
+ *      (pf_amg_level0, gathered); grow / ltptr / ltnode / ltslot: as for pf_amg_prolong0_rows / pf_amg_restrict0_rows;
+ *      n1: level-1 dofs.  work: 9 nrows_local + 2 n1 + 64 doubles of scratch.
+ *        pf_dist_vcycle:   z = M^-1 r (work: 4 nrows_local + 2 n1 doubles)
+ *        pf_dist_pcg_amg:  single-reduction PCG, x0 = 0, stop and errors as pf_dist_cg                                   */
+typedef struct {
+  pf_ctx* local;
+  pf_ctx* global;
+  pf_halo* halo;         /* window of the dof-vector exchange (plan_dof) */
+  pf_halo* halo_coarse;  /* window of the level-1 exchange (plan_coarse): its messages are ~10x larger */
+  int32_t plan_dof, plan_coarse;
+  const double* K;
+  const double* own_w;
+  const double* d1;
+  const double* d2;
+  int64_t nl;
+  const int32_t* grow;
+  const int32_t* ltptr;
+  const int32_t* ltnode;
+  const int32_t* ltslot;
+  int64_t n1;
+} pf_dist_amg;
+int pf_dist_vcycle(const pf_dist_amg* a, const double* r, double* z, double* work);
+int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x, double* work, double rtol, double atol,
+                    int maxiter, int check_every, int32_t* iters_host, double* relres_host);
+
 /* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
  *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */
 enum { PF_K_ASSEMBLE_ELASTICITY = 0, PF_K_SPMV = 1, PF_K_ASSEMBLE_HELMHOLTZ = 2 };

@@ -95,9 +95,20 @@ SIGNATURES = {
     "pf_halo_destroy": (C.c_int, [_vp]),
     "pf_dist_cg": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32),
                              C.POINTER(_f64)]),
+    "pf_dist_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pf_dist_pcg_amg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
     "pf_hbm_probe": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_f64)]),
 }
+
+
+
+class DistAmgArgs(C.Structure):
+    """pf_dist_amg of include/pyfem_hip.h."""
+    _fields_ = [("local", _vp), ("global_", _vp), ("halo", _vp), ("halo_coarse", _vp), ("plan_dof", _i32), ("plan_coarse", _i32),
+                ("K", _vp), ("own_w", _vp), ("d1", _vp), ("d2", _vp), ("nl", _i64), ("grow", _vp), ("ltptr", _vp),
+                ("ltnode", _vp), ("ltslot", _vp), ("n1", _i64)]
+
 
 _lib = None
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libpyfem_hip.so")
-SOURCES = ["pf_pattern.hip", "pf_assemble.hip", "pf_assemble3d.hip", "pf_tabular.hip", "pf_solve.hip", "pf_amg.hip", "pf_halo.hip"]
+SOURCES = ["pf_pattern.hip", "pf_assemble.hip", "pf_assemble3d.hip", "pf_tabular.hip", "pf_solve.hip", "pf_amg.hip", "pf_halo.hip", "pf_dist.hip"]
 LIB_EXP = os.path.join(PKG, "libpyfem_hip_exp.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]

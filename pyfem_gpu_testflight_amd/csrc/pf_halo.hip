@@ -30,6 +30,7 @@
 
 struct pf_halo_plan {
   int nnbr = 0;
+  int64_t max_msg = 0;           // largest message of the plan (doubles)
   int32_t* nbr = nullptr;        // (nnbr) neighbour ranks, ascending                        [device]
   int32_t* nbr_ptr = nullptr;    // (nnbr+1) offsets into send_idx                           [device]
   int32_t* send_idx = nullptr;   // local vector index of every packed value                 [device]
@@ -48,6 +49,7 @@ struct pf_halo {
   double** peer_win = nullptr;   // (world) device array of mapped window base pointers (own entry = win)
   std::vector<void*> mapped;     // host copies for hipIpcCloseMemHandle
   int32_t* err = nullptr;        // device flag: 1 after a wait timed out (every later wait gives up at once)
+  uint32_t* done = nullptr;      // (world) workgroups that finished a peer's message in the current send
   uint64_t seq = 0;
   long long timeout_ticks = 200000000LL;  // 2 s of the 100 MHz wall clock
   pf_halo_plan plans[PF_HALO_MAXPLANS];
@@ -58,17 +60,22 @@ __host__ __device__ static inline size_t halo_flag_doubles(int world) { return (
 __host__ __device__ static inline size_t halo_scal_off(int world) { return halo_flag_doubles(world); }
 __host__ __device__ static inline size_t halo_recv_off(int world) { return halo_scal_off(world) + (size_t)2 * world * PF_HALO_NSCAL; }
 
-// one workgroup per peer: scalars to every peer, the packed interface values to the neighbours of the plan
+// NB workgroups per peer (NB = gridDim.y): scalars to every peer, the packed values to the neighbours of the plan; the
+// workgroup that finishes a peer's message last raises that peer's flag (counted in done[peer], which it resets)
 __global__ __launch_bounds__(256) void k_halo_send(int world, int rank, int64_t cap, double* const* __restrict__ peer_win,
                                                    int nnbr, const int32_t* __restrict__ nbr,
                                                    const int32_t* __restrict__ nbr_ptr,
                                                    const int32_t* __restrict__ send_idx, const double* __restrict__ v,
-                                                   const double* __restrict__ scal_in, int ns, uint64_t seq) {
+                                                   const double* __restrict__ scal_in, int ns, uint64_t seq,
+                                                   uint32_t* __restrict__ done) {
   const int peer = blockIdx.x;  // including this rank: its own scalars go through its own window too
+  const int part = blockIdx.y, nparts = gridDim.y;
   double* w = peer_win[peer];
   const int par = (int)(seq & 1);
-  double* scal = w + halo_scal_off(world) + ((size_t)par * world + rank) * PF_HALO_NSCAL;
-  if ((int)threadIdx.x < ns) scal[threadIdx.x] = scal_in[threadIdx.x];
+  if (part == 0) {
+    double* scal = w + halo_scal_off(world) + ((size_t)par * world + rank) * PF_HALO_NSCAL;
+    if ((int)threadIdx.x < ns) scal[threadIdx.x] = scal_in[threadIdx.x];
+  }
   if (peer != rank && nnbr > 0) {
     // is this peer a neighbour of the plan?  (nbr is short: linear scan by every thread, same result)
     int k = -1;
@@ -76,13 +83,23 @@ __global__ __launch_bounds__(256) void k_halo_send(int world, int rank, int64_t 
     if (k >= 0) {
       double* dst = w + halo_recv_off(world) + ((size_t)par * world + rank) * cap;
       const int32_t b = nbr_ptr[k], e = nbr_ptr[k + 1];
-      for (int32_t i = b + (int32_t)threadIdx.x; i < e; i += (int32_t)blockDim.x) dst[i - b] = v[send_idx[i]];
+      for (int32_t i = b + part * (int32_t)blockDim.x + (int32_t)threadIdx.x; i < e; i += nparts * (int32_t)blockDim.x)
+        dst[i - b] = v[send_idx[i]];
     }
   }
   __threadfence_system();
   __syncthreads();
-  if (threadIdx.x == 0)
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(w) + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (nparts > 1) {
+      const uint32_t prev = atomicAdd(&done[peer], 1u);
+      last = prev + 1 == (uint32_t)nparts;
+      if (last) done[peer] = 0;  // nobody else touches it before the next exchange (stream order)
+      __threadfence_system();
+    }
+    if (last)
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(w) + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // every workgroup waits for ALL ranks' messages of this exchange, then sums its share of the interface entries;
@@ -154,6 +171,8 @@ extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doub
   PF_HIP(hipMemcpy(h->peer_win, pw.data(), sizeof(double*) * world, hipMemcpyHostToDevice));
   PF_HIP(hipMalloc((void**)&h->err, sizeof(int32_t)));
   PF_HIP(hipMemset(h->err, 0, sizeof(int32_t)));
+  PF_HIP(hipMalloc((void**)&h->done, sizeof(uint32_t) * world));
+  PF_HIP(hipMemset(h->done, 0, sizeof(uint32_t) * world));
   *out = h;
   return PF_OK;
 }
@@ -216,6 +235,8 @@ extern "C" int pf_halo_plan_create(pf_halo* h, int nnbr, const int32_t* nbr_rank
   pf_halo_plan& P = h->plans[h->nplans];
   P.nnbr = nnbr;
   P.n_if = n_if;
+  P.max_msg = 0;
+  for (int k = 0; k < nnbr; ++k) P.max_msg = std::max<int64_t>(P.max_msg, nbr_ptr[k + 1] - nbr_ptr[k]);
   int rc;
   if ((rc = halo_upload(ctx, nbr_rank, nnbr, P.nbr))) return rc;
   if ((rc = halo_upload(ctx, nbr_ptr, nnbr ? nnbr + 1 : 0, P.nbr_ptr))) return rc;
@@ -237,9 +258,12 @@ int pf_halo_exchange_impl(pf_halo* h, int plan, double* v, const double* scal_in
   static const pf_halo_plan none;
   const pf_halo_plan& P = plan >= 0 ? h->plans[plan] : none;
   const uint64_t seq = ++h->seq;
-  k_halo_send<<<h->world, 256, 0, ctx->stream>>>(h->world, h->rank, h->cap, h->peer_win, P.nnbr, P.nbr, P.nbr_ptr, P.send_idx,
-                                                 v, scal_in, ns, seq);
-  const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.n_if, 256), 64));
+  // interface rows of a strip (4 K doubles) go through one workgroup per peer; the level-1 right-hand side of the AMG
+  // cycle (~100 K doubles per peer) through up to 16
+  const unsigned nparts = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.max_msg, 8192), 16));
+  k_halo_send<<<dim3(h->world, nparts), 256, 0, ctx->stream>>>(h->world, h->rank, h->cap, h->peer_win, P.nnbr, P.nbr, P.nbr_ptr,
+                                                               P.send_idx, v, scal_in, ns, seq, h->done);
+  const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.n_if, 256), 256));
   k_halo_recv<<<g, 256, 0, ctx->stream>>>(h->world, h->rank, h->cap, h->win, P.n_if, P.if_idx, P.src_ptr, P.src_off, v,
                                           scal_out, ns, seq, h->err, h->timeout_ticks);
   PF_LAUNCH_CHECK();
@@ -282,6 +306,7 @@ extern "C" int pf_halo_destroy(pf_halo* h) {
   }
   pf_free(h->peer_win);
   pf_free(h->err);
+  pf_free(h->done);
   if (h->win) (void)hipFree(h->win);
   delete h;
   return PF_OK;

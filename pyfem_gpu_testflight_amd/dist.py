@@ -675,6 +675,75 @@ class ReplicatedHierarchy:
                     f(slots[order].astype(np.int32), torch.int32))
         return self._lt
 
+    def coarse_exchange(self, iface):
+        """The level-1 sum over ranks through peer-store windows (a second PeerHalo: its messages are the ~n1/world
+        level-1 entries a rank contributes to, sent to EVERY other rank, since levels >= 1 are replicated).  Returns
+        (halo, plan) or None when the dof exchange does not run on the peer transport."""
+        if getattr(self, "_coarse", None) is not None:
+            return self._coarse
+        if iface.transport != "peer":
+            return None
+        import torch.distributed as dist
+
+        world, rank = self.part.world, self.part.rank
+        dc = self.b1.numel() // self.nc
+        mine = self.coarse_nodes_touched.astype(np.int64)
+        if world > 1:
+            lists = [None] * world
+            dist.all_gather_object(lists, mine, group=self.group)
+        else:
+            lists = [mine]
+        cap = max(len(x) for x in lists) * dc
+        halo = PeerHalo.try_create(self.ops, self.part, self.group, cap=cap)
+        if halo is None:
+            self._coarse = None
+            return None
+        k = np.arange(dc)
+        others = [r for r in range(world) if r != rank]
+        msg = (mine[:, None] * dc + k).ravel()
+        nbr_ptr = np.arange(len(others) + 1, dtype=np.int64) * msg.size
+        send_idx = np.tile(msg, len(others))
+        nodes_all = np.concatenate(lists)
+        ranks_all = np.concatenate([np.full(len(x), r, dtype=np.int64) for r, x in enumerate(lists)])
+        pos_all = np.concatenate([np.arange(len(x), dtype=np.int64) for x in lists])
+        order = np.lexsort((ranks_all, nodes_all))
+        nodes_s, ranks_s, pos_s = nodes_all[order], ranks_all[order], pos_all[order]
+        unodes, first, cnt = np.unique(nodes_s, return_index=True, return_counts=True)
+        # entries: dof (node, kk) for every touched node; sources: the node's ranks ascending, position pos * dc + kk
+        if_idx = (unodes[:, None] * dc + k).ravel()
+        src_ptr = np.zeros(if_idx.size + 1, dtype=np.int64)
+        src_ptr[1:] = np.cumsum(np.repeat(cnt, dc))
+        src_rank = np.empty(int(src_ptr[-1]), dtype=np.int64)
+        src_pos = np.empty(int(src_ptr[-1]), dtype=np.int64)
+        within = np.arange(nodes_s.size) - np.repeat(first, cnt)
+        node_of = np.repeat(np.arange(unodes.size), cnt)
+        for kk in range(dc):
+            dst = src_ptr[node_of * dc + kk] + within
+            src_rank[dst] = ranks_s
+            src_pos[dst] = pos_s * dc + kk
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        plan = halo.add_plan({"nbr_rank": i32(others), "nbr_ptr": i32(nbr_ptr), "send_idx": i32(send_idx), "if_idx": i32(if_idx),
+                              "src_ptr": i32(src_ptr), "src_rank": i32(src_rank), "src_pos": i32(src_pos)})
+        self._coarse = (halo, plan)
+        return self._coarse
+
+    def native_args(self, K, iface, own_w):
+        """pf_dist_amg for pf_dist_pcg_amg / pf_dist_vcycle, or None if the exchanges cannot run on peer windows."""
+        ce = self.coarse_exchange(iface)
+        if ce is None:
+            return None
+        ops = self.ops
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        a = ops._lib.DistAmgArgs()
+        a.local, a.global_ = ops.h._ctx, self.g._ctx
+        a.halo, a.halo_coarse = iface.halo._h, ce[0]._h
+        a.plan_dof, a.plan_coarse = int(iface.plan), int(ce[1])
+        a.K, a.own_w, a.d1, a.d2 = p(K), p(own_w), p(self.d1), p(self.d2)
+        a.nl, a.grow = int(self.grow.numel()), p(self.grow)
+        a.ltptr, a.ltnode, a.ltslot = p(self._lt[0]), p(self._lt[1]), p(self._lt[2])
+        a.n1 = int(self.b1.numel())
+        return a
+
     def setup(self, Kg_vals, reuse=False):
         """Numeric setup from the assembled, BC-applied matrix of the WHOLE mesh (values on the global context)."""
         p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
@@ -714,14 +783,27 @@ class ReplicatedHierarchy:
         return z
 
 
-def dist_pcg_amg(ops, K, b, own_w, iface, hier, rtol=1e-8, atol=0.0, maxiter=None, check_every=1):
+def dist_pcg_amg(ops, K, b, own_w, iface, hier, rtol=1e-8, atol=0.0, maxiter=None, check_every=1, native=None):
     """Single-reduction PCG over ranks preconditioned with the replicated hierarchy's V-cycle (hier.setup was called for
     the matrix K belongs to).  Per iteration: the V-cycle (four products with interface sums, one all-reduce of the
     level-1 right-hand side) and one exchange carrying the interface sums of w = K z with gamma = r.z, delta = z.w and
-    r.r.  Same stopping rule and errors as dist_cg.  Returns (x_local, iters, relres)."""
+    r.r.  Same stopping rule and errors as dist_cg.  Returns (x_local, iters, relres).
+    With the peer transport the whole loop runs in C (pf_dist_pcg_amg), the level-1 sum included (a second window);
+    native=False forces this Python loop (tests compare the two)."""
     n = ops.n
     if hasattr(ops, "begin"):
         ops.begin()
+    args = hier.native_args(K, iface, own_w) if (native is not False and hasattr(hier, "native_args")) else None
+    if args is not None:  # the whole loop in C, both exchanges through peer windows
+        hier.g._sync_stream()
+        x = ops.zeros(n)
+        work = ops.zeros(9 * n + 2 * args.n1 + 64)
+        iters, relres = ops._lib._i32(), ops._lib._f64()
+        rc = ops.lib.pf_dist_pcg_amg(C.byref(args), C.c_void_p(b.data_ptr()), C.c_void_p(x.data_ptr()),
+                                     C.c_void_p(work.data_ptr()), float(rtol), float(atol), int(maxiter or 0),
+                                     int(check_every or 1), C.byref(iters), C.byref(relres))
+        ops._lib.check(ops.h._ctx, rc, "pf_dist_pcg_amg")
+        return x, iters.value, relres.value
     x, r, z, w, p, s, zt = ops.zeros(n), b.clone(), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n), ops.zeros(n)
     state, state_next = ops.zeros(3), ops.zeros(3)
     red, g = ops.zeros(3), ops.zeros(1)

@@ -117,6 +117,17 @@ def _worker(rank, world, port, etype, transport):
         assert err < 1e-8, err
         assert pm.last_iters <= 1.3 * it_single + 1, (pm.last_iters, it_single)
         assert pm.last_iters * 3 < it_jacobi
+        if transport == "peer":  # that was pf_dist_pcg_amg (all in C); the Python-driven loop must agree with it
+            from pyfem_gpu_testflight_amd.dist import dist_pcg_amg
+
+            K = pm.compute_jacobian(rho)
+            rhs = pm.ops.from_numpy(pm.model.compute_rhs(), torch.float64)
+            K, bb = pm.apply_dirichlet_bcs(K, rhs)
+            hier = pm._hierarchy_for(rho)
+            assert hier.native_args(K.vals, pm.iface, pm.own_w) is not None
+            xp, itp, _ = dist_pcg_amg(pm.ops, K.vals, bb, pm.own_w, pm.iface, hier, rtol=1e-12, native=False)
+            assert abs(itp - pm.last_iters) <= 1, (itp, pm.last_iters)
+            assert float((xp - x).abs().max()) <= 1e-9 * float(x.abs().max())
         # ... on any partition: compact blocks (elements sorted by centroid) need the same number
         pc = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=3.0, elem_order="centroid", transport=transport)
         x = pc.solve(rho=rho, rtol=1e-12, precond="amg")
