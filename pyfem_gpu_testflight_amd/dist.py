@@ -1,6 +1,5 @@
-"""One-process-per-GPU partitioned assembly and solve (torch.distributed: RCCL on GPUs, gloo in
-the CPU tests).  Nothing like this exists in the reference (it is single-process numpy); the
-partition follows BASELINE.json north_star: contiguous ELEMENT blocks per rank.
+"""One-process-per-GPU partitioned assembly and solve.  Nothing like this exists in the reference (it is
+single-process numpy); the partition follows BASELINE.json north_star: contiguous ELEMENT blocks per rank.
 
 Layout
   * rank r owns elements [r*E/W, (r+1)*E/W).  Its local mesh is those elements over the nodes
@@ -8,20 +7,23 @@ Layout
     relative order).  Assembly of the local K needs no communication; rows of interface nodes
     hold partial sums.
   * vectors (x, r, z, p, s, b) are CONSISTENT: an interface dof carries the full value on
-    every rank that has it.  Products w = K z are completed by summing interface rows over ranks.
-  * all interface dofs of the job form one packed "interface vector" (G entries).  Each CG
-    iteration does ONE all-reduce of G+3 doubles: interface partial sums of w plus the three
-    scalars gamma = r.z, delta = z.w, r.r (Chronopoulos-Gear single-reduction PCG), so the
-    iteration has a single synchronisation point and no host round trip.  delta uses
-    z.(K z) = sum_ranks z_loc.(K_loc z_loc), so it is taken from the un-summed local product;
-    gamma and r.r count every dof once through the ownership mask (lowest rank owns).
-  * xGMI is point-to-point: for strip partitions (structured meshes) G is tiny (one node row per
-    cut) and the all-reduce is latency-bound -- see DESIGN.md for the numbers and the next step
-    (neighbour P2P + overlap with the interior SpMV).
+    every rank that has it.  Products w = K z are completed by summing interface rows over the ranks that share
+    them -- a NEIGHBOUR exchange (`Interface`): each rank sends a neighbour only the values of the nodes the two
+    share (one node row per cut for strips), the sums run in ascending rank order so that every copy of an
+    interface dof carries the same bits.
+  * one exchange per CG iteration: the interface sums of w with the three scalars gamma = r.z, delta = z.w, r.r
+    riding along (Chronopoulos-Gear single-reduction PCG).  delta uses z.(K z) = sum_ranks z_loc.(K_loc z_loc), so it
+    is taken from the un-summed local product; gamma and r.r count every dof once through the ownership mask (lowest
+    rank owns).
+  * transports: "peer" -- kernels store into the other ranks' windows over xGMI (csrc/pf_halo.hip: HIP IPC, sequence
+    flags; torch.distributed only carries the set-up handshake) and the loops run in C (pf_dist_cg, pf_dist_pcg_amg);
+    "p2p" -- torch.distributed send/recv driven from Python (gloo CPU tests, fallback).
+  * AMG over the partition: the single-GPU hierarchy replicated on every rank, its finest level distributed
+    (`ReplicatedHierarchy`): single-GPU iteration counts on any partition.
 
-`LocalOps` is what the driver needs from a rank-local backend.  The product backend is
-HipLocalOps (C ABI -> HIP kernels).  tests/ provides a numpy stand-in so the partition logic and
-the iteration can be exercised under gloo with world_size 2 on a CPU-only host.
+`LocalOps` is what the drivers need from a rank-local backend.  The product backend is
+HipLocalOps (C ABI -> HIP kernels).  tests/ provides a numpy stand-in so the partition logic, the exchange tables and
+the Jacobi iteration can be exercised under gloo with world_size 2 and 3 on a CPU-only host.
 """
 import ctypes as C
 
@@ -871,7 +873,7 @@ class PartitionedHelmholtz:
         self.hier = ReplicatedHierarchy(self.ops, pt, self._gmodel.hctx, group).setup(self._gmodel.K.vals)
 
     def _solve(self, b):
-        x, it, rr = dist_pcg_amg(self.ops, self.model.K.vals, b, self.own_w, self.iface, self.hier, rtol=self.rtol)
+        x, it, _ = dist_pcg_amg(self.ops, self.model.K.vals, b, self.own_w, self.iface, self.hier, rtol=self.rtol)
         self.last_iters = it
         return x
 
@@ -981,7 +983,6 @@ class PartitionedElasticity:
         up.  rho: global nodal density (numpy / device tensor over all nodes) or a scalar."""
         from . import pyfem
 
-        torch = self.ops.torch
         if self._gmodel is None:
             X, conn, dof_fixed, vals, force, q, b, E, nu, p, device = self._global_args
             self._gmodel = pyfem.LinearElasticity(X, conn, dof_fixed, vals, force, q, b, E=E, nu=nu, p=p, device=device)
