@@ -83,20 +83,26 @@ int pf_pattern_build(pf_ctx* ctx, int ndof_per_node /* 1 or the space dimension 
 int pf_pattern_dims(pf_ctx* ctx, int64_t* nrows, int64_t* nnz, int64_t* nblocks, int32_t* max_row_blocks);
 /* node graph (device out): nptr int32[nnodes+1], nidx int32[nblocks]; either may be NULL */
 int pf_pattern_get_graph(pf_ctx* ctx, int32_t* nptr, int32_t* nidx);
-/* The compact 8-byte visit records, if this mesh's numbering allows them (HOST out nvisits: 0 if not; DEVICE out
- * rec8 uint32[2*nvisits], may be NULL): d0 = off1 | off2<<13 | (off3&63)<<26, d1 = off3>>6 | pos0<<7 | pos1<<12 |
- * pos2<<17 | pos3<<22 | slot<<27 with 13-bit signed node offsets from the pair's own node.  For tests. */
-int pf_pattern_get_rec8(pf_ctx* ctx, int64_t* nvisits, uint32_t* rec8);
+/* The compact visit records the assembly kernel reads instead of the 16-byte ones, if any (HOST out rec_bytes: 8, 12 or
+ * 0 = none; nvisits; DEVICE out recs uint32[rec_bytes/4 * nvisits], may be NULL).  With signed node offsets from the
+ * pair's own node:
+ *   quads, 8 bytes      d0 = off1 | off2<<13 | (off3&63)<<26, d1 = off3>>6 | pos0<<7 | pos1<<12 | pos2<<17 | pos3<<22 | slot<<27
+ *   triangles, 8 bytes  d0 = (off1&0xffff) | off2<<16,        d1 = pos0 | pos1<<5 | pos2<<10 | slot<<15 | a<<20
+ *   triangles, 12 bytes {o1, o2, w} = the 16-byte record without its unused third node (numberings the offsets do not fit)
+ * For tests. */
+int pf_pattern_get_compact(pf_ctx* ctx, int32_t* rec_bytes, int64_t* nvisits, uint32_t* recs);
 /* scipy-layout CSR structure (device out): indptr int32[nrows+1], indices int32[nnz] */
 int pf_pattern_get_csr(pf_ctx* ctx, int32_t* indptr, int32_t* indices);
 /* Gather maps of the fused assembly kernel (2-D meshes and 8-node blocks), for tests that replay its index
  * arithmetic on the host.  Sizes come back through the HOST outputs ntiles / npt / nvisits (any may be NULL);
  * the DEVICE outputs may be NULL: tile_desc int32[4*ntiles] = {first node, first visit, first block,
- * nodes | visits<<8 | blocks<<16} per tile, vis_rec int32[4*nvisits] (12*nvisits for blocks) = the visit records,
+ * nodes | (a node with > 8 incident elements)<<7 | visits<<8 | blocks<<16} per tile, vis_rec int32[4*nvisits] (12*nvisits for blocks) = the visit records,
  * n2e_ptr int32[nnodes+1] = first visit of each node.  No counterpart in the reference (its scatter is
  * coo_matrix(...).tocsr(), pyfem.py:921-931). */
 int pf_pattern_get_tiles(pf_ctx* ctx, int64_t* ntiles, int32_t* npt, int64_t* nvisits, int32_t* tile_desc,
                          int32_t* vis_rec, int32_t* n2e_ptr);
+/* max_tile_blocks: blocks of the largest tile's segment = the plane size of the assembly kernel's LDS image (HOST out) */
+int pf_pattern_tile_info(pf_ctx* ctx, int32_t* max_tile_blocks);
 
 /* ---- numeric assembly --------------------------------------------------------------------
  * pf_assemble_elasticity2d replaces LinearElasticity.compute_jacobian (pyfem.py:1771-1795):

@@ -37,8 +37,9 @@ SIGNATURES = {
     "pf_pattern_dims": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     "pf_pattern_get_graph": (C.c_int, [_vp, _vp, _vp]),
     "pf_pattern_get_csr": (C.c_int, [_vp, _vp, _vp]),
-    "pf_pattern_get_rec8": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
+    "pf_pattern_get_compact": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "pf_pattern_get_tiles": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), _vp, _vp, _vp]),
+    "pf_pattern_tile_info": (C.c_int, [_vp, C.POINTER(_i32)]),
     "pf_assemble_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, C.c_int, _vp]),
     "pf_assemble_helmholtz2d": (C.c_int, [_vp, _f64, _vp, _vp]),
     "pf_sens_elasticity2d": (C.c_int, [_vp, _f64, _f64, _f64, _vp, _vp, _vp, _vp]),

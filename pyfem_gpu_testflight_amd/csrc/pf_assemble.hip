@@ -343,6 +343,7 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 // ------------------------------------------------------------------------------------------
 typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int pf_u32x3 __attribute__((ext_vector_type(3)));
 typedef double pf_f64x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t pf_rsrc;
 
@@ -359,16 +360,19 @@ __device__ __forceinline__ double buf_ld_f64(pf_rsrc r, uint32_t off) {
 }
 
 // packed word of a visit record: row positions of the rotated element's nodes and the node's slot in its tile.
-// 16-byte records: w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | slot<<26;  8-byte records: the second dword
-// d1 = (off3>>6)&127 | pos0<<7 | pos1<<12 | pos2<<17 | pos3<<22 | slot<<27   (pf_pattern.hip k_build_visits / k_build_rec8)
-template <bool REC8>
+// REC = bytes per record (pf_pattern.hip k_build_visits / k_build_rec8 / k_build_rec_tri):
+//   16 (any mesh; quads' fallback)  {o1, o2, o3, w}, w = pos0 | pos1<<6 | pos2<<12 | pos3<<18 | a<<24 | slot<<26
+//   12 (triangles' fallback)        {o1, o2, w}, the same w
+//    8 quads      d1 = (off3>>6)&127 | pos0<<7 | pos1<<12 | pos2<<17 | pos3<<22 | slot<<27
+//    8 triangles  d1 = pos0 | pos1<<5 | pos2<<10 | slot<<15 | a<<20
+template <int REC, int P>
 __device__ __forceinline__ int rec_pos(uint32_t w, int k) {
-  if constexpr (REC8) return (int)((w >> (7 + 5 * k)) & 31u);
+  if constexpr (REC == 8) return (int)((w >> ((P == 4 ? 7 : 0) + 5 * k)) & 31u);
   else return (int)((w >> (6 * k)) & 63u);
 }
-template <bool REC8>
+template <int REC, int P>
 __device__ __forceinline__ int rec_slot(uint32_t w) {
-  return (int)((w >> (REC8 ? 27 : 26)) & 15u);
+  return (int)((w >> (REC == 8 ? (P == 4 ? 27 : 15) : 26)) & 31u);
 }
 
 struct V4Rec {        // stage B: the lane's visit record + the tile's row pointers (one tile ahead)
@@ -389,6 +393,7 @@ struct V4Visit {      // stage C: what the quadrature needs (gathers in flight d
 
 struct V4Tile {       // wave-uniform tile scalars (one 16-byte scalar load, two tiles ahead)
   int32_t vb, nv, base, nblk, n0, nn;
+  bool deep;          // a node of the tile has more than 8 incident elements (fourth step of the diagonal pre-reduction)
 };
 
 // NOTE: the pipeline stages are free __forceinline__ functions, not lambdas: hipcc keeps local arrays of
@@ -402,47 +407,58 @@ __device__ __forceinline__ V4Tile v4_load_tile(int64_t t, int64_t t1, const int4
   T.n0 = dsc.x;
   T.vb = dsc.y;
   T.base = dsc.z;
-  T.nn = dsc.w & 255;
+  T.nn = dsc.w & 63;
+  T.deep = (dsc.w & 128) != 0;
   T.nv = (t < t1) ? ((dsc.w >> 8) & 255) : 0;
   T.nblk = (int32_t)((uint32_t)dsc.w >> 16);
   return T;
 }
 
-template <bool REC8>
+// step j of a wave's walk (n steps): descriptor t0 + j tstride; look-ahead past the end re-reads the last descriptor
+// with no pairs
+__device__ __forceinline__ V4Tile v4_walk_tile(int64_t j, int64_t n, int64_t t0, int64_t tstride,
+                                               const int4* __restrict__ tile_desc) {
+  const int64_t idx = t0 + min(j, n - 1) * tstride;
+  return v4_load_tile(j < n ? idx : idx + 1, idx + 1, tile_desc);
+}
+
+template <int REC>
 __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const int4* __restrict__ vis_rec,
                                              const int32_t* __restrict__ nptr) {
   V4Rec B;
   B.active = lane < T.nv;
   B.n0 = T.n0;
   B.base = T.base;
-  if constexpr (REC8) {  // 8-byte records: rec.x / rec.y hold the two dwords
-    const pf_rsrc rr = make_rsrc(reinterpret_cast<const uint2*>(vis_rec) + T.vb, (uint32_t)T.nv * 8u);
-    const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);
+  // this tile's records only, and its nn + 1 row pointers
+  const pf_rsrc rr = make_rsrc(reinterpret_cast<const unsigned char*>(vis_rec) + (int64_t)T.vb * REC, (uint32_t)T.nv * (uint32_t)REC);
+  const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);
+  if constexpr (REC == 8) {  // rec.x / rec.y hold the two dwords
     const pf_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, 0, 0);
     B.rec = make_int4((int)r.x, (int)r.y, 0, 0);
-    B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
-    return B;
+  } else if constexpr (REC == 12) {
+    const pf_u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rr, lane * 12, 0, 0);
+    B.rec = make_int4((int)r.x, (int)r.y, 0, (int)r.z);
+  } else {
+    const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
+    B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   }
-  const pf_rsrc rr = make_rsrc(vis_rec + T.vb, (uint32_t)T.nv * 16u);         // this tile's records only
-  const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);      // and its nn + 1 row pointers
-  const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
-  B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
   return B;
 }
 
-template <int P, bool RHO, bool REC8>
+template <int P, bool RHO, int REC>
 __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsrc Rrho, V4Visit<P, RHO>& C) {
-  if constexpr (REC8) {
+  if constexpr (REC == 8) {
     const uint32_t d0 = (uint32_t)B.rec.x, d1 = (uint32_t)B.rec.y;
-    const int ln = rec_slot<true>(d1);
+    const int ln = rec_slot<8, P>(d1);
     C.w = d1;
     C.active = B.active;
     C.roff = __shfl(B.rp, ln) - B.base;
     // a lane without a pair holds an all-zero record: offsets 0, i.e. node n0 four times -- in range
     const int32_t n = B.n0 + ln;
-    const int32_t o1 = n + ((int32_t)(d0 << 19) >> 19);
-    const int32_t o2 = n + ((int32_t)(d0 << 6) >> 19);
+    // quads: three 13-bit offsets; triangles: two 16-bit offsets
+    const int32_t o1 = n + (P == 4 ? ((int32_t)(d0 << 19) >> 19) : ((int32_t)(d0 << 16) >> 16));
+    const int32_t o2 = n + (P == 4 ? ((int32_t)(d0 << 6) >> 19) : ((int32_t)d0 >> 16));
     const int32_t o3 = n + ((int32_t)(((d0 >> 26) | ((d1 & 127u) << 6)) << 19) >> 19);
     const double2 p0 = buf_ld_f64x2(RX, (uint32_t)n * 16u);
     const double2 p1 = buf_ld_f64x2(RX, (uint32_t)o1 * 16u);
@@ -469,9 +485,9 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
   // write-after-write hazard makes it wait for the record right behind its issue (r02 ISA: s_waitcnt vmcnt(1) one
   // instruction after the load -- a full memory latency per tile; 0.181 -> 0.212 ms on 4 M triangles).  Keeping the
   // component alive until the record is consumed removes the wait.
-  if constexpr (P == 3) asm volatile("" ::"v"(B.rec.z));
+  if constexpr (P == 3 && REC == 16) asm volatile("" ::"v"(B.rec.z));
   const uint32_t w = (uint32_t)B.rec.w;
-  const int ln = (int)((w >> 26) & 15);
+  const int ln = (int)((w >> 26) & 31);
   C.w = w;
   C.active = B.active;
   C.roff = __shfl(B.rp, ln) - B.base;
@@ -499,15 +515,27 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
 }
 
 // one step of the segmented inclusive scan of v4_tile: x[k] += x[k] of the lane SH places down the row if that lane
-// works for the same node (keys are sorted along the lanes, so equal keys SH apart mean one run)
-template <int SH, int V>
-__device__ __forceinline__ void v4_seg_step(int key, double x[V]) {
+// works for the same node (keys are sorted along the lanes, so equal keys SH apart mean one run).
+// The shifted values are fetched by every lane (a DPP source lane must be active), the adds run under the lane mask:
+// written as `x += same ? y : 0` hipcc selects both halves of every y (2 v_cndmask per value and step -- 64 of the 240
+// vector instructions of a triangle pass, r02 ISA, and the triangle kernel is bound by instruction issue); the volatile
+// asm keeps the add inside the branch, i.e. under EXEC, at one instruction per value.
+template <int SH, int NV>
+__device__ __forceinline__ void v4_seg_step(int key, double* x) {
   const bool same = __builtin_amdgcn_update_dpp(-1, key, 0x110 + SH, 0xf, 0xf, false) == key;  // row_shr:SH
+  double y[NV];
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x[k]), 0x110 + SH, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x[k]), 0x110 + SH, 0xf, 0xf, true);
-    x[k] += same ? __hiloint2double(hi, lo) : 0.0;
+    y[k] = __hiloint2double(hi, lo);
+  }
+  if (same) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[k]) : "v"(y[k]));
+    // the next DPP reads x: 2 wait states between a VALU write and a DPP read of one VGPR (ISA manual, manually
+    // inserted wait states); hipcc's hazard recogniser does not look inside inline asm
+    asm volatile("s_nop 1");
   }
 }
 
@@ -526,7 +554,7 @@ __device__ int g_abl_mask = 0;
 // blocks' 4 values adjacent (the global layout) every lane of an add instruction would land on the same
 // 8 of the 32 banks (PMC counters: a third of all LDS cycles were bank conflicts); by planes, lanes that
 // touch different blocks touch different banks.  The copy-out re-interleaves two planes per 16-byte piece.
-template <int P, class Phys, bool RHO, int NOUT, bool COMB, bool REC8>
+template <int P, class Phys, bool RHO, int NOUT, bool COMB, int REC>
 __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V4Tile& Tcur,
                                         const V4Visit<P, RHO>& Cuse, double* img, int plane, int lane,
                                         double* __restrict__ out0, double* __restrict__ out1) {
@@ -564,16 +592,26 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
       // lanes first: a segmented scan over the node slot inside each row of 16 lanes (DPP row shifts: plain VALU,
       // no LDS), after which only the last lane of a node's run adds.  A run that crosses a row boundary adds twice.
       // Fixed lane order, so the result stays bitwise reproducible.
-      const int key = rec_slot<REC8>(Cuse.w);
-      v4_seg_step<1, V>(key, v[0]);
-      v4_seg_step<2, V>(key, v[0]);
-      v4_seg_step<4, V>(key, v[0]);
-      v4_seg_step<8, V>(key, v[0]);
+      const int key = rec_slot<REC, P>(Cuse.w);
+      // 2x2 blocks: the diagonal block of a symmetric element matrix is symmetric up to the rounding of its two
+      // off-diagonal entries; scan three values and use the sum of [0][1] for both
+      constexpr int NV = (V == 4) ? 3 : V;
+      double xs[NV];
+      xs[0] = v[0][0];
+      if constexpr (V == 4) { xs[1] = v[0][1]; xs[2] = v[0][3]; }
+      else if constexpr (V == 2) xs[1] = v[0][1];
+      v4_seg_step<1, NV>(key, xs);
+      v4_seg_step<2, NV>(key, xs);
+      v4_seg_step<4, NV>(key, xs);
+      if (Tcur.deep) v4_seg_step<8, NV>(key, xs);  // only tiles with a node of more than 8 incident elements
+      v[0][0] = xs[0];
+      if constexpr (V == 4) { v[0][1] = xs[1]; v[0][2] = xs[1]; v[0][3] = xs[2]; }
+      else if constexpr (V == 2) v[0][1] = xs[1];
       add_diag = __builtin_amdgcn_update_dpp(-1, key, 0x101, 0xf, 0xf, false) != key;  // row_shl:1: the next lane's node
     }
 #pragma unroll
     for (int b = 0; b < P; ++b) {
-      double* dst = row + rec_pos<REC8>(Cuse.w, b);
+      double* dst = row + rec_pos<REC, P>(Cuse.w, b);
 #ifdef PF_EXPERIMENTS
       if (abl & 1) { if (v[b][0] == 1.2345e300) dst[0] = v[b][V > 1 ? 1 : 0] + v[b][V - 1]; continue; }  // keeps v alive, adds nothing
 #endif
@@ -655,10 +693,11 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
   }
 }
 
-// COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it takes 0.191 ms back
-// to 0.156 ms on 4 M elements; quads are HBM-bound and measured the same with and without it (profiles/r02_assembly_ab.md)
-template <int P, class Phys, bool RHO, int NOUT, bool REC8, bool COMB = (P == 3)>
-__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t npt, int32_t maxrow,
+// COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it took 0.191 ms back
+// to 0.156 ms on 4 M elements, and its cheaper form (v4_seg_step) to 0.14 ms; quads are HBM-bound and measured the same
+// with and without it (profiles/r02_assembly_ab.md)
+template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3)>
+__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int4* __restrict__ tile_desc,
@@ -666,8 +705,7 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
                                                     typename Phys::Params pr, double* __restrict__ out0,
                                                     double* __restrict__ out1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double* const img = reinterpret_cast<double*>(smem);
-  const int plane = npt * maxrow + 1;  // odd plane stride: the V planes start on different banks
+  double* const img = reinterpret_cast<double*>(smem);  // V planes of `plane` doubles (odd: the planes start on different banks)
   const int lane = threadIdx.x;
   // tile walk: contiguous run per wave (tstride == 1) or round-robin over the grid (tstride == gridDim)
   // strided == 2: XCD-aware round-robin.  Workgroups are dealt to the 8 XCDs round-robin (b % 8), so with
@@ -678,19 +716,20 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   const int64_t t0 = strided ? vblk : ntiles * blockIdx.x / gridDim.x;
   const int64_t t1 = strided ? ntiles : ntiles * (blockIdx.x + 1) / gridDim.x;
   if (t0 >= t1) return;
+  const int64_t n = strided ? (t1 - t0 + tstride - 1) / tstride : t1 - t0;  // tiles of this wave
   // resources of the gathered arrays (the host checked that nnodes * 16 fits 32 bits)
   const pf_rsrc RX = make_rsrc(X, (uint32_t)nnodes * 16u);
   const pf_rsrc Rrho = make_rsrc(pr.rho, pr.rho ? (uint32_t)nnodes * 8u : 0u);
 
   // Pipeline state.  Two register sets (a/b) are used on alternate tiles, so nothing a load is about to
   // write is ever copied: a rotation by copy would have to wait for the loads just issued.
-  V4Tile T0 = v4_load_tile(t0, t1, tile_desc);
-  V4Tile T1 = v4_load_tile(t0 + tstride, t1, tile_desc);
-  V4Tile T2 = v4_load_tile(t0 + 2 * tstride, t1, tile_desc);
-  V4Rec Ba = v4_load_rec<REC8>(T0, lane, vis_rec, nptr);
-  V4Rec Bb = v4_load_rec<REC8>(T1, lane, vis_rec, nptr);
+  V4Tile T0 = v4_walk_tile(0, n, t0, tstride, tile_desc);
+  V4Tile T1 = v4_walk_tile(1, n, t0, tstride, tile_desc);
+  V4Tile T2 = v4_walk_tile(2, n, t0, tstride, tile_desc);
+  V4Rec Ba = v4_load_rec<REC>(T0, lane, vis_rec, nptr);
+  V4Rec Bb = v4_load_rec<REC>(T1, lane, vis_rec, nptr);
   V4Visit<P, RHO> Ca, Cb;
-  v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca);
+  v4_load_visit<P, RHO, REC>(Ba, RX, Rrho, Ca);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
@@ -701,21 +740,21 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
 
   // steady state: two tiles per trip, both always executed (a conditional second half gives the
   // back edge two different in-flight counts and hipcc falls back to vmcnt(0) at the loop top)
-  int64_t t = t0;
-  for (; t + tstride < t1; t += 2 * tstride) {
-    // tile t: integrate Ca; gathers of tile t+1 -> Cb (record Bb arrived last step); record of t+2 -> Ba
-    const V4Tile T3 = v4_load_tile(t + 3 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO, REC8>(Bb, RX, Rrho, Cb);
-    Ba = v4_load_rec<REC8>(T2, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T0, Ca, img, plane, lane, out0, out1);
-    // tile t+1: integrate Cb; gathers of tile t+2 -> Ca; record of t+3 -> Bb
-    const V4Tile T4 = v4_load_tile(t + 4 * tstride, t1, tile_desc);
-    v4_load_visit<P, RHO, REC8>(Ba, RX, Rrho, Ca);
-    Bb = v4_load_rec<REC8>(T3, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T1, Cb, img, plane, lane, out0, out1);
+  int64_t j = 0;
+  for (; j + 1 < n; j += 2) {
+    // tile j: integrate Ca; gathers of tile j+1 -> Cb (record Bb arrived last step); record of j+2 -> Ba
+    const V4Tile T3 = v4_walk_tile(j + 3, n, t0, tstride, tile_desc);
+    v4_load_visit<P, RHO, REC>(Bb, RX, Rrho, Cb);
+    Ba = v4_load_rec<REC>(T2, lane, vis_rec, nptr);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1);
+    // tile j+1: integrate Cb; gathers of tile j+2 -> Ca; record of j+3 -> Bb
+    const V4Tile T4 = v4_walk_tile(j + 4, n, t0, tstride, tile_desc);
+    v4_load_visit<P, RHO, REC>(Ba, RX, Rrho, Ca);
+    Bb = v4_load_rec<REC>(T3, lane, vis_rec, nptr);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T1, Cb, img, plane, lane, out0, out1);
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (t < t1) v4_tile<P, Phys, RHO, NOUT, COMB, REC8>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
+  if (j < n) v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
 }
 
 // ------------------------------------------------------------------------------------------
@@ -943,6 +982,16 @@ static inline ElasticityParams make_elasticity(double E, double nu, double p, co
   return pr;
 }
 
+// copy-out variant for `per_lane` 16-byte pieces per lane: a static store count (3, 5, 10) or the counted loop (0)
+template <int P, class Phys, bool RHO, int REC>
+static auto v4_variant(int per_lane, int& nout) -> decltype(&k_assemble_v4<P, Phys, RHO, 0, REC>) {
+  if (per_lane <= 3) { nout = 3; return k_assemble_v4<P, Phys, RHO, 3, REC>; }
+  if (per_lane <= 5) { nout = 5; return k_assemble_v4<P, Phys, RHO, 5, REC>; }
+  if (per_lane <= 10) { nout = 10; return k_assemble_v4<P, Phys, RHO, 10, REC>; }
+  nout = per_lane;
+  return k_assemble_v4<P, Phys, RHO, 0, REC>;
+}
+
 // Launch of the fused assembly kernel.  Experiment knobs (builds with -DPF_EXPERIMENTS only; the product library never
 // reads them): PF_GATHER_WAVES_PER_CU, PF_TILE_ORDER=c|x.
 template <int P, class Phys, bool RHO>
@@ -957,15 +1006,22 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   const int per_lane = Phys::V == 4 ? (int)cdiv(tile_blocks * 2, 64) : (int)cdiv(tile_blocks, 128);  // 16-byte pieces
   // compact records whenever the symbolic phase built them (quads: r02 A/B on 4M elements -- triangles ran 2.5 % slower
   // with them, the quad Helmholtz kernel 2.6 % faster, quad elasticity the same with 8 % less traffic)
-  const bool r8 = ctx->vis_rec8 != nullptr;
-  auto k4 = r8 ? k_assemble_v4<P, Phys, RHO, 0, true> : k_assemble_v4<P, Phys, RHO, 0, false>;
+  // compact records whenever the symbolic phase built them: 8 bytes when the numbering allows it, else 12 (triangles) or
+  // 16 (quads).  Both kernels are bound by the memory system (r02: quads 8 % less traffic, the same time; triangles
+  // after the cheaper pre-reduction: see profiles/r02_assembly_ab.md)
+  constexpr int RECF = (P == 3) ? 12 : 16;  // fallback record
+  const void* recs = ctx->vis_rec8 ? ctx->vis_rec8 : (P == 3 && ctx->vis_rec12) ? ctx->vis_rec12 : ctx->vis_rec;
+  const int rec = ctx->vis_rec8 ? 8 : (P == 3 && ctx->vis_rec12) ? 12 : 16;
   int nout = 0;
-  if (per_lane <= 3) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 3, true> : k_assemble_v4<P, Phys, RHO, 3, false>; nout = 3; }
-  else if (per_lane <= 5) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 5, true> : k_assemble_v4<P, Phys, RHO, 5, false>; nout = 5; }
-  else if (per_lane <= 10) { k4 = r8 ? k_assemble_v4<P, Phys, RHO, 10, true> : k_assemble_v4<P, Phys, RHO, 10, false>; nout = 10; }
-  else nout = per_lane;
+  decltype(&k_assemble_v4<P, Phys, RHO, 0, 8>) k4 = nullptr;
+  if (rec == 8) k4 = v4_variant<P, Phys, RHO, 8>(per_lane, nout);
+  else if (rec == RECF) k4 = v4_variant<P, Phys, RHO, RECF>(per_lane, nout);
+#if defined(PF_EXPERIMENTS) || defined(PF_AB_TRI_REC)  // triangles on the 16-byte records: A/B builds only
+  else if constexpr (P == 3) k4 = v4_variant<P, Phys, RHO, 16>(per_lane, nout);
+#endif
+  if (!k4) return pf_fail(ctx, PF_E_UNSUPPORTED, "assemble: no kernel for this record layout");
   // image + the run-over of the copy-out's LDS reads (pieces past the segment end are read and then dropped)
-  const size_t plane = (size_t)ctx->npt * ctx->max_row_blocks + 1;
+  const size_t plane = (size_t)tile_blocks | 1;
   // (2x2 blocks: piece u of a lane reads 32 u doubles past its base; scalar matrices: 128 u.  Keep it tight: with 2.5 KB
   // more than needed the quad elasticity kernel dropped from 16 to 15 resident waves per CU and ran 25 % slower, r02.)
   const size_t lds4 = (((plane * Phys::V + 127) & ~(size_t)127) + (size_t)(Phys::V == 4 ? 32 : 128) * nout + 2) * 8;
@@ -988,8 +1044,8 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   // elasticity kernel, 24-32 for the others).  More than that and the surplus waves only start when the first ones
   // have finished their share -- a second, half-empty round (r02: 24 launched / 16 resident cost the quad kernel a
   // quarter of its time); fewer and latency is not covered.  Capped at 32 per CU (r01 sweep: no gain beyond).
-  static thread_local struct { size_t lds; int wpc; } occ[8] = {};  // per copy-out variant and record width
-  auto& oc = occ[(nout == 3 ? 1 : nout == 5 ? 2 : nout == 10 ? 3 : 0) + (r8 ? 4 : 0)];
+  static thread_local struct { size_t lds; int wpc; } occ[12] = {};  // per copy-out variant and record width
+  auto& oc = occ[(nout == 3 ? 1 : nout == 5 ? 2 : nout == 10 ? 3 : 0) + (rec == 8 ? 4 : rec == 12 ? 8 : 0)];
   if (oc.wpc == 0 || oc.lds != lds4) {
     int q = 0;
     PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(k4), 64, lds4));
@@ -1005,9 +1061,9 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   const char* to = pf_exp_env("PF_TILE_ORDER");
   int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
   if (tile_order == 2 && (grid & 7)) tile_order = 1;
-  hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, ctx->npt, ctx->max_row_blocks,
+  hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, (int32_t)plane,
                      ctx->X, ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc),
-                     reinterpret_cast<const int4*>(r8 ? ctx->vis_rec8 : ctx->vis_rec), (int64_t)(ctx->nelems * ctx->P), tile_order,
+                     reinterpret_cast<const int4*>(recs), (int64_t)(ctx->nelems * ctx->P), tile_order,
                      pr, out0, out1);
   PF_LAUNCH_CHECK();
   return PF_OK;

@@ -59,10 +59,12 @@ struct pf_ctx {
   uint8_t* diagpos = nullptr;  // (nnodes) position of n in its own row
   void* vis_rec = nullptr;     // (nelems*P) int4 per incident pair: other node ids + packed positions/indices
                                //   (blocks: 3 x int4 = 8 node ids, 8 position bytes, local index, tile slot)
+  void* vis_rec12 = nullptr;   // triangles: (nelems*3) x 12 bytes {o1, o2, w} (the 16-byte record without its unused slot)
+                               //   when the 8-byte form does not fit the numbering
   void* vis_rec8 = nullptr;    // (nelems*P) uint2: the same records in 8 bytes (13-bit node offsets, 5-bit positions) when
                                //   the numbering allows it, else nullptr (pf_pattern.hip k_build_rec8)
   int npt = 0;                 // max nodes per assembly tile (incident pairs of a tile fit 64 lanes); 0: legacy kernel only
-  void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | visits<<8 | blocks<<16}
+  void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | deep<<7 | visits<<8 | blocks<<16}
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   int32_t max_tile_blocks = 0; // blocks of the largest tile (sets the static store count of the copy-out)
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)

@@ -244,9 +244,38 @@ __global__ void k_build_rec8(int64_t nnodes, const int32_t* __restrict__ n2e_ptr
       ok = ok && pos < 32u;
       d1 |= pos << (7 + 5 * k);
     }
-    d1 |= ((w >> 26) & 15u) << 27;
+    d1 |= ((w >> 26) & 31u) << 27;
     if (!ok) { flag[0] = 1; return; }
     rec8[jj] = make_uint2(off[0] | (off[1] << 13) | ((off[2] & 63u) << 26), d1);
+  }
+}
+
+// Triangles: the 16-byte record carries an unused slot (o3).  Two compact forms for the assembly kernel:
+//   12 bytes  {o1, o2, w}                                           any numbering
+//    8 bytes  d0 = (off1 & 0xffff) | off2 << 16                      neighbours within +-32767 node ids, rows <= 32 blocks
+//             d1 = pos0 | pos1 << 5 | pos2 << 10 | slot << 15 | a << 20
+// (the record stream is 28 % of what a triangle launch moves with 16-byte records, r02).  flag[0] is raised when some
+// record does not fit the 8-byte form; the caller then keeps the 12-byte array.
+__global__ void k_build_rec_tri(int64_t nnodes, const int32_t* __restrict__ n2e_ptr, const int4* __restrict__ vis_rec,
+                                uint2* __restrict__ rec8, uint32_t* __restrict__ rec12, int32_t* __restrict__ flag) {
+  int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (n >= nnodes) return;
+  for (int32_t jj = n2e_ptr[n]; jj < n2e_ptr[n + 1]; ++jj) {
+    const int4 r = vis_rec[jj];
+    const uint32_t w = (uint32_t)r.w;
+    rec12[3 * (int64_t)jj + 0] = (uint32_t)r.x;
+    rec12[3 * (int64_t)jj + 1] = (uint32_t)r.y;
+    rec12[3 * (int64_t)jj + 2] = w;
+    const int64_t d1n = (int64_t)r.x - n, d2n = (int64_t)r.y - n;
+    bool ok = d1n >= -32768 && d1n <= 32767 && d2n >= -32768 && d2n <= 32767;
+    uint32_t d1 = (((w >> 26) & 31u) << 15) | (((w >> 24) & 3u) << 20);
+    for (int k = 0; k < 3; ++k) {
+      const uint32_t pos = (w >> (6 * k)) & 63u;
+      ok = ok && pos < 32u;
+      d1 |= (pos & 31u) << (5 * k);
+    }
+    if (!ok) flag[0] = 1;
+    rec8[jj] = make_uint2(((uint32_t)d1n & 0xffffu) | ((uint32_t)d2n << 16), d1);
   }
 }
 
@@ -361,6 +390,7 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->e2pos);
   pf_free(ctx->vis_rec);
   pf_free(ctx->vis_rec8);
+  pf_free(ctx->vis_rec12);
   pf_free(ctx->tile_desc);
   pf_free(ctx->tab_order);
   ctx->tab_color_ptr.clear();
@@ -594,6 +624,9 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     for (int64_t n0 = 0; n0 < nn;) {
       int64_t emax = std::min<int64_t>(n0 + ctx->npt, nn);
       while (emax > n0 + 1 && hv[emax] - hv[n0] > 64) --emax;  // at most 64 incident pairs per tile
+      // 2x2 blocks: at most 160 blocks (5 KB) per tile, so that one irregular tile (16 nodes with rows of 11 blocks)
+      // does not put the whole launch on the 10-store copy-out with a twice as large LDS image
+      while (d == 2 && emax > n0 + 1 && hp[emax] - hp[n0] > 160) --emax;
       int64_t e = emax;
       if (emax < nn && !fixed) {
         // stop early for alignment only while the wave stays >= 90 % as full as it could be: on valence-6 triangles
@@ -609,14 +642,17 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
       }
       ctx->max_tile_blocks = std::max(ctx->max_tile_blocks, hp[e] - hp[n0]);
       for (int64_t n = n0; n < e; ++n) slot[n] = (uint8_t)(n - n0);
+      int32_t deep = 0;  // bit 7 (2-D tiles): a node with more than 8 incident elements
+      if (ctx->P != 8)
+        for (int64_t n = n0; n < e; ++n) deep |= (hv[n + 1] - hv[n] > 8) ? 128 : 0;
       desc.push_back((int32_t)n0);
       desc.push_back(hv[n0]);
       desc.push_back(hp[n0]);
-      desc.push_back((int32_t)((e - n0) | ((int64_t)(hv[e] - hv[n0]) << 8) | ((int64_t)(hp[e] - hp[n0]) << 16)));
+      desc.push_back((int32_t)((e - n0) | deep | ((int64_t)(hv[e] - hv[n0]) << 8) | ((int64_t)(hp[e] - hp[n0]) << 16)));
       n0 = e;
     }
     ctx->ntiles = (int64_t)desc.size() / 4;
-    PF_REQUIRE((int64_t)ctx->npt * ctx->max_row_blocks < 65536, "pf_pattern_build: tile too large for the descriptor");
+    PF_REQUIRE(ctx->max_tile_blocks < 65536 && ctx->npt <= 32, "pf_pattern_build: tile too large for the descriptor");
     uint8_t* dslot = nullptr;
     PF_HIP(hipMalloc(&ctx->tile_desc, sizeof(int32_t) * desc.size()));
     PF_HIP(hipMalloc(&dslot, nn));
@@ -630,17 +666,40 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     else
       k_build_visits<3><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, dslot, ctx->conn, ctx->n2e_ptr, ctx->n2e, ctx->n2e_pos, (int4*)ctx->vis_rec);
     PF_LAUNCH_CHECK();
-    if (ctx->P == 4) {  // compact records for quads when the numbering allows them
+    if (ctx->P == 4 || ctx->P == 3) {  // compact records when the numbering allows them (triangles: else 12 bytes)
       int32_t* f8 = nullptr;
       PF_HIP(hipMalloc(&ctx->vis_rec8, sizeof(uint2) * (size_t)total));
+      if (ctx->P == 3) PF_HIP(hipMalloc(&ctx->vis_rec12, 12 * (size_t)total));
       PF_HIP(hipMalloc(&f8, sizeof(int32_t)));
       PF_HIP(hipMemsetAsync(f8, 0, sizeof(int32_t), ctx->stream));
-      k_build_rec8<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
+      if (ctx->P == 4)
+        k_build_rec8<4><<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8, f8);
+      else
+        k_build_rec_tri<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, (uint2*)ctx->vis_rec8,
+                                                                      (uint32_t*)ctx->vis_rec12, f8);
       int32_t bad = 0;
       PF_HIP(hipMemcpyAsync(&bad, f8, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
       PF_HIP(hipStreamSynchronize(ctx->stream));
       (void)hipFree(f8);
       if (bad || pf_exp_env("PF_NO_REC8")) pf_free(ctx->vis_rec8);
+      if (ctx->vis_rec8 || pf_exp_env("PF_NO_REC12")) pf_free(ctx->vis_rec12);  // one compact form is kept
+#ifdef PF_AB_TRI_REC  // tools/build_variant.sh: force the triangles' record width (12 or 16)
+      if (ctx->P == 3 && PF_AB_TRI_REC >= 12 && ctx->vis_rec8) {
+        pf_free(ctx->vis_rec8);
+        if (PF_AB_TRI_REC == 12) {
+          int32_t* f8 = nullptr;
+          uint2* tmp8 = nullptr;
+          PF_HIP(hipMalloc(&f8, sizeof(int32_t)));
+          PF_HIP(hipMalloc(&tmp8, sizeof(uint2) * (size_t)total));
+          PF_HIP(hipMalloc(&ctx->vis_rec12, 12 * (size_t)total));
+          k_build_rec_tri<<<(unsigned)cdiv(nn, T), T, 0, ctx->stream>>>(nn, ctx->n2e_ptr, (const int4*)ctx->vis_rec, tmp8, (uint32_t*)ctx->vis_rec12, f8);
+          PF_HIP(hipStreamSynchronize(ctx->stream));
+          (void)hipFree(f8);
+          (void)hipFree(tmp8);
+        }
+      }
+      if (ctx->P == 3 && PF_AB_TRI_REC == 16) pf_free(ctx->vis_rec12);
+#endif
     }
     PF_HIP(hipStreamSynchronize(ctx->stream));  // the host staging vectors go out of scope
     (void)hipFree(dslot);
@@ -695,12 +754,22 @@ extern "C" int pf_pattern_get_tiles(pf_ctx* ctx, int64_t* ntiles, int32_t* npt, 
   return PF_OK;
 }
 
-extern "C" int pf_pattern_get_rec8(pf_ctx* ctx, int64_t* nvisits, uint32_t* rec8) {
+extern "C" int pf_pattern_tile_info(pf_ctx* ctx, int32_t* max_tile_blocks) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(ctx->d, "pf_pattern_get_rec8: no pattern built");
-  if (nvisits) *nvisits = ctx->vis_rec8 ? ctx->nelems * ctx->P : 0;
-  if (rec8 && ctx->vis_rec8)
-    PF_HIP(hipMemcpyAsync(rec8, ctx->vis_rec8, sizeof(uint2) * (size_t)(ctx->nelems * ctx->P), hipMemcpyDeviceToDevice, ctx->stream));
+  PF_REQUIRE(ctx->d && ctx->npt && ctx->tile_desc, "pf_pattern_tile_info: this pattern has no assembly tiles");
+  if (max_tile_blocks) *max_tile_blocks = ctx->max_tile_blocks;
+  return PF_OK;
+}
+
+extern "C" int pf_pattern_get_compact(pf_ctx* ctx, int32_t* rec_bytes, int64_t* nvisits, uint32_t* recs) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d, "pf_pattern_get_compact: no pattern built");
+  const void* src = ctx->vis_rec8 ? ctx->vis_rec8 : ctx->vis_rec12;
+  const int32_t bytes = ctx->vis_rec8 ? 8 : ctx->vis_rec12 ? 12 : 0;
+  if (rec_bytes) *rec_bytes = bytes;
+  if (nvisits) *nvisits = src ? ctx->nelems * ctx->P : 0;
+  if (recs && src)
+    PF_HIP(hipMemcpyAsync(recs, src, (size_t)bytes * (size_t)(ctx->nelems * ctx->P), hipMemcpyDeviceToDevice, ctx->stream));
   return PF_OK;
 }
 

@@ -152,8 +152,8 @@ class HipContext:
         return nptr, nidx
 
     def assembly_maps(self):
-        """Host copies of the fused assembly kernel's gather maps (pf_pattern_get_tiles): dict with npt, tile_desc
-        (ntiles,4), vis_rec (nvisits,4 | 12), rec8 (nvisits,2) uint32 or None (the compact records, when the numbering allows them), n2e_ptr
+        """Host copies of the fused assembly kernel's gather maps (pf_pattern_get_tiles): dict with npt, max_tile_blocks (pf_pattern_tile_info), tile_desc
+        (ntiles,4), vis_rec (nvisits,4 | 12), rec8 (nvisits,2) / rec12 (nvisits,3) uint32 or None (the compact records of pf_pattern_get_compact), n2e_ptr
         (nnodes+1), nptr (nnodes+1).  For tests that replay the kernel's index arithmetic."""
         torch = self.torch
         nt, npt, nv = _lib._i64(), _lib._i32(), _lib._i64()
@@ -165,14 +165,17 @@ class HipContext:
         n2e = self.empty(self.nnodes + 1, torch.int32)
         self._call("pf_pattern_get_tiles", None, None, None, _ptr(td), _ptr(vr), _ptr(n2e))
         nptr, _ = self.graph()
-        n8 = _lib._i64()
-        self._call("pf_pattern_get_rec8", C.byref(n8), None)
-        rec8 = None
+        n8, rb = _lib._i64(), _lib._i32()
+        self._call("pf_pattern_get_compact", C.byref(rb), C.byref(n8), None)
+        rec8 = rec12 = None
         if n8.value:
-            r8 = self.empty(2 * n8.value, torch.int32)
-            self._call("pf_pattern_get_rec8", None, _ptr(r8))
-            rec8 = r8.cpu().numpy().view(np.uint32).reshape(-1, 2)
-        return {"npt": npt.value, "rec8": rec8, "tile_desc": td.cpu().numpy().reshape(-1, 4), "vis_rec": vr.cpu().numpy().reshape(-1, w),
+            rc = self.empty(rb.value // 4 * n8.value, torch.int32)
+            self._call("pf_pattern_get_compact", None, None, _ptr(rc))
+            rc = rc.cpu().numpy().view(np.uint32).reshape(-1, rb.value // 4)
+            rec8, rec12 = (rc, None) if rb.value == 8 else (None, rc)
+        mtb = _lib._i32()
+        self._call("pf_pattern_tile_info", C.byref(mtb))
+        return {"npt": npt.value, "max_tile_blocks": mtb.value, "rec8": rec8, "rec12": rec12, "tile_desc": td.cpu().numpy().reshape(-1, 4), "vis_rec": vr.cpu().numpy().reshape(-1, w),
                 "n2e_ptr": n2e.cpu().numpy(), "nptr": nptr.cpu().numpy()}
 
     # -- numeric --------------------------------------------------------------------------

@@ -30,20 +30,21 @@ def pf():
 def _replay(maps, nnodes, P, max_row_blocks, d, conn):
     td, vr, n2e, nptr, npt = maps["tile_desc"], maps["vis_rec"], maps["n2e_ptr"], maps["nptr"], maps["npt"]
     ntiles, nvis = td.shape[0], vr.shape[0]
-    assert nvis == n2e[-1]
-    plane = npt * max_row_blocks + 1  # doubles per value plane of the LDS image (k_assemble_v4: `plane`)
+    assert nvis == n2e[-1] and npt <= 32
+    plane = maps["max_tile_blocks"] | 1  # doubles per value plane of the LDS image (launch_gather: `plane`)
     lanes = np.arange(64)
     radix = nnodes ** np.arange(P, dtype=np.int64)  # test meshes are small: nnodes**P fits int64
     conn_keys = conn.astype(np.int64) @ radix
     covered_nodes = covered_vis = covered_blocks = 0
-    # the kernel reads descriptors min(t, t1 - 1) for t up to 4 tiles ahead: always inside [0, ntiles)
+    # the kernel reads descriptors up to 4 steps ahead, clamped to the wave's last one: always inside [0, ntiles)
     for t in range(ntiles):
         n0, vb, base, w = (int(v) for v in td[t])
-        nn_t, nv_t, nblk = w & 255, (w >> 8) & 255, (w >> 16) & 0xFFFF
+        nn_t, nv_t, nblk, deep = w & 63, (w >> 8) & 255, (w >> 16) & 0xFFFF, (w >> 7) & 1
         assert 0 <= n0 and n0 + nn_t <= nnodes and 1 <= nn_t <= npt
-        assert nv_t <= 64 and vb == n2e[n0] and vb + nv_t == n2e[n0 + nn_t]
-        assert base == nptr[n0] and base + nblk == nptr[n0 + nn_t] and nblk <= npt * max_row_blocks
-        assert n0 == covered_nodes and vb == covered_vis and base == covered_blocks  # tiles partition everything
+        assert nv_t <= 64 and base == nptr[n0] and base + nblk == nptr[n0 + nn_t] and nblk <= maps["max_tile_blocks"]
+        assert deep == int((np.diff(n2e[n0:n0 + nn_t + 1]) > 8).any())  # fourth step of the diagonal pre-reduction
+        assert n0 == covered_nodes and vb == covered_vis == n2e[n0] and base == covered_blocks  # tiles partition everything
+        assert vb + nv_t == n2e[n0 + nn_t] and (d != 2 or nblk <= 160 or nn_t == 1)
         covered_nodes, covered_vis, covered_blocks = n0 + nn_t, vb + nv_t, base + nblk
         # v4_load_rec: all 64 lanes; the record resource covers [vb, vb + nv_t), the pointer resource nn_t + 1 entries
         jj = vb + lanes
@@ -52,7 +53,7 @@ def _replay(maps, nnodes, P, max_row_blocks, d, conn):
         rp = np.where(lanes <= nn_t, nptr[np.minimum(n0 + lanes, nnodes)], 0)
         # v4_load_visit: all 64 lanes (gathers are unconditional): own node first, then the rotated element's others
         wv = rec[:, 3].astype(np.int64) & 0xFFFFFFFF
-        a, ln = (wv >> 24) & 3, (wv >> 26) & 15
+        a, ln = (wv >> 24) & 3, (wv >> 26) & 31
         n = n0 + ln
         nd = np.concatenate([n[:, None], rec[:, :3].astype(np.int64)], axis=1)[:, :P]
         assert ((nd >= 0) & (nd < nnodes)).all(), f"tile {t}: gather outside X / rho"
@@ -77,20 +78,29 @@ def _replay(maps, nnodes, P, max_row_blocks, d, conn):
         # copy-out: the store resource ends with the segment (nblk blocks); LDS reads run over by < 32 NOUT doubles,
         # which the launcher allocates (pf_assemble.hip launch_gather)
     assert covered_nodes == nnodes and covered_vis == nvis and covered_blocks == nptr[-1]
-    # the compact 8-byte records (used whenever they exist) must decode to exactly the 16-byte ones
-    r8 = maps.get("rec8")
-    if r8 is not None:
+    # the compact records (used whenever they exist) must decode to exactly the 16-byte ones
+    r8, r12 = maps.get("rec8"), maps.get("rec12")
+    own = np.repeat(np.arange(nnodes), np.diff(n2e))  # the node of every visit
+    w16 = vr[:, 3].astype(np.int64) & 0xFFFFFFFF
+    if r8 is not None and P == 4:
         d0, d1 = r8[:, 0].astype(np.int64), r8[:, 1].astype(np.int64)
-        own = np.repeat(np.arange(nnodes), np.diff(n2e))  # the node of every visit
         sext = lambda v: ((v & 8191) ^ 4096) - 4096  # noqa: E731
         offs = [sext(d0), sext(d0 >> 13), sext((d0 >> 26) | ((d1 & 127) << 6))]
-        w16 = vr[:, 3].astype(np.int64) & 0xFFFFFFFF
         for k in range(P - 1):
             assert np.array_equal(own + offs[k], vr[:, k].astype(np.int64)), f"rec8: node {k + 1} decodes differently"
         for k in range(P):
             assert np.array_equal((d1 >> (7 + 5 * k)) & 31, (w16 >> (6 * k)) & 63)
-        assert np.array_equal((d1 >> 27) & 15, (w16 >> 26) & 15)
-    return r8 is not None
+        assert np.array_equal((d1 >> 27) & 31, (w16 >> 26) & 31)
+    if r8 is not None and P == 3:
+        d0, d1 = r8[:, 0].astype(np.int64), r8[:, 1].astype(np.int64)
+        sext = lambda v: ((v & 0xFFFF) ^ 0x8000) - 0x8000  # noqa: E731
+        assert np.array_equal(own + sext(d0), vr[:, 0].astype(np.int64)) and np.array_equal(own + sext(d0 >> 16), vr[:, 1].astype(np.int64))
+        for k in range(P):
+            assert np.array_equal((d1 >> (5 * k)) & 31, (w16 >> (6 * k)) & 63)
+        assert np.array_equal((d1 >> 15) & 31, (w16 >> 26) & 31) and np.array_equal((d1 >> 20) & 3, (w16 >> 24) & 3)
+    if r12 is not None:
+        assert P == 3 and np.array_equal(r12.view(np.int32)[:, :2], vr[:, :2]) and np.array_equal(r12[:, 2], vr[:, 3].view(np.uint32))
+    return 8 if r8 is not None else 12 if r12 is not None else 16
 
 
 def _fan_mesh(k):
@@ -138,11 +148,21 @@ def test_every_index_the_assembly_kernel_forms_is_in_range(pf, d):
         h = HipContext(X, conn, d)
         maps = h.assembly_maps()
         compact = _replay(maps, h.nnodes, h.P, h.max_row_blocks, d, conn)
-        assert compact == (h.P == 4)  # compact records are built for quads (triangles measured slower with them)
+        # compact records: 8 bytes where the numbering is banded; the hub of fan63 has rows of 64 blocks (5-bit positions
+        # do not fit) and the shuffled mesh scatters neighbours, but both stay within 16-bit offsets at these sizes
+        assert compact == (12 if name == "fan63" else 8), (name, compact)
         h.close()
     # a numbering that scatters neighbours more than 4095 node ids apart falls back to the 16-byte records
     c = pf.ProblemCreator(nnodes_x=5000, nnodes_y=3)
     conn, X, _, _ = c.create_linear_elasticity_problem()
     h = HipContext(X, conn, d)
     assert h.assembly_maps()["rec8"] is None
+    h.close()
+    # triangles with neighbours more than 32767 node ids apart: the 12-byte records
+    c = pf.ProblemCreator(nnodes_x=40000, nnodes_y=3, element_type="tri")
+    conn, X, _, _ = c.create_linear_elasticity_problem()
+    h = HipContext(X, conn, d)
+    maps = h.assembly_maps()
+    assert maps["rec8"] is None and maps["rec12"] is not None
+    assert np.array_equal(maps["rec12"].view(np.int32)[:, :2], maps["vis_rec"][:, :2])
     h.close()

@@ -26,6 +26,10 @@ cases["quad_rho"] = lambda: m.compute_jacobian(rho, out=K)
 c = pyfem.ProblemCreator(1416, 1416, element_type="tri"); conn, X, df, f = c.create_linear_elasticity_problem()
 mt = pyfem.LinearElasticity(X, conn, df, None, f, qt, bt); Kt = mt.compute_jacobian()
 cases["tri"] = lambda: mt.compute_jacobian(out=Kt)
+import bench
+conn, X, df, f = bench.arm_mesh(5)
+ma = pyfem.LinearElasticity(X, conn, df, None, f, qt, bt); Ka = ma.compute_jacobian()
+cases["arm5"] = lambda: ma.compute_jacobian(out=Ka)
 c = pyfem.ProblemCreator(2049, 2049); conn, X, x = c.create_helmhotz_problem()
 mh = pyfem.Helmholtz(0.05, X, conn, qq, bq)
 Kv, Rv = mh.hctx.assemble_helmholtz(0.05)

@@ -1,13 +1,17 @@
-"""Assembly kernel under the SQ counters for quads and triangles (for rocprofv3 --pmc ...; see profiles/r01_ablation.md):
+"""Assembly kernel under the counters for quads, split-quad triangles and the refined arm (tools/pmc_assembly.sh; r01 form:
    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS \
              SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d out -o p -- python3 tools/pmc_assembly.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyfem_gpu_testflight_amd import pyfem, _lib
-for etype, n in (("quad", 2049), ("tri", 1416)):
-    c = pyfem.ProblemCreator(n, n, element_type=etype)
-    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+import bench
+for etype, n in (("quad", 2049), ("tri", 1416), ("tri", 0)):
+    if n:
+        c = pyfem.ProblemCreator(n, n, element_type=etype)
+        conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    else:
+        conn, X, dof_fixed, force = bench.arm_mesh(5)  # refined torque arm, refinement order
     q = pyfem.QuadratureBilinear2D() if etype == "quad" else pyfem.QuadratureTriangle2D()
     b = pyfem.BasisBilinear2D(q) if etype == "quad" else pyfem.BasisTriangle2D(q)
     m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b)

@@ -17,6 +17,6 @@ for fixed in (0, 1, 0, 1):
     mt = pyfem.LinearElasticity(X, conn, df, None, f, qt, bt); Kt = mt.compute_jacobian()
     maps = mt.hctx.assembly_maps()
     td = maps["tile_desc"]
-    print(json.dumps({"PF_TILE_FIXED": fixed, "ntiles": int(td.shape[0]), "mean_nodes_per_tile": float((td[:,3] & 255).mean()), "mean_pairs": float(((td[:,3]>>8)&255).mean()),
+    print(json.dumps({"PF_TILE_FIXED": fixed, "ntiles": int(td.shape[0]), "mean_nodes_per_tile": float((td[:,3] & 63).mean()), "mean_pairs": float(((td[:,3]>>8)&255).mean()),
                       "tri_ms": round(timer(lambda: mt.compute_jacobian(out=Kt)), 4)}), flush=True)
     del mt, Kt
