@@ -147,6 +147,9 @@ def pmc_traffic(kernel_substr, fetch_scale=1.0):
     return None, None, None
 
 
+WARM_MS = 60.0  # back-to-back device work before a timed region (see Timer.__call__)
+
+
 class Timer:
     """Average device milliseconds of fn() over `reps` back-to-back calls: HIP events on torch's current stream,
     which is the stream every pf_* launch goes to (HipContext binds the ctx to it before each call)."""
@@ -154,8 +157,19 @@ class Timer:
     def __init__(self, torch):
         self.torch = torch
 
-    def __call__(self, fn, reps, warmup=2):
+    def __call__(self, fn, reps, warmup=None):
+        """warmup=None: warm until the device has had WARM_MS of back-to-back work -- after an idle period an MI355X
+        needs about 100 launches / 30 ms before a memory-bound kernel reaches its steady time (tools/launch_series.py:
+        0.35 -> 0.26 ms for the quad assembly); a 2-launch warm-up times the ramp, not the kernel."""
         torch = self.torch
+        if warmup is None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            warmup = int(min(400, max(2, WARM_MS / max(e0.elapsed_time(e1) / 3, 1e-3))))
         for _ in range(warmup):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,9 +182,10 @@ class Timer:
         return e0.elapsed_time(e1) / reps
 
 
-def arm_mesh(levels):
+def arm_mesh(levels, morton=False):
     """examples/torque_arm arm.inp (tests/golden/arm_tri.npz holds its nodes, triangles and groups) after `levels`
-    uniform red refinements, refinement order; BASELINE.json config 4 (5 levels = 2.55 M triangles)."""
+    uniform red refinements, refinement order; BASELINE.json config 4 (5 levels = 2.55 M triangles).
+    morton=True: the same mesh with its nodes renumbered along a Morton curve (meshtools.morton_node_order)."""
     from pyfem_gpu_testflight_amd import meshtools
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "arm_tri.npz"))
@@ -179,6 +194,8 @@ def arm_mesh(levels):
     load_val = g["force_vals"][0]
     for _ in range(levels):
         X, conn, sets = meshtools.red_refine_tri(X, conn, sets)
+    if morton:
+        X, conn, sets = meshtools.renumber_nodes(X, conn, meshtools.morton_node_order(X), sets)
     dof_fixed = list(np.stack([2 * sets["fixed"], 2 * sets["fixed"] + 1], axis=1).ravel())
     force = {int(n): [float(load_val[0]), float(load_val[1])] for n in sets["load"]}
     return conn, X, dof_fixed, force
@@ -205,10 +222,10 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         h = model4m.hctx
         model4m.p = 5.0
         rho = torch.rand(h.nnodes, dtype=torch.float64, device=dev) * 0.7 + 0.3
-        ms = timer(lambda: model4m.compute_jacobian(rho, out=K4m), 20)
+        ms = timer(lambda: model4m.compute_jacobian(rho, out=K4m), 100)
         legs["rho"] = {"workload": "2048x2048 quads, nodal RAMP density p=5 (k_assemble_v4<4,Elasticity<4,true>,..>)",
                        "elements_per_s": h.nelems / (ms * 1e-3),
-                       **roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, with_rho=True), ms, ceil.get("mix"))}
+                       **roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, with_rho=True), ms, ceil.get("mix_best"))}
         model4m.p = 0.0
         model4m.compute_jacobian(out=K4m)
 
@@ -217,9 +234,9 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         conn, X, x = c.create_helmhotz_problem()
         m = pyfem.Helmholtz(0.05, X, conn, qq, bq)
         h = m.hctx
-        ms_asm = h.time_kernel(_lib.PF_K_ASSEMBLE_HELMHOLTZ, 20, out0=m.K.vals, E=0.05)  # K only (R = None inside)
         Kv, Rv = h.assemble_helmholtz(0.05)
-        ms_asm2 = timer(lambda: h._call("pf_assemble_helmholtz2d", 0.05, pyfem_ptr(Kv), pyfem_ptr(Rv)), 20)
+        ms_asm2 = timer(lambda: h._call("pf_assemble_helmholtz2d", 0.05, pyfem_ptr(Kv), pyfem_ptr(Rv)), 100)
+        ms_asm = h.time_kernel(_lib.PF_K_ASSEMBLE_HELMHOLTZ, 100, out0=m.K.vals, E=0.05)  # K only (R = None inside)
         xd = h.to_device(x, torch.float64)
         y = torch.empty_like(xd)
         ms_spmv = h.time_kernel(_lib.PF_K_SPMV, 50, in0=m.K.vals, in1=xd, out0=y)
@@ -236,30 +253,33 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         sp["layout_bytes"] = lay
         sp["frac_layout"] = lay / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS
         legs["c3"] = {"workload": "Helmholtz filter r0=0.05 on 2048x2048 quads (4198401 rows, d=1)",
-                      "assemble_K": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz), ms_asm, ceil.get("mix")),
-                      "assemble_K_and_R": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, nmat=2), ms_asm2, ceil.get("mix")),
+                      "assemble_K": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz), ms_asm, ceil.get("mix_best")),
+                      "assemble_K_and_R": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, nmat=2), ms_asm2, ceil.get("mix_best")),
                       "spmv": sp, "apply_s": t_apply, "apply_iters": m.last_iters, "apply_true_relres": relres}
         del m, Kv, Rv
 
     if "c4" in which:  # examples/torque_arm/arm.py:19-48 scaled to BASELINE's 4M triangles
         tri = {}
-        for tag, mesh in (("split1415", None), ("arm5", "arm")):
+        for tag, mesh in (("split1415", None), ("arm5", "arm"), ("arm5_morton", "arm_morton")):
             if mesh is None:
                 c = pyfem.ProblemCreator(1416, 1416, element_type="tri")
                 conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
                 desc = "1415x1415 split quads (4.0 M triangles), structured order"
-            else:
+            elif mesh == "arm":
                 conn, X, dof_fixed, force = arm_mesh(5)
                 desc = "arm.inp red-refined 5 times (2.55 M triangles, detJ < 0), refinement order"
+            else:
+                conn, X, dof_fixed, force = arm_mesh(5, morton=True)
+                desc = "the same mesh, nodes renumbered along a Morton curve (meshtools.morton_node_order)"
             m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, qt, bt)
             h = m.hctx
             K = m.compute_jacobian()
-            ms = timer(lambda: m.compute_jacobian(out=K), 20)
+            ms = timer(lambda: m.compute_jacobian(out=K), 100)
             xv = torch.rand(h.nrows, dtype=torch.float64, device=dev)
             yv = torch.empty_like(xv)
             ms_spmv = h.time_kernel(_lib.PF_K_SPMV, 30, in0=K.vals, in1=xv, out0=yv)
             tri[tag] = {"workload": desc, "nelems": h.nelems, "elements_per_s": h.nelems / (ms * 1e-3),
-                        "assemble": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, P=3), ms, ceil.get("mix")),
+                        "assemble": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, P=3), ms, ceil.get("mix_best")),
                         "spmv": roof(algorithmic_bytes_spmv(h.nnz, h.nrows), ms_spmv, ceil.get("read"))}
             if mesh == "arm":
                 rhs = h.to_device(m.compute_rhs(), torch.float64)
@@ -308,13 +328,15 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
             return t, comp
 
         iteration()  # builds the graph-only AMG hierarchies once per mesh and loads every kernel
+        iteration()  # and brings the device to its steady clocks (see Timer)
         t, comp = iteration()
         legs["c5"] = {"workload": "one topology-optimisation inner iteration, 2048x1024 quads, nodal density, RAMP p=5, "
-                                  "AMG-PCG rtol 1e-8 (second iteration: hierarchies cached)",
+                                  "AMG-PCG rtol 1e-8 (third iteration: hierarchies cached, device warm)",
                       "filter_apply_s": t[1] - t[0], "filter_iters": filtr.last_iters, "assemble_bc_s": t[2] - t[1],
                       "elasticity_solve_s": t[3] - t[2], "elasticity_cg_iters": asm.last_iters, "compliance": comp,
                       "sensitivity_and_three_filter_gradients_s": t[4] - t[3], "iteration_total_s": t[4] - t[0]}
     return legs
+
 
 
 def pyfem_ptr(t):
@@ -326,8 +348,10 @@ def pyfem_ptr(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200 per GPU)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps first (default 150 per GPU: ~30 ms of launches bring the device to its steady "
+                         "clocks, see launch_ramp in the output)")
     ap.add_argument("--nx", type=int, default=2048, help="quads per side (2048 -> the 4M-quad metric mesh)")
     ap.add_argument("--cg-iters", type=int, default=200)
     ap.add_argument("--spmv-reps", type=int, default=50)
@@ -342,6 +366,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # strong scaling: a step is 1/N of the single-GPU work per rank, so the defaults grow with N to keep the warm-up
+    # and the timed region at the same ~40 / 50 ms of device time
+    if args.steps is None:
+        args.steps = 200 * world
+    if args.warmup is None:
+        args.warmup = 150 * world
     # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): PF_BENCH_BACKEND=gloo with
     # PF_BENCH_DEVICE=0 runs the N>1 code path with every rank on the same GPU
     if "PF_BENCH_DEVICE" in os.environ:
@@ -397,18 +427,34 @@ def main():
     ceil = {}
     if world == 1:
         nb = 8 * h.nnz  # the size of the K value array
+        h.hbm_probe(_lib.PF_HBM_MIX, nb, reps=150)  # untimed: bring the device to its steady state first
         for name, mode in (("write", _lib.PF_HBM_FILL), ("read", _lib.PF_HBM_READ), ("mix", _lib.PF_HBM_MIX)):
-            ceil[name] = h.hbm_probe(mode, nb, reps=20)
-            ceil[name + "_nt"] = h.hbm_probe(mode, nb, reps=20, nt=True)
+            ceil[name] = h.hbm_probe(mode, nb, reps=60)
+            ceil[name + "_nt"] = h.hbm_probe(mode, nb, reps=60, nt=1)
+        ceil["mix_ntstore"] = h.hbm_probe(_lib.PF_HBM_MIX, nb, reps=60, nt=2)  # the assembly's own policy
+        ceil["mix_best"] = max(ceil["mix"], ceil["mix_nt"], ceil["mix_ntstore"])
         ceil["bytes_per_pass"] = nb
         ceil["note"] = ("pf_hbm_probe: every wave streams whole 64 KiB runs, 16 B per lane (the friendliest walk; the "
                         "assembly writes 4.6 KB tile segments, which alone reach ~5.5 TB/s: tools/micro/fillpat.hip); "
-                        "mix = 1/4 read + 3/4 written (the assembly's byte mix); GB/s")
+                        "mix = 1/4 read + 3/4 written (the assembly's byte mix), _nt = non-temporal loads and stores, "
+                        "_ntstore = non-temporal stores only; GB/s.  A plain streaming kernel measured in this process, "
+                        "for box-to-box normalisation -- not an upper bound: the assembly kernels (non-temporal stores of "
+                        "whole tile segments, gathers mostly served by L2) move their bytes faster than it")
 
     # ---- assembly: W warm-up + exactly K timed steps ------------------------------------------
     K = model.compute_jacobian()
-    for _ in range(args.warmup):
+    ew = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ew[0].record()
+    for i in range(args.warmup):
+        if i == min(20, args.warmup):
+            ew[1].record()
         model.compute_jacobian(out=K)
+    ew[2].record()
+    torch.cuda.synchronize()
+    n20 = min(20, args.warmup)
+    ramp = {"first_launches": n20, "first_ms_per_launch": ew[0].elapsed_time(ew[1]) / max(n20, 1) if args.warmup > 20 else None,
+            "rest_of_warmup_ms_per_launch": ew[1].elapsed_time(ew[2]) / max(args.warmup - n20, 1) if args.warmup > 20 else None,
+            "note": "the warm-up steps, timed: the same kernel runs slower until the device has had ~100 launches of work"}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -520,13 +566,13 @@ def main():
                                f"{nelems_total} elements, ndof={2 * (nx + 1) ** 2}, element-block partition over "
                                f"{world} GPU(s)", "nelems": nelems_total, "cg_iters_timed": int(iters)},
         "cg_iter_per_sec": cg_rate, **cg_extra,
-        "roofline": {"bound": "hbm", "kernel": "k_assemble_v4<4,Elasticity<4,false>,false,5,true>", "achieved": asm_gbs,
+        "roofline": {"bound": "hbm", "kernel": "k_assemble_v4<4,Elasticity<4,false>,false,5,8>", "achieved": asm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
                      "traffic_source": None if src_asm is None else f"replay of {src_asm} (committed rocprofv3 --pmc "
                                                                    "passes of this command; not measured in this run)",
                      "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms,
-                     "frac_of_measured": (asm_gbs / ceil["mix"]) if ceil else None,
-                     "measured_ceiling": "hbm_ceiling.mix" if ceil else None},
+                     "frac_of_measured": (asm_gbs / ceil["mix_best"]) if ceil else None,
+                     "measured_ceiling": "hbm_ceiling.mix_best" if ceil else None},
         "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true,double>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
                           "traffic_source": None if src_spmv is None else f"replay of {src_spmv}",
@@ -537,7 +583,7 @@ def main():
                           "note": "frac counts CSR's 12 B per scalar nonzero (SURVEY 8d); frac_layout counts what the "
                                   "2x2-block layout with 16-bit column offsets really moves (8.5 B per nonzero + "
                                   "vectors) and is the HBM utilisation"},
-        "setup_s": t_setup,
+        "setup_s": t_setup, "launch_ramp": ramp,
     }
     if ceil:
         out["hbm_ceiling"] = ceil

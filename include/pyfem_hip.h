@@ -382,7 +382,7 @@ int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const do
  *      ms_host = average milliseconds per pass (HIP events).  No counterpart in the reference.
  *      mode PF_HBM_FILL: write only;  PF_HBM_READ: read only;  PF_HBM_MIX: one quarter read, three quarters
  *      written (the byte mix of the quad assembly: K written once, records + coordinates read).
- *      nt != 0: non-temporal loads / stores. */
+ *      nt: 0 plain accesses, 1 non-temporal loads and stores, 2 non-temporal stores only (what the assembly does). */
 enum { PF_HBM_FILL = 0, PF_HBM_READ = 1, PF_HBM_MIX = 2 };
 int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int reps, double* ms_host);
 

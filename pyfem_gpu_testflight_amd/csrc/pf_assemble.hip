@@ -346,6 +346,12 @@ typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int pf_u32x3 __attribute__((ext_vector_type(3)));
 typedef double pf_f64x2 __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t pf_rsrc;
+#ifndef PF_AB_REC_AUX
+#define PF_AB_REC_AUX 0  // cache-policy bits of the visit-record loads (read once per launch)
+#endif
+#ifndef PF_AB_STORE_AUX
+#define PF_AB_STORE_AUX 2  // cache-policy bits of the copy-out stores: nt.  (tools/build_variant.sh A/B: 0 none, 1 sc0, 2 nt, 16 sc1)
+#endif
 
 // raw buffer (stride 0): offsets and num_records in bytes; out-of-range loads return 0, stores are dropped
 __device__ __forceinline__ pf_rsrc make_rsrc(const void* base, uint32_t bytes) {
@@ -433,13 +439,13 @@ __device__ __forceinline__ V4Rec v4_load_rec(const V4Tile& T, int lane, const in
   const pf_rsrc rr = make_rsrc(reinterpret_cast<const unsigned char*>(vis_rec) + (int64_t)T.vb * REC, (uint32_t)T.nv * (uint32_t)REC);
   const pf_rsrc rn = make_rsrc(nptr + T.n0, (uint32_t)(T.nn + 1) * 4u);
   if constexpr (REC == 8) {  // rec.x / rec.y hold the two dwords
-    const pf_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, 0, 0);
+    const pf_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, lane * 8, 0, PF_AB_REC_AUX);
     B.rec = make_int4((int)r.x, (int)r.y, 0, 0);
   } else if constexpr (REC == 12) {
-    const pf_u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rr, lane * 12, 0, 0);
+    const pf_u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rr, lane * 12, 0, PF_AB_REC_AUX);
     B.rec = make_int4((int)r.x, (int)r.y, 0, (int)r.z);
   } else {
-    const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, 0);
+    const pf_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, 0, PF_AB_REC_AUX);
     B.rec = make_int4((int)r.x, (int)r.y, (int)r.z, (int)r.w);  // triangles: .z is unused -- see v4_load_visit
   }
   B.rp = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(rn, lane * 4, 0, 0);
@@ -645,12 +651,12 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
       }
     } else {
       for (int u = 0; 32 * u < nblk; ++u) {
         const pf_f64x2 val = {a0[32 * u], a1[32 * u]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, val), ro, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
       }
     }
   } else {
@@ -667,19 +673,19 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #pragma unroll
       for (int u = 0; u < NOUT; ++u) {
         const pf_f64x2 v0 = {a0[128 * u], a0[128 * u + 1]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
         if constexpr (V == 2) {
           const pf_f64x2 v1 = {a0[plane + 128 * u], a0[plane + 128 * u + 1]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
         }
       }
     } else {
       for (int u = 0; 128 * u < nblk; ++u) {
         const pf_f64x2 v0 = {a0[128 * u], a0[128 * u + 1]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v0), r0, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
         if constexpr (V == 2) {
           const pf_f64x2 v1 = {a0[plane + 128 * u], a0[plane + 128 * u + 1]};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pf_u32x4, v1), r1, lane * 16 + 1024 * u, 0, PF_AB_STORE_AUX);
         }
       }
     }
@@ -687,16 +693,25 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
     // lane 0's offset nblk * 8 is past it too)
     const uint32_t toff = (nblk & 1) ? (uint32_t)(nblk - 1) * 8u + (uint32_t)lane * 0x100000u : all_bytes;
     const int32_t ti = (nblk & 1) ? nblk - 1 : 0;
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[ti]), t0, (int)toff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[ti]), t0, (int)toff, 0, PF_AB_STORE_AUX);
     if constexpr (V == 2)
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[plane + ti]), t1, (int)toff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pf_u32x2, img[plane + ti]), t1, (int)toff, 0, PF_AB_STORE_AUX);
   }
 }
 
 // COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it took 0.191 ms back
 // to 0.156 ms on 4 M elements, and its cheaper form (v4_seg_step) to 0.14 ms; quads are HBM-bound and measured the same
 // with and without it (profiles/r02_assembly_ab.md)
-template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3)>
+#ifndef PF_AB_TILE_ORDER
+#define PF_AB_TILE_ORDER (P == 3 ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
+#endif
+#ifndef PF_AB_WPC_CAP
+#define PF_AB_WPC_CAP 32   // persistent waves per CU: min(resident, cap)
+#endif
+#ifndef PF_AB_QUAD_COMB
+#define PF_AB_QUAD_COMB 1  // the diagonal pre-reduction for the 2x2-block quad kernels too (tools/build_variant.sh A/B: 0)
+#endif
+template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4))>
 __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
@@ -993,7 +1008,7 @@ static auto v4_variant(int per_lane, int& nout) -> decltype(&k_assemble_v4<P, Ph
 }
 
 // Launch of the fused assembly kernel.  Experiment knobs (builds with -DPF_EXPERIMENTS only; the product library never
-// reads them): PF_GATHER_WAVES_PER_CU, PF_TILE_ORDER=c|x.
+// reads them): PF_GATHER_WAVES_PER_CU, PF_TILE_ORDER=c|r (default: XCD-aware round-robin).
 template <int P, class Phys, bool RHO>
 static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, double* out1) {
   if (ctx->npt == 0 || !ctx->vis_rec || !ctx->tile_desc)
@@ -1050,7 +1065,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     int q = 0;
     PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(k4), 64, lds4));
     oc.lds = lds4;
-    oc.wpc = std::max(1, std::min(q, 32));
+    oc.wpc = std::max(1, std::min(q, PF_AB_WPC_CAP));
   }
   int wpc = oc.wpc;
   const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
@@ -1059,7 +1074,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
   const unsigned grid = (unsigned)std::min<int64_t>(nt, (int64_t)ncu * wpc);
   // tile walk: 0 contiguous run per wave, 1 round-robin over the grid, 2 XCD-aware round-robin (grid % 8 == 0)
   const char* to = pf_exp_env("PF_TILE_ORDER");
-  int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'x') ? 2 : 1;
+  int32_t tile_order = (to && to[0] == 'c') ? 0 : (to && to[0] == 'r') ? 1 : PF_AB_TILE_ORDER;
   if (tile_order == 2 && (grid & 7)) tile_order = 1;
   hipLaunchKernelGGL(k4, dim3(grid), dim3(64), lds4, ctx->stream, ctx->nnodes, ctx->ntiles, (int32_t)plane,
                      ctx->X, ctx->nptr, reinterpret_cast<const int4*>(ctx->tile_desc),

@@ -1169,14 +1169,16 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
 // a pure read and the assembly's 1:3 read:write mix, with the access shape the kernels of this library use
 // (persistent waves, 16 bytes per lane, 1 KiB per wave access).
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool NT>
-__global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, const double2* __restrict__ b, int64_t n2,
+typedef double pf_probe_f64x2 __attribute__((ext_vector_type(2)));
+// NT: 0 plain accesses, 1 non-temporal loads and stores, 2 non-temporal stores only (what the assembly kernels do)
+template <int MODE, int NT>
+__global__ __launch_bounds__(256) void k_hbm_probe(pf_probe_f64x2* __restrict__ a, const pf_probe_f64x2* __restrict__ b, int64_t n2,
                                                    double* __restrict__ sink) {
   // Every WAVE streams whole 64 KiB chunks (dealt round-robin to the waves), 16 bytes per lane and access, four accesses
   // in flight: the walk that gets the most out of the memory system (tools/micro/fillpat.hip, r02: a chip-wide store
   // stream reaches 4.3 TB/s in 1 KiB pieces scattered by a grid-stride loop, 5.5 TB/s in the 4.6 KB pieces of the quad
   // assembly's tile segments, 6.2 TB/s in 64 KiB runs per wave; hipMemset 6.5).
-  constexpr int64_t CH2 = 4096;  // double2 per chunk = 64 KiB
+  constexpr int64_t CH2 = 4096;  // 16-byte pieces per chunk = 64 KiB
   constexpr int U = 4;
   const int lane = threadIdx.x & 63;
   const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -1185,12 +1187,12 @@ __global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, cons
   for (int64_t c0 = wave * CH2; c0 < n2; c0 += nwaves * CH2) {
     const int64_t c1 = min(n2, c0 + CH2);
     for (int64_t i0 = c0 + lane; i0 < c1; i0 += 64 * U) {
-      double2 v[U];
+      pf_probe_f64x2 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t i = min(i0 + 64 * u, c1 - 1);
-        if constexpr (MODE == PF_HBM_FILL) v[u] = make_double2((double)u, 1.0);
-        else if constexpr (NT) { v[u].x = __builtin_nontemporal_load(&b[i].x); v[u].y = __builtin_nontemporal_load(&b[i].y); }
+        if constexpr (MODE == PF_HBM_FILL) v[u] = pf_probe_f64x2{(double)u, 1.0};
+        else if constexpr (NT == 1) v[u] = __builtin_nontemporal_load(b + i);
         else v[u] = b[i];
       }
 #pragma unroll
@@ -1203,9 +1205,9 @@ __global__ __launch_bounds__(256) void k_hbm_probe(double2* __restrict__ a, cons
           constexpr int NW = MODE == PF_HBM_MIX ? 3 : 1;
 #pragma unroll
           for (int k = 0; k < NW; ++k) {
-            const double2 w = make_double2(v[u].x + k, v[u].y - k);
-            double2* dst = a + i + k * n2;
-            if constexpr (NT) { __builtin_nontemporal_store(w.x, &dst->x); __builtin_nontemporal_store(w.y, &dst->y); }
+            const pf_probe_f64x2 w = {v[u].x + k, v[u].y - k};
+            pf_probe_f64x2* dst = a + i + k * n2;
+            if constexpr (NT != 0) __builtin_nontemporal_store(w, dst);
             else *dst = w;
           }
         }
@@ -1221,7 +1223,7 @@ extern "C" int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int r
   PF_HIP(hipSetDevice(ctx->device));
   // FILL: a = nbytes; READ: b = nbytes; MIX: b = nbytes/4 read, a = 3 nbytes/4 written
   const int64_t n2 = (mode == PF_HBM_MIX ? nbytes / 4 : nbytes) / 16;
-  double2 *a = nullptr, *b = nullptr;
+  pf_probe_f64x2 *a = nullptr, *b = nullptr;
   if (mode != PF_HBM_READ) PF_HIP(hipMalloc(&a, (size_t)n2 * 16 * (mode == PF_HBM_MIX ? 3 : 1)));
   if (mode != PF_HBM_FILL) {
     PF_HIP(hipMalloc(&b, (size_t)n2 * 16));
@@ -1234,8 +1236,9 @@ extern "C" int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int r
   auto launch = [&]() {
 #define PF_PROBE(M_)                                                                                            \
     if (mode == M_) {                                                                                           \
-      if (nt) k_hbm_probe<M_, true><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                        \
-      else k_hbm_probe<M_, false><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                          \
+      if (nt == 1) k_hbm_probe<M_, 1><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                      \
+      else if (nt == 2) k_hbm_probe<M_, 2><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                 \
+      else k_hbm_probe<M_, 0><<<grid, 256, 0, ctx->stream>>>(a, b, n2, ctx->scal);                              \
     }
     PF_PROBE(PF_HBM_FILL) PF_PROBE(PF_HBM_READ) PF_PROBE(PF_HBM_MIX)
 #undef PF_PROBE

@@ -377,10 +377,11 @@ class HipContext:
         return [(nodes[i], dpn[i], om[i]) for i in range(nl.value)]
 
     def hbm_probe(self, mode, nbytes, reps=20, nt=False):
-        """GB/s this device sustains now for a pure write / pure read / 1:3 read:write mix of `nbytes` (pf_hbm_probe)."""
+        """GB/s this device sustains now for a pure write / pure read / 1:3 read:write mix of `nbytes` (pf_hbm_probe);
+        nt: 0 plain accesses, 1 non-temporal loads and stores, 2 non-temporal stores only."""
         ms = _lib._f64()
         self._sync_stream()
-        self._call("pf_hbm_probe", int(mode), int(bool(nt)), _lib._i64(int(nbytes)), int(reps), C.byref(ms))
+        self._call("pf_hbm_probe", int(mode), int(nt), _lib._i64(int(nbytes)), int(reps), C.byref(ms))
         return nbytes / (ms.value * 1e-3) / 1e9
 
     def time_kernel(self, which, reps, in0=None, in1=None, out0=None, E=0.0, nu=0.0, p=0.0):

@@ -7,8 +7,10 @@ import torch
 from pyfem_gpu_testflight_amd import pyfem
 tag = sys.argv[1] if len(sys.argv) > 1 else os.path.basename(os.environ.get("PF_LIB_PATH", "product"))
 
-def timer(fn, reps=20):
-    for _ in range(3): fn()
+def timer(fn, reps=100, warm=150):
+    # the device needs ~100 back-to-back launches (30 ms) after an idle period to reach its steady clocks
+    # (tools/launch_series.py: 0.346 -> 0.262 ms for the quad kernel): warm up that long, then time
+    for _ in range(warm): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(reps): fn()

@@ -3,7 +3,7 @@ import csv, glob, os, sys, collections
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for sub in "abc":
+for sub in "abcdefg":
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
