@@ -25,7 +25,6 @@ and "hbm_ceiling": what THIS device sustains in THIS process for a pure write, a
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
@@ -118,19 +117,32 @@ def cpu_baseline(n=1024, reps=3, cg_iters=40):
 
 
 def smi_snapshot():
-    """Clocks / power / temperature as rocm-smi reports them (outside every timed region); {} when unreadable."""
+    """Clocks / power / temperature of the first GPU from sysfs (outside every timed region); {} when unreadable.
+    Plain file reads: starting rocm-smi from a process that has initialised the GPU is an exec the GPU boxes refuse."""
+    import glob
+
+    keep = {}
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True,
-                             text=True, timeout=20).stdout
-        card = next(iter(json.loads(out).values()))
-        keep = {}
-        for k, v in card.items():
-            kl = k.lower()
-            if any(s in kl for s in ("sclk", "mclk", "fclk", "power", "junction", "edge")) and len(keep) < 12:
-                keep[k] = v
-        return keep
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if not os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                continue
+            for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+                try:
+                    cur = [ln.split(":")[1].strip(" *\n") for ln in open(os.path.join(dev, name)) if ln.rstrip().endswith("*")]
+                    keep[name] = cur[0] if cur else None
+                except OSError:
+                    pass
+            for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                for name, unit, scale in (("power1_average", "W", 1e-6), ("power1_input", "W", 1e-6), ("temp1_input", "C", 1e-3),
+                                          ("temp2_input", "C", 1e-3)):
+                    try:
+                        keep[f"{name}_{unit}"] = round(float(open(os.path.join(hw, name)).read()) * scale, 1)
+                    except (OSError, ValueError):
+                        pass
+            break
     except Exception:
         return {}
+    return keep
 
 
 def pmc_traffic(kernel_substr, fetch_scale=1.0):

@@ -101,6 +101,9 @@ __device__ __forceinline__ T spmv_ld(const T* p) {
   else return *p;
 }
 #define PF_SPMV_LD(p) spmv_ld<D == 1>(p)
+#ifndef PF_AB_SPMV_NT2
+#define PF_AB_SPMV_NT2 0  // A/B: 16-byte non-temporal loads of the 2x2 value blocks
+#endif
 template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
@@ -157,11 +160,16 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             if constexpr (sizeof(VT) == 8) {
-              const VT* vp = vals + 4 * (int64_t)g[u];
-              k0[u] = make_double2(PF_SPMV_LD(vp), PF_SPMV_LD(vp + 1));
-              k1[u] = make_double2(PF_SPMV_LD(vp + 2), PF_SPMV_LD(vp + 3));
+              typedef double f64x2 __attribute__((ext_vector_type(2)));
+              const f64x2* vp = reinterpret_cast<const f64x2*>(vals + 4 * (int64_t)g[u]);
+              const f64x2 a0 = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : vp[0];
+              const f64x2 a1 = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp + 1) : vp[1];
+              k0[u] = make_double2(a0.x, a0.y);
+              k1[u] = make_double2(a1.x, a1.y);
             } else {  // fp32 copy of the operator (the AMG cycle's smoother): one 16-byte load per block
-              const float4 f = *reinterpret_cast<const float4*>(vals + 4 * (int64_t)g[u]);
+              typedef float f32x4 __attribute__((ext_vector_type(4)));
+              const f32x4* vp = reinterpret_cast<const f32x4*>(vals + 4 * (int64_t)g[u]);
+              const f32x4 f = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : vp[0];
               k0[u] = make_double2((double)f.x, (double)f.y);
               k1[u] = make_double2((double)f.z, (double)f.w);
             }
