@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=200)
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dist-amg", action="store_true", help="N > 1: skip the partitioned AMG-PCG solve")
     ap.add_argument("--legs", default="rho,c3,c4,c5", help="comma list of secondary legs at N=1 ('' = none)")
     args = ap.parse_args()
 
@@ -551,6 +552,29 @@ def main():
             cg_extra["cg_first_transport_error"] = cg_err
     cg_rate = iters / t_cg if t_cg == t_cg else None
 
+    # ---- N > 1: AMG-PCG over the partition (replicated hierarchy, distributed finest level) to rtol 1e-8 on
+    # the metric mesh -- the iteration count must be the single-GPU one.  Only over the peer-store transport the CG leg
+    # has just proven on this node: every wait of that path is bounded by the halo's own timeout, so a failure comes
+    # back as an exception on every rank instead of a hang.
+    amg_extra = {}
+    if world > 1 and not args.no_dist_amg and cg_extra.get("cg_transport") == "peer" and pm.iface.transport == "peer":
+        dt, ok, err = float("nan"), True, None
+        try:
+            pm.solve(rtol=1e-8, precond="amg")  # builds the hierarchies, loads the kernels
+            barrier()
+            t0 = time.perf_counter()
+            pm.solve(rtol=1e-8, precond="amg")
+            barrier()
+            dt = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            ok, err = False, f"{type(e).__name__}: {e}"[:300]
+        if all_ok(ok):
+            amg_extra = {"dist_amg_pcg": {"solve_s": max_over_ranks(dt), "iters": int(pm.last_iters), "rtol": 1e-8,
+                                          "note": "assembly + BCs + numeric AMG setup + PCG; iterations equal the "
+                                                  "single-GPU count by construction (same hierarchy)"}}
+        else:
+            amg_extra = {"dist_amg_pcg": {"error": err or "another rank failed"}}
+
     # HBM traffic per launch: replayed from the committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE
     # passes of this command), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE of a wide coalesced stream is
     # tallied at half its bytes (128-byte requests counted as 64) -- the whole SpMV stream, and of the assembly's
@@ -577,7 +601,7 @@ def main():
         "config": {"workload": f"{nx}x{nx}-quad plane-stress mesh (ProblemCreator), E=10 nu=0.3 rho=1, "
                                f"{nelems_total} elements, ndof={2 * (nx + 1) ** 2}, element-block partition over "
                                f"{world} GPU(s)", "nelems": nelems_total, "cg_iters_timed": int(iters)},
-        "cg_iter_per_sec": cg_rate, **cg_extra,
+        "cg_iter_per_sec": cg_rate, **cg_extra, **amg_extra,
         "roofline": {"bound": "hbm", "kernel": "k_assemble_v4<4,Elasticity<4,false>,false,5,8>", "achieved": asm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_gbs / HBM_PEAK_GBS, "traffic": traffic_asm,
                      "traffic_source": None if src_asm is None else f"replay of {src_asm} (committed rocprofv3 --pmc "
