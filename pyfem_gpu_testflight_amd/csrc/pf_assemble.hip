@@ -702,6 +702,12 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 // COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it took 0.191 ms back
 // to 0.156 ms on 4 M elements, and its cheaper form (v4_seg_step) to 0.14 ms; quads are HBM-bound and measured the same
 // with and without it (profiles/r02_assembly_ab.md)
+#ifndef PF_AB_RHO_NOCOMB
+#define PF_AB_RHO_NOCOMB 0
+#endif
+#ifndef PF_AB_V4_ATTR
+#define PF_AB_V4_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): A/B builds
+#endif
 #ifndef PF_AB_TILE_ORDER
 #define PF_AB_TILE_ORDER (P == 3 ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
 #endif
@@ -711,8 +717,8 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #ifndef PF_AB_QUAD_COMB
 #define PF_AB_QUAD_COMB 1  // the diagonal pre-reduction for the 2x2-block quad kernels too (tools/build_variant.sh A/B: 0)
 #endif
-template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4))>
-__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
+template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4 && !(PF_AB_RHO_NOCOMB && RHO)))>
+__global__ __launch_bounds__(64) PF_AB_V4_ATTR void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int4* __restrict__ tile_desc,
