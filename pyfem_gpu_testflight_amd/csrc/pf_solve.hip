@@ -92,17 +92,22 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 //   VT = float reads an fp32 copy of the values (arithmetic stays fp64): the smoother sweeps of the AMG cycle, whose
 //   operator only has to be a fixed symmetric one.
 // ------------------------------------------------------------------------------------------
-// The value stream is read once per product while x is gathered again and again: for scalar matrices (d = 1) loading
-// the values NON-TEMPORALLY leaves the cache to x -- 0.0968 -> 0.0822 ms on the Helmholtz 2048^2 matrix (r02 A/B,
-// tools/spmv_ab.py); for 2x2 blocks the same change costs 11 % (0.261 -> 0.291 ms), so they keep plain loads.
+// The value stream is read once per product while x is gathered again and again: loading the values NON-TEMPORALLY
+// leaves the cache to x.  Scalar matrices (d = 1): 0.0968 -> 0.0822 ms on the Helmholtz 2048^2 matrix.  2x2 blocks: with
+// a lane per 32-byte block each of its two 16-byte loads touches HALF of 16 lines and the cache joins them, so
+// non-temporal loads cost 11 % (0.261 -> 0.291 ms); with one block ROW per lane and access every instruction covers
+// whole lines and they gain 10 % (0.242 -> 0.218 ms = 6.6 TB/s of the bytes the layout moves; r02, tools/spmv_ab.py).
 template <bool NT, typename T>
 __device__ __forceinline__ T spmv_ld(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
 }
 #define PF_SPMV_LD(p) spmv_ld<D == 1>(p)
+#ifndef PF_AB_SPMV_HALF
+#define PF_AB_SPMV_HALF 1  // one 16-byte block row per lane and access in the fp64 2x2 product (0: a lane per block)
+#endif
 #ifndef PF_AB_SPMV_NT2
-#define PF_AB_SPMV_NT2 0  // A/B: 16-byte non-temporal loads of the 2x2 value blocks
+#define PF_AB_SPMV_NT2 1  // non-temporal loads of the fp64 2x2 value stream (only pays with whole-line accesses: PF_AB_SPMV_HALF)
 #endif
 template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
@@ -136,6 +141,36 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
       // phase A: stream blocks [c0, c1), U per lane in flight
+      if constexpr (D == 2 && sizeof(VT) == 8 && PF_AB_SPMV_HALF) {
+        // fp64 2x2 blocks, one block ROW (16 bytes) per lane and access: every load instruction covers 1 KiB of whole
+        // lines (a lane per 32-byte block makes each of its two 16-byte loads touch half of 16 lines and leaves the
+        // joining to the cache), which is also what lets the value stream go non-temporal.
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        constexpr int UH = 2 * U;
+        double* prodh = reinterpret_cast<double*>(prod);
+        const int32_t h1 = 2 * c1;
+        for (int32_t hb0 = 2 * c0 + lane; hb0 < h1; hb0 += 64 * UH) {
+          int32_t hb[UH], m[UH];
+#pragma unroll
+          for (int u = 0; u < UH; ++u) {
+            hb[u] = min(hb0 + 64 * u, h1 - 1);  // clamped: loads stay in range, result discarded
+            if constexpr (IDX16) m[u] = (int32_t)(tile * TILE) + reinterpret_cast<const int16_t*>(nidx)[hb[u] >> 1];
+            else m[u] = nidx[hb[u] >> 1];
+          }
+          f64x2 kv[UH];
+          double2 xv[UH];
+#pragma unroll
+          for (int u = 0; u < UH; ++u) {
+            const f64x2* vp = reinterpret_cast<const f64x2*>(vals) + hb[u];
+            kv[u] = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : *vp;
+          }
+#pragma unroll
+          for (int u = 0; u < UH; ++u) xv[u] = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m[u]);
+#pragma unroll
+          for (int u = 0; u < UH; ++u)
+            if (hb0 + 64 * u < h1) prodh[hb[u] - 2 * c0] = kv[u].x * xv[u].x + kv[u].y * xv[u].y;
+        }
+      } else
       for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
         int32_t g[U], m[U];
 #pragma unroll
@@ -169,7 +204,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
             } else {  // fp32 copy of the operator (the AMG cycle's smoother): one 16-byte load per block
               typedef float f32x4 __attribute__((ext_vector_type(4)));
               const f32x4* vp = reinterpret_cast<const f32x4*>(vals + 4 * (int64_t)g[u]);
-              const f32x4 f = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : vp[0];
+              const f32x4 f = vp[0];
               k0[u] = make_double2((double)f.x, (double)f.y);
               k1[u] = make_double2((double)f.z, (double)f.w);
             }

@@ -23,4 +23,6 @@ for rep in range(3):
     out["cg_it_per_s"] = round(200 / (time.perf_counter() - t0), 1)
     torch.cuda.synchronize(); t0 = time.perf_counter(); rho = mh.apply(xh); torch.cuda.synchronize()
     out["helmholtz_apply_ms"] = round(1e3 * (time.perf_counter() - t0), 3); out["helmholtz_iters"] = mh.last_iters
+    torch.cuda.synchronize(); t0 = time.perf_counter(); _, it, _ = h.cg(Kbc.vals, b, rtol=1e-8, precond=_lib.PF_PRECOND_AMG); torch.cuda.synchronize()
+    out["amg_pcg_2048sq_ms"] = round(1e3 * (time.perf_counter() - t0), 2); out["amg_iters"] = it
     print(json.dumps(out), flush=True)
