@@ -754,6 +754,49 @@ def test_high_valence_hub_matches_oracle(pf, orc, k):
     assert relmax(u, uo) < U_TOL
 
 
+def _quad_hub_mesh(k):
+    """Every triangle of the closed fan split into three quads (centroid + edge midpoints): the hub keeps valence k,
+    the centroids have valence 3, the spoke midpoints 4 -- an unstructured all-quad mesh."""
+    Xt, tri = _fan_mesh(k)
+    nodes = [tuple(x) for x in Xt]
+    index = {}
+
+    def node(pt):
+        key = (round(pt[0], 12), round(pt[1], 12))
+        if key not in index:
+            index[key] = len(nodes)
+            nodes.append((pt[0], pt[1]))
+        return index[key]
+
+    for i, x in enumerate(Xt):
+        index[(round(x[0], 12), round(x[1], 12))] = i
+    quads = []
+    for a, b, c in tri:
+        pa, pb, pc = Xt[a], Xt[b], Xt[c]
+        mab, mbc, mca, g = node((pa + pb) / 2), node((pb + pc) / 2), node((pc + pa) / 2), node((pa + pb + pc) / 3)
+        quads += [[a, mab, g, mca], [b, mbc, g, mab], [c, mca, g, mbc]]
+    return np.array(nodes), np.array(quads, dtype=np.int64)
+
+
+@pytest.mark.parametrize("k", [5, 10])
+def test_unstructured_quads_with_a_hub_match_oracle(pf, orc, k):
+    """The diagonal pre-reduction of the 2x2 quad kernels on runs of 3, 4, 5 and 10 incident pairs per node (k = 10: the
+    fourth scan step), with nodal density."""
+    X, conn = _quad_hub_mesh(k)
+    rho = 0.3 + 0.7 * np.random.RandomState(k).rand(X.shape[0])
+    q, b = _qb(pf, "quad")
+    fixed = [2, 3, 4, 5]
+    model = pf.LinearElasticity(X, conn, fixed, None, {0: [0.0, -1.0]}, q, b, p=3.0)
+    for r in (None, rho):
+        Ks = (model.compute_jacobian() if r is None else model.compute_jacobian(r)).to_scipy()
+        Ko = orc.assemble_csr(orc.elasticity_Ke(X, conn, "quad", rho=r, p=3.0), orc.create_conn_dof(conn, 2))
+        assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+        assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    u = pf.Assembler(model).solve(method="cg")
+    uo, *_ = orc.solve_elasticity(X, conn, "quad", np.array(fixed), {0: [0.0, -1.0]})
+    assert relmax(u, uo) < U_TOL
+
+
 def test_too_many_neighbours_is_refused(pf):
     """More than 64 neighbours per node is outside the pattern's 1-byte/6-bit position encoding: a clean error."""
     X, conn = _fan_mesh(70)
