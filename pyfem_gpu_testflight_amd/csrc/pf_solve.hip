@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __r
           const VT* src = vals + 9 * (int64_t)gu;
           const int32_t last = max(nb[u], 1) * 9 - 1;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) v[u][k] = (double)src[min(k * 64 + lane, last)];
+          for (int k = 0; k < 9; ++k) v[u][k] = (double)src[min(k * 64 + lane, last)];  // (non-temporal: +4 % at 96^3, 0 at 128^3: not used)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
