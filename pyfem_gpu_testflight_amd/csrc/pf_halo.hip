@@ -51,7 +51,8 @@ struct pf_halo {
   int32_t* err = nullptr;        // device flag: 1 after a wait timed out (every later wait gives up at once)
   uint32_t* done = nullptr;      // (world) workgroups that finished a peer's message in the current send
   uint64_t seq = 0;
-  long long timeout_ticks = 200000000LL;  // 2 s of the 100 MHz wall clock
+  long long timeout_ticks = 1000000000LL;  // 10 s of the 100 MHz wall clock: ranks reach their first exchange skewed by
+                                           // their own setup (pattern, hierarchy, code-object load)
   pf_halo_plan plans[PF_HALO_MAXPLANS];
   int nplans = 0;
 };
@@ -173,6 +174,8 @@ extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doub
   PF_HIP(hipMemset(h->err, 0, sizeof(int32_t)));
   PF_HIP(hipMalloc((void**)&h->done, sizeof(uint32_t) * world));
   PF_HIP(hipMemset(h->done, 0, sizeof(uint32_t) * world));
+  // hipMemset of device memory may return before it ran: a peer's first flag must not be zeroed by a late memset
+  PF_HIP(hipDeviceSynchronize());
   *out = h;
   return PF_OK;
 }

@@ -529,21 +529,24 @@ class PeerHalo:
         try:
             d = iface.d
             gd = self.ops.from_numpy((part.nodes[:, None] * d + np.arange(d)).ravel().astype(np.float64), torch.float64)
-            v = 1e-3 * gd + (self.rank + 1.0)  # a value that depends on the global entry and on the rank
-            scal = torch.tensor([self.rank + 1.0, 2.0, -0.5 * self.rank], dtype=torch.float64, device=self.ops.device)
-            out = self.exchange(iface.plan, v, scal)
-            self.check()
-            ref = scal.clone()
-            dist.all_reduce(ref, group=group)
-            ok = bool(torch.allclose(out, ref, rtol=1e-15, atol=0))
-            # interface entries: sum over the sharers s of (1e-3 gd + s + 1)
             t = iface.tables
             cnt = np.diff(t["src_ptr"])
-            if cnt.size:
-                ranks_sum = np.add.reduceat(t["src_rank"] + 1.0, t["src_ptr"][:-1])
-                loc = iface.local.long()
-                exp = 1e-3 * gd[loc].cpu().numpy() * cnt + ranks_sum
-                ok = ok and bool(np.allclose(v[loc].cpu().numpy(), exp, rtol=1e-14, atol=0))
+            ranks_sum = np.add.reduceat(t["src_rank"] + 1.0, t["src_ptr"][:-1]) if cnt.size else None
+            loc = iface.local.long()
+            # four exchanges with different values: both message slots (sequence parity) are written, read, overwritten
+            # and read again -- a receiver served stale lines of a slot's previous use would pass a single exchange
+            for k in range(4):
+                v = 1e-3 * (k + 1) * gd + (self.rank + 1.0)  # depends on the global entry, the rank and the round
+                scal = torch.tensor([self.rank + 1.0 + k, 2.0, -0.5 * self.rank * (k + 1)], dtype=torch.float64,
+                                    device=self.ops.device)
+                out = self.exchange(iface.plan, v, scal)
+                self.check()
+                ref = scal.clone()
+                dist.all_reduce(ref, group=group)
+                ok = ok and bool(torch.allclose(out, ref, rtol=1e-15, atol=0))
+                if cnt.size:  # interface entries: sum over the sharers s of (1e-3 (k+1) gd + s + 1)
+                    exp = 1e-3 * (k + 1) * gd[loc].cpu().numpy() * cnt + ranks_sum
+                    ok = ok and bool(np.allclose(v[loc].cpu().numpy(), exp, rtol=1e-14, atol=0))
         except Exception as e:
             PeerHalo.last_failure = f"self-test: {type(e).__name__}: {e}"
             ok = False
