@@ -1,5 +1,5 @@
 import sys, os, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyfem_gpu_testflight_amd import pyfem
 qq = pyfem.QuadratureBilinear2D(); bq = pyfem.BasisBilinear2D(qq)
