@@ -435,6 +435,21 @@ __global__ void k_apply_dirichlet(int64_t nnodes, const int32_t* __restrict__ np
 
 __device__ __forceinline__ double2 ld2(const double* p, int64_t i) { return reinterpret_cast<const double2*>(p)[i]; }
 __device__ __forceinline__ void st2(double* p, int64_t i, double2 v) { reinterpret_cast<double2*>(p)[i] = v; }
+// non-temporal forms for the streams an iteration touches once (x, r, Ap, dinv; p and s in the single-reduction form):
+// they stop evicting what IS re-read soon -- p / z, which the next product gathers, and the fresh Ap / w
+#ifndef PF_AB_CG_NT
+#define PF_AB_CG_NT 1  // r02, 8.4 M dofs: 2435-2595 -> 2663-2905 Jacobi-PCG iterations/s (tools/spmv_ab.py); 0 = plain accesses
+#endif
+typedef double pf_vec_f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2s(const double* p, int64_t i) {
+  if (!PF_AB_CG_NT) return ld2(p, i);
+  const pf_vec_f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const pf_vec_f64x2*>(p) + i);
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void st2s(double* p, int64_t i, double2 v) {
+  if (!PF_AB_CG_NT) { st2(p, i, v); return; }
+  __builtin_nontemporal_store(pf_vec_f64x2{v.x, v.y}, reinterpret_cast<pf_vec_f64x2*>(p) + i);
+}
 
 // out_part[b] = sum w a b
 __global__ __launch_bounds__(256) void k_dot(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
@@ -478,12 +493,12 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* _
   double s1 = 0.0, s2 = 0.0;
   const int64_t n2 = n >> 1;
   PF_VEC_LOOP(i, n2) {
-    const double2 pv = ld2(p, i), av = ld2(Ap, i);
-    double2 xv = ld2(x, i), rv = ld2(r, i), zv;
+    const double2 pv = ld2(p, i), av = ld2s(Ap, i);
+    double2 xv = ld2s(x, i), rv = ld2s(r, i), zv;
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
     rv.x -= alpha * av.x; rv.y -= alpha * av.y;
-    if (dinv) { const double2 dv = ld2(dinv, i); zv.x = dv.x * rv.x; zv.y = dv.y * rv.y; } else zv = rv;
-    st2(x, i, xv); st2(r, i, rv); st2(z, i, zv);
+    if (dinv) { const double2 dv = ld2s(dinv, i); zv.x = dv.x * rv.x; zv.y = dv.y * rv.y; } else zv = rv;
+    st2s(x, i, xv); st2s(r, i, rv); st2(z, i, zv);
     s1 += rv.x * zv.x + rv.y * zv.y;
     s2 += rv.x * rv.x + rv.y * rv.y;
   }
@@ -654,15 +669,15 @@ __global__ __launch_bounds__(256) void k_cgcg_fused(int64_t n, const double* __r
   const int64_t n2 = n >> 1;
   PF_VEC_LOOP(i, n2) {
     const double2 zv = ld2(z, i), wv = ld2(w, i);
-    double2 pv = ld2(p, i), sv = ld2(s, i), xv = ld2(x, i), rv = ld2(r, i), zn;
+    double2 pv = ld2s(p, i), sv = ld2s(s, i), xv = ld2s(x, i), rv = ld2s(r, i), zn;
     pv.x = zv.x + beta * pv.x; pv.y = zv.y + beta * pv.y;
     sv.x = wv.x + beta * sv.x; sv.y = wv.y + beta * sv.y;
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
     rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
-    if (dinv) { const double2 dv = ld2(dinv, i); zn.x = dv.x * rv.x; zn.y = dv.y * rv.y; } else zn = rv;
-    st2(p, i, pv); st2(s, i, sv); st2(x, i, xv); st2(r, i, rv); st2(z, i, zn);
+    if (dinv) { const double2 dv = ld2s(dinv, i); zn.x = dv.x * rv.x; zn.y = dv.y * rv.y; } else zn = rv;
+    st2s(p, i, pv); st2s(s, i, sv); st2s(x, i, xv); st2s(r, i, rv); st2(z, i, zn);
     double2 ov = make_double2(1.0, 1.0);
-    if (own) ov = ld2(own, i);
+    if (own) ov = ld2s(own, i);
     s1 += ov.x * rv.x * zn.x + ov.y * rv.y * zn.y;
     s2 += ov.x * rv.x * rv.x + ov.y * rv.y * rv.y;
   }
