@@ -18,5 +18,7 @@ for i in range(8):
     # same values, other vectors: which buffer's placement matters?
     res[-1]["copyvals_origxy_ms"] = round(h.time_kernel(_lib.PF_K_SPMV, 100, in0=v, in1=x, out0=y), 4)
     res[-1]["origvals_copyxy_ms"] = round(h.time_kernel(_lib.PF_K_SPMV, 100, in0=K.vals, in1=xx, out0=yy), 4)
+    res[-1]["orig_v_copy_x_orig_y_ms"] = round(h.time_kernel(_lib.PF_K_SPMV, 100, in0=K.vals, in1=xx, out0=y), 4)
+    res[-1]["orig_v_orig_x_copy_y_ms"] = round(h.time_kernel(_lib.PF_K_SPMV, 100, in0=K.vals, in1=x, out0=yy), 4)
 print(json.dumps({"orig": {"v": hex(K.vals.data_ptr()), "x": hex(x.data_ptr()), "y": hex(y.data_ptr())}}))
 for r in res: print(json.dumps(r))
