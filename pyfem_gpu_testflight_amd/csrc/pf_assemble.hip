@@ -709,7 +709,7 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #define PF_AB_V4_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): A/B builds
 #endif
 #ifndef PF_AB_TILE_ORDER
-#define PF_AB_TILE_ORDER (P == 3 ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
+#define PF_AB_TILE_ORDER ((P == 3 || ctx->tiles_sorted) ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %; Morton-sorted tiles), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
 #endif
 #ifndef PF_AB_WPC_CAP
 #define PF_AB_WPC_CAP 32   // persistent waves per CU: min(resident, cap)

@@ -67,6 +67,7 @@ struct pf_ctx {
   void* tile_desc = nullptr;   // (ntiles) int4 {first node, first visit, first block, nodes | deep<<7 | visits<<8 | blocks<<16}
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   int32_t max_tile_blocks = 0; // blocks of the largest tile (sets the static store count of the copy-out)
+  bool tiles_sorted = false;   // descriptors sorted along a Morton curve (scattered numberings), else in node order
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 
   // table-driven elements (pf_tabular.hip): elements sorted by colour, no two of one colour share a node

@@ -343,6 +343,9 @@ __global__ void k_vals_to_csr(int64_t nnodes, const int32_t* __restrict__ nptr, 
         csr[(int64_t)D * D * b + (int64_t)k * D * c + t * D + l] = vals[((int64_t)b + t) * D * D + k * D + l];
 }
 
+#ifndef PF_AB_TILE_SORT
+#define PF_AB_TILE_SORT 1  // tools/build_variant.sh A/B: 0 = tiles walked in node order on every mesh
+#endif
 // ------------------------------------------------------------------------------------------
 extern "C" int pf_version(void) { return 1; }
 
@@ -703,6 +706,40 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
     }
     PF_HIP(hipStreamSynchronize(ctx->stream));  // the host staging vectors go out of scope
     (void)hipFree(dslot);
+    // Scattered numberings (no 8-byte records: some neighbour lies far away in node ids -- refinement order, a mesher's
+    // insertion order): the nodes of ONE tile are still neighbours in space, but consecutive tiles are not, and the
+    // coordinate gathers of the waves that run side by side share nothing.  The order in which tiles are WALKED is free
+    // (each tile still writes its own contiguous segment): sort the descriptors along a Morton curve of their first
+    // node, so that the tiles an XCD's waves take together (k_assemble_v4's XCD-aware walk) are neighbours in space and
+    // share its L2.  r02, torque arm refined to 2.55 M triangles in refinement order: 0.0805 -> see
+    // profiles/r02_assembly_ab.md section 15.
+    ctx->tiles_sorted = false;
+    const bool scattered = ctx->ndims == 2 && ctx->P != 8 && !ctx->vis_rec8 && !pf_exp_env("PF_NO_TILE_SORT") && PF_AB_TILE_SORT;
+    if (scattered && ctx->ntiles > 1) {
+      std::vector<double> xy((size_t)nn * 2);
+      PF_HIP(hipMemcpy(xy.data(), ctx->X, sizeof(double) * xy.size(), hipMemcpyDeviceToHost));
+      double lo[2] = {xy[0], xy[1]}, hi[2] = {xy[0], xy[1]};
+      for (int64_t i = 0; i < nn; ++i)
+        for (int c = 0; c < 2; ++c) { lo[c] = std::min(lo[c], xy[2 * i + c]); hi[c] = std::max(hi[c], xy[2 * i + c]); }
+      const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-300);
+      auto spread = [](uint64_t v) {
+        v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+        v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull;
+        return (v | (v << 1)) & 0x5555555555555555ull;
+      };
+      const int64_t nt = ctx->ntiles;
+      std::vector<std::pair<uint64_t, int32_t>> key((size_t)nt);
+      for (int64_t t = 0; t < nt; ++t) {
+        const int64_t n0 = desc[4 * t];
+        const uint64_t qx = (uint64_t)((xy[2 * n0] - lo[0]) / span * 65535.0), qy = (uint64_t)((xy[2 * n0 + 1] - lo[1]) / span * 65535.0);
+        key[t] = {spread(qx) | (spread(qy) << 1), (int32_t)t};
+      }
+      std::sort(key.begin(), key.end());
+      std::vector<int32_t> sorted(desc.size());
+      for (int64_t t = 0; t < nt; ++t) memcpy(&sorted[4 * t], &desc[4 * (size_t)key[t].second], 4 * sizeof(int32_t));
+      PF_HIP(hipMemcpy(ctx->tile_desc, sorted.data(), sizeof(int32_t) * sorted.size(), hipMemcpyHostToDevice));
+      ctx->tiles_sorted = true;
+    }
   }
   ctx->d = d;
   return PF_OK;

@@ -36,8 +36,10 @@ def _replay(maps, nnodes, P, max_row_blocks, d, conn):
     radix = nnodes ** np.arange(P, dtype=np.int64)  # test meshes are small: nnodes**P fits int64
     conn_keys = conn.astype(np.int64) @ radix
     covered_nodes = covered_vis = covered_blocks = 0
-    # the kernel reads descriptors up to 4 steps ahead, clamped to the wave's last one: always inside [0, ntiles)
-    for t in range(ntiles):
+    # the kernel reads descriptors up to 4 steps ahead, clamped to the wave's last one: always inside [0, ntiles).
+    # Tiles are WALKED in descriptor order, which is node order or (scattered numberings) a Morton order of the tiles'
+    # first nodes; the partition of nodes / visits / blocks is checked in node order
+    for t in np.argsort(td[:, 0], kind="stable"):
         n0, vb, base, w = (int(v) for v in td[t])
         nn_t, nv_t, nblk, deep = w & 63, (w >> 8) & 255, (w >> 16) & 0xFFFF, (w >> 7) & 1
         assert 0 <= n0 and n0 + nn_t <= nnodes and 1 <= nn_t <= npt
