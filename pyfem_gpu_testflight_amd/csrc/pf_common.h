@@ -68,6 +68,7 @@ struct pf_ctx {
   int64_t ntiles = 0;          //   tiles end where the value segment is 128-byte aligned whenever possible
   int32_t max_tile_blocks = 0; // blocks of the largest tile (sets the static store count of the copy-out)
   bool tiles_sorted = false;   // descriptors sorted along a Morton curve (scattered numberings), else in node order
+  int32_t* spmv_perm = nullptr; // scattered numberings: k_spmv's 64 (d = 2) / 128 (d = 1)-node tiles in Morton order, else nullptr
   uint8_t* e2pos = nullptr;    // (nelems*P*P) pos of conn[e,b] in row conn[e,a] (atomic mode; lazy)
 
   // table-driven elements (pf_tabular.hip): elements sorted by colour, no two of one colour share a node

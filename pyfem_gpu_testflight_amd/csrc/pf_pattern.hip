@@ -394,6 +394,8 @@ int pf_pattern_free(pf_ctx* ctx) {
   pf_free(ctx->vis_rec);
   pf_free(ctx->vis_rec8);
   pf_free(ctx->vis_rec12);
+  pf_free(ctx->spmv_perm);
+  ctx->tiles_sorted = false;
   pf_free(ctx->tile_desc);
   pf_free(ctx->tab_order);
   ctx->tab_color_ptr.clear();
@@ -739,6 +741,21 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
       for (int64_t t = 0; t < nt; ++t) memcpy(&sorted[4 * t], &desc[4 * (size_t)key[t].second], 4 * sizeof(int32_t));
       PF_HIP(hipMemcpy(ctx->tile_desc, sorted.data(), sizeof(int32_t) * sorted.size(), hipMemcpyHostToDevice));
       ctx->tiles_sorted = true;
+      // the same walk for the product's tiles (64 nodes per wave for d = 2, 128 for d = 1: pf_solve.hip k_spmv)
+      if (d <= 2) {
+        const int64_t ts = d == 1 ? 128 : 64, nts = cdiv(nn, ts);
+        std::vector<std::pair<uint64_t, int32_t>> k2((size_t)nts);
+        for (int64_t t = 0; t < nts; ++t) {
+          const int64_t n0 = t * ts;
+          const uint64_t qx = (uint64_t)((xy[2 * n0] - lo[0]) / span * 65535.0), qy = (uint64_t)((xy[2 * n0 + 1] - lo[1]) / span * 65535.0);
+          k2[t] = {spread(qx) | (spread(qy) << 1), (int32_t)t};
+        }
+        std::sort(k2.begin(), k2.end());
+        std::vector<int32_t> perm((size_t)nts);
+        for (int64_t t = 0; t < nts; ++t) perm[t] = k2[t].second;
+        PF_HIP(hipMalloc(&ctx->spmv_perm, sizeof(int32_t) * (size_t)nts));
+        PF_HIP(hipMemcpy(ctx->spmv_perm, perm.data(), sizeof(int32_t) * (size_t)nts, hipMemcpyHostToDevice));
+      }
     }
   }
   ctx->d = d;
