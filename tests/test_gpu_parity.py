@@ -247,6 +247,43 @@ def test_shuffled_unstructured_numbering(pf, orc):
     assert relmax(model.compute_jacobian().dot(v), Ko.dot(v)) < K_TOL
 
 
+@pytest.mark.parametrize("etype", ["tri", "quad"])
+def test_scattered_numbering_uses_the_morton_walks(pf, orc, etype):
+    """A randomly renumbered mesh of 48 k nodes: neighbours lie further apart than the compact 8-byte records reach, so the
+    assembly falls back to 12 / 16-byte records and walks its tiles -- and the products their tiles (64 nodes for 2x2
+    blocks, 128 for scalar matrices) -- along a Morton curve (pf_pattern_build).  K, the Helmholtz pair and both
+    products against the oracle."""
+    conn, X = orc.structured_mesh(241, 201, etype)
+    rng = np.random.RandomState(11)
+    perm = rng.permutation(X.shape[0])
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    X2 = X[perm]
+    conn2 = inv[conn][rng.permutation(conn.shape[0])]
+    q, b = _qb(pf, etype)
+    model = pf.LinearElasticity(X2, conn2, [0, 1, 2], None, {5: [1.0, -1.0]}, q, b)
+    maps = model.hctx.assembly_maps()
+    assert maps["rec8"] is None and (maps["rec12"] is not None) == (etype == "tri")
+    assert not np.array_equal(maps["tile_desc"][:, 0], np.sort(maps["tile_desc"][:, 0]))  # tiles are not in node order
+    K = model.compute_jacobian()
+    Ks = K.to_scipy()
+    Ko = orc.assemble_csr(orc.elasticity_Ke(X2, conn2, etype), orc.create_conn_dof(conn2, 2))
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    assert np.abs(Ks.data - Ko.data).max() <= K_TOL * np.abs(Ko.data).max()
+    v = rng.rand(Ko.shape[0])
+    assert relmax(K.dot(v), Ko.dot(v)) < K_TOL
+    hm = pf.Helmholtz(0.07, X2, conn2, q, b)
+    Keh, Reh = orc.helmholtz_Ke_Re(X2, conn2, etype, 0.07)
+    cd1 = orc.create_conn_dof(conn2, 1)
+    Kh, Rh = orc.assemble_csr(Keh, cd1), orc.assemble_csr(Reh, cd1)
+    assert np.abs(hm.K.to_scipy().data - Kh.data).max() <= K_TOL * np.abs(Kh.data).max()
+    assert np.abs(hm.R.to_scipy().data - Rh.data).max() <= K_TOL * np.abs(Rh.data).max()
+    w = rng.rand(Kh.shape[0])
+    assert relmax(hm.K.dot(w), Kh.dot(w)) < K_TOL
+    rho = hm.apply(w)
+    assert relmax(rho, orc.spsolve(Kh, Rh.dot(w))) < U_TOL
+
+
 def test_error_behaviour(pf):
     q, b = _qb(pf, "quad")
     c = pf.ProblemCreator(4, 4)
