@@ -365,7 +365,7 @@ def main():
                     help="untimed steps first (default 150 per GPU: ~30 ms of launches bring the device to its steady "
                          "clocks, see launch_ramp in the output)")
     ap.add_argument("--nx", type=int, default=2048, help="quads per side (2048 -> the 4M-quad metric mesh)")
-    ap.add_argument("--cg-iters", type=int, default=200)
+    ap.add_argument("--cg-iters", type=int, default=None, help="timed PCG iterations (default 200 per GPU)")
     ap.add_argument("--spmv-reps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dist-amg", action="store_true", help="N > 1: skip the partitioned AMG-PCG solve")
@@ -385,6 +385,8 @@ def main():
         args.steps = 200 * world
     if args.warmup is None:
         args.warmup = 150 * world
+    if args.cg_iters is None:
+        args.cg_iters = 200 * world
     # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): PF_BENCH_BACKEND=gloo with
     # PF_BENCH_DEVICE=0 runs the N>1 code path with every rank on the same GPU
     if "PF_BENCH_DEVICE" in os.environ:
@@ -496,7 +498,7 @@ def main():
     if world == 1:
         rhs = h.to_device(model.compute_rhs(), torch.float64)
         Kbc, b = model.apply_dirichlet_bcs(K, rhs, True)
-        h.cg(Kbc.vals, b, rtol=0.0, maxiter=10, allow_maxiter=True)  # warm-up
+        h.cg(Kbc.vals, b, rtol=0.0, maxiter=25, allow_maxiter=True)  # warm-up
         barrier()
         t0 = time.perf_counter()
         _, iters, relres = h.cg(Kbc.vals, b, rtol=0.0, maxiter=args.cg_iters, check_every=args.cg_iters,
@@ -527,7 +529,7 @@ def main():
                     if "failed with code" not in str(e):  # reaching maxiter is the point; anything else is an error
                         raise
 
-            run(10)
+            run(max(10, args.cg_iters // 8))  # warm-up
             barrier()
             t0 = time.perf_counter()
             run(args.cg_iters)
