@@ -702,23 +702,14 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 // COMB (pre-reduction of the diagonal block across the lanes of a node): on for triangles, where it took 0.191 ms back
 // to 0.156 ms on 4 M elements, and its cheaper form (v4_seg_step) to 0.14 ms; quads are HBM-bound and measured the same
 // with and without it (profiles/r02_assembly_ab.md)
-#ifndef PF_AB_RHO_NOCOMB
-#define PF_AB_RHO_NOCOMB 0
-#endif
-#ifndef PF_AB_V4_ATTR
-#define PF_AB_V4_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(4, 4))): A/B builds
-#endif
 #ifndef PF_AB_TILE_ORDER
 #define PF_AB_TILE_ORDER ((P == 3 || ctx->tiles_sorted) ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %; Morton-sorted tiles), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
-#endif
-#ifndef PF_AB_WPC_CAP
-#define PF_AB_WPC_CAP 32   // persistent waves per CU: min(resident, cap)
 #endif
 #ifndef PF_AB_QUAD_COMB
 #define PF_AB_QUAD_COMB 1  // the diagonal pre-reduction for the 2x2-block quad kernels too (tools/build_variant.sh A/B: 0)
 #endif
-template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4 && !(PF_AB_RHO_NOCOMB && RHO)))>
-__global__ __launch_bounds__(64) PF_AB_V4_ATTR void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
+template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4))>
+__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
                                                     const double* __restrict__ X,
                                                     const int32_t* __restrict__ nptr,
                                                     const int4* __restrict__ tile_desc,
@@ -1071,7 +1062,7 @@ static int launch_gather(pf_ctx* ctx, typename Phys::Params pr, double* out0, do
     int q = 0;
     PF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(k4), 64, lds4));
     oc.lds = lds4;
-    oc.wpc = std::max(1, std::min(q, PF_AB_WPC_CAP));
+    oc.wpc = std::max(1, std::min(q, 32));
   }
   int wpc = oc.wpc;
   const char* g3 = pf_exp_env("PF_GATHER_WAVES_PER_CU");
