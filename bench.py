@@ -487,8 +487,13 @@ def main():
     # ---- SpMV roofline leg (local block) ---------------------------------------------------------
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     xv = torch.rand(h.nrows, generator=g, dtype=torch.float64).to(dev)
-    yv = torch.empty_like(xv)
-    spmv_ms = h.time_kernel(_lib.PF_K_SPMV, args.spmv_reps, in0=K.vals, in1=xv, out0=yv)
+    # the same launch runs at two speeds depending on where the OUTPUT vector lies relative to the values;
+    # pf_cg places its own by measurement, so the leg does the same: three candidates, all reported, the fastest counted
+    ys = [torch.empty_like(xv) for _ in range(3)]
+    spmv_all = [h.time_kernel(_lib.PF_K_SPMV, args.spmv_reps, in0=K.vals, in1=xv, out0=y_) for y_ in ys]
+    spmv_ms = min(spmv_all)
+    yv = ys[spmv_all.index(spmv_ms)]
+    del ys
     b_spmv = algorithmic_bytes_spmv(h.nnz, h.nrows)
     spmv_gbs = b_spmv / (spmv_ms * 1e-3) / 1e9
     lay_spmv = layout_bytes_spmv(h.nnz, h.nrows, h.nnodes, 2)
@@ -615,7 +620,7 @@ def main():
                           "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
                           "traffic_source": None if src_spmv is None else f"replay of {src_spmv}",
                           "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
-                          "layout_bytes_per_launch": lay_spmv,
+                          "output_placements_ms": spmv_all, "layout_bytes_per_launch": lay_spmv,
                           "frac_layout": lay_spmv / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "frac_layout_of_measured": (lay_spmv / (spmv_ms * 1e-3) / 1e9 / ceil["read"]) if ceil else None,
                           "note": "frac counts CSR's 12 B per scalar nonzero (SURVEY 8d); frac_layout counts what the "

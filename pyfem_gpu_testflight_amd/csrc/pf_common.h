@@ -81,6 +81,8 @@ struct pf_ctx {
   double* scal = nullptr;      // PF_NPART_ARRAYS x PF_NPART per-block partial sums
   double* cgw = nullptr;       // CG work vectors (4*nrows), grown on demand
   int64_t cgw_cap = 0;
+  double* cg_ap = nullptr;     // the product's output vector of pf_cg, placed by measurement (pf_solve.hip cg_place_ap)
+  int64_t cg_ap_n = 0;
   void* scan_tmp = nullptr;
   size_t scan_tmp_cap = 0;
 };

@@ -414,6 +414,8 @@ extern "C" int pf_ctx_destroy(pf_ctx* ctx) {
   pf_free(ctx->conn);
   pf_free(ctx->scal);
   pf_free(ctx->cgw);
+  pf_free(ctx->cg_ap);
+  ctx->cg_ap_n = 0;
   if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
   delete ctx;
   return PF_OK;

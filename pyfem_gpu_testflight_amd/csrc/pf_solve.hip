@@ -922,6 +922,47 @@ static double host_sum(const double* v, int n) {
   return s;
 }
 
+// Where the product's OUTPUT vector lies relative to the value array decides between two times of the same launch
+// (2x2 blocks, 8.4 M dofs: 0.208 against 0.235 ms, reproducible per pair of allocations, no pattern in the virtual
+// addresses: DESIGN 3.2, tools/spmv_placement.py).  pf_cg owns that vector, so it places it by measurement: three
+// candidate allocations, a few products into each, keep the fastest.  Once per context and size (about 4 ms at 8.4 M
+// dofs; skipped below 1 M dofs, where the iteration is launch-bound).
+static int cg_place_ap(pf_ctx* ctx, const double* vals, double* xprobe, int64_t n) {
+  if (ctx->cg_ap && ctx->cg_ap_n == n) return PF_OK;
+  pf_free(ctx->cg_ap);
+  ctx->cg_ap_n = 0;
+  constexpr int NC = 3;
+  double* cand[NC] = {nullptr, nullptr, nullptr};
+  for (int c = 0; c < NC; ++c) PF_HIP(hipMalloc(&cand[c], sizeof(double) * n));
+  int best = 0;
+  if (n >= ((int64_t)1 << 20)) {
+    PF_HIP(hipMemsetAsync(xprobe, 0, sizeof(double) * n, ctx->stream));
+    hipEvent_t e0, e1;
+    PF_HIP(hipEventCreate(&e0));
+    PF_HIP(hipEventCreate(&e1));
+    float tbest = 0.f;
+    for (int c = 0; c < NC; ++c) {
+      int rc = PF_OK;
+      for (int i = 0; i < 2 && !rc; ++i) rc = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
+      PF_HIP(hipEventRecord(e0, ctx->stream));
+      for (int i = 0; i < 4 && !rc; ++i) rc = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
+      PF_HIP(hipEventRecord(e1, ctx->stream));
+      PF_HIP(hipEventSynchronize(e1));
+      if (rc) return rc;
+      float ms = 0.f;
+      PF_HIP(hipEventElapsedTime(&ms, e0, e1));
+      if (c == 0 || ms < tbest) { tbest = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  for (int c = 0; c < NC; ++c)
+    if (c != best) (void)hipFree(cand[c]);
+  ctx->cg_ap = cand[best];
+  ctx->cg_ap_n = n;
+  return PF_OK;
+}
+
 extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
                      int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
@@ -940,7 +981,9 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
     PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * 5 * n));
     ctx->cgw_cap = 5 * n;
   }
-  double *r = ctx->cgw, *z = r + n, *p = z + n, *Ap = p + n, *dinv = Ap + n;
+  double *r = ctx->cgw, *z = r + n, *p = z + n, *dinv = p + 2 * n;
+  if (int prc = cg_place_ap(ctx, vals, p, n)) return prc;
+  double* Ap = ctx->cg_ap;
   hipStream_t st = ctx->stream;
   const unsigned vg = vec_grid(n);
   const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
