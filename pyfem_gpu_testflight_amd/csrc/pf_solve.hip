@@ -1079,7 +1079,9 @@ extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* va
     PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * need));
     ctx->cgw_cap = need;
   }
-  double *r = ctx->cgw, *z = r + n, *w = z + n, *p = w + n, *s = p + n;
+  double *r = ctx->cgw, *z = r + n, *p = z + 2 * n, *s = p + n;
+  if (int prc = cg_place_ap(ctx, vals, p, n)) return prc;  // the product's output vector, placed by measurement
+  double* w = ctx->cg_ap;
   double* small = s + n;  // [0..2] state a, [8..10] state b, [16..23] local scalars, [24..31] reduced scalars
   double *stA = small, *stB = small + 8, *red = small + 16, *redg = small + 24;
   hipStream_t st = ctx->stream;
