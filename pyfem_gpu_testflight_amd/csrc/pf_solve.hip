@@ -1318,7 +1318,9 @@ __global__ __launch_bounds__(256) void k_hbm_probe(pf_probe_f64x2* __restrict__ 
 #pragma unroll
           for (int k = 0; k < NW; ++k) {
             const pf_probe_f64x2 w = {v[u].x + k, v[u].y - k};
-            pf_probe_f64x2* dst = a + i + k * n2;
+            // MIX: the three written runs of a chunk lie next to each other (one 192 KiB run per 64 KiB read), not in three
+            // arrays n2 apart -- four streams whose relative placement then decides the result
+            pf_probe_f64x2* dst = (MODE == PF_HBM_MIX) ? a + 3 * c0 + k * (c1 - c0) + (i - c0) : a + i;
             if constexpr (NT != 0) __builtin_nontemporal_store(w, dst);
             else *dst = w;
           }
