@@ -933,31 +933,35 @@ static int cg_place_ap(pf_ctx* ctx, const double* vals, double* xprobe, int64_t 
   ctx->cg_ap_n = 0;
   constexpr int NC = 3;
   double* cand[NC] = {nullptr, nullptr, nullptr};
-  for (int c = 0; c < NC; ++c) PF_HIP(hipMalloc(&cand[c], sizeof(double) * n));
-  int best = 0;
-  if (n >= ((int64_t)1 << 20)) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int best = 0, rc = PF_OK;
+  auto body = [&]() -> int {
+    for (int c = 0; c < NC; ++c) PF_HIP(hipMalloc(&cand[c], sizeof(double) * n));
+    if (n < ((int64_t)1 << 20)) return PF_OK;
     PF_HIP(hipMemsetAsync(xprobe, 0, sizeof(double) * n, ctx->stream));
-    hipEvent_t e0, e1;
     PF_HIP(hipEventCreate(&e0));
     PF_HIP(hipEventCreate(&e1));
     float tbest = 0.f;
     for (int c = 0; c < NC; ++c) {
-      int rc = PF_OK;
-      for (int i = 0; i < 2 && !rc; ++i) rc = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
+      int r2 = PF_OK;
+      for (int i = 0; i < 2 && !r2; ++i) r2 = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
       PF_HIP(hipEventRecord(e0, ctx->stream));
-      for (int i = 0; i < 4 && !rc; ++i) rc = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
+      for (int i = 0; i < 4 && !r2; ++i) r2 = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
       PF_HIP(hipEventRecord(e1, ctx->stream));
       PF_HIP(hipEventSynchronize(e1));
-      if (rc) return rc;
+      if (r2) return r2;
       float ms = 0.f;
       PF_HIP(hipEventElapsedTime(&ms, e0, e1));
       if (c == 0 || ms < tbest) { tbest = ms; best = c; }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-  }
+    return PF_OK;
+  };
+  rc = body();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
   for (int c = 0; c < NC; ++c)
-    if (c != best) (void)hipFree(cand[c]);
+    if ((rc || c != best) && cand[c]) (void)hipFree(cand[c]);
+  if (rc) return rc;
   ctx->cg_ap = cand[best];
   ctx->cg_ap_n = n;
   return PF_OK;
