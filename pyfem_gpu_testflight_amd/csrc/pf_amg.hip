@@ -1374,7 +1374,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   int64_t maxdof = 1;
   for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
   PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
-  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 3)));  // + non-positive flag + diagonal scale + positive flag
+  PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 4)));  // + non-positive flag + diagonal scale + positive flag + power-iteration scratch
   return PF_OK;
 }
 
@@ -1417,27 +1417,29 @@ __global__ void k_amg_pow_div(int64_t n, const double* __restrict__ diag, const 
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) v[i] = t[i] / diag[i];
 }
-__global__ void k_amg_pow_norm(int64_t n, const double* __restrict__ s, double* __restrict__ v) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) v[i] *= rsqrt(s[0]);
-}
-
 // lambda_max(D^-1 A) by a few power iterations, all on the device: lam2 (one device double) ends up
 // holding |D^-1 A v|^2 with |v| = 1.  Lv.dinv still holds the raw diagonal; v is scratch of at least ndof
 // doubles.  Unlike a Gershgorin row sum this is invariant under the scaling of individual dofs, which
 // matters on the coarse levels where translations and the rotation have different units.
-static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2) {
+__global__ void k_amg_pow_ratio(double* __restrict__ num, const double* __restrict__ den) { num[0] = den[0] > 0.0 ? num[0] / den[0] : 0.0; }
+
+// The iterate is NOT normalised between steps: D^-1 A has a spectral radius of a few units, ten steps grow the start
+// vector by at most that to the tenth, and only the last two norms are needed -- two launches per step (product, divide
+// by the diagonal) instead of five (+ dot, its finalize, rescale): 30 launches less per level and numeric setup.
+static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2, double* den) {
   const int64_t ndof = Lv.n * Lv.dr;
   const unsigned g = (unsigned)cdiv(ndof, 256);
   k_amg_pow_init<<<g, 256, 0, ctx->stream>>>(ndof, v);
   for (int it = 0; it < 10; ++it) {
-    int rc = amg_spmv(ctx, Lv, level, v, Lv.t);
+    int rc;
+    if (it == 9 && (rc = pf_dot(ctx, ndof, v, v, nullptr, den))) return rc;  // |v_9|^2
+    rc = amg_spmv(ctx, Lv, level, v, Lv.t);
     if (rc) return rc;
     k_amg_pow_div<<<g, 256, 0, ctx->stream>>>(ndof, Lv.dinv, Lv.t, v);
-    rc = pf_dot(ctx, ndof, v, v, nullptr, lam2);
-    if (rc) return rc;
-    if (it + 1 < 10) k_amg_pow_norm<<<g, 256, 0, ctx->stream>>>(ndof, lam2, v);
   }
+  int rc = pf_dot(ctx, ndof, v, v, nullptr, lam2);  // |v_10|^2
+  if (rc) return rc;
+  k_amg_pow_ratio<<<1, 1, 0, ctx->stream>>>(lam2, den);  // |D^-1 A v_9|^2 / |v_9|^2
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -1481,7 +1483,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     }
   }
   double* bad = H->lam + AMG_MAX_LEVELS;
-  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 3), ctx->stream));
+  PF_HIP(hipMemsetAsync(H->lam, 0, sizeof(double) * (AMG_MAX_LEVELS + 4), ctx->stream));
   for (int l = 0; l < H->nlevels; ++l) {
     AmgLevel& Lv = H->L[l];
     const unsigned gr = (unsigned)cdiv(Lv.n * AMG_ROW_LANES, 256);
@@ -1493,7 +1495,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
     // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
     const int64_t ndof = Lv.n * Lv.dr;
-    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l);
+    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l, H->lam + AMG_MAX_LEVELS + 3);
     if (rc) return rc;
     if (l + 1 < H->nlevels) {
       AmgLevel& Nx = H->L[l + 1];
