@@ -337,9 +337,13 @@ __device__ __forceinline__ void element_rows(const typename Phys::Params& pr, co
 //     with an immediate offset per piece against a resource that ends where the tile's segment ends;
 //   * the image is cleared with flat 16-byte LDS stores; the copy-out reads LDS at immediate offsets from two
 //     per-lane base addresses computed once per tile.
+// Later in round 2 (profiles/r02_assembly_ab.md sections 7-15): the contributions to a node's diagonal block are summed
+// across its lanes before they go to the LDS (v4_seg_step: DPP scan under EXEC); the records shrink to 8 bytes where
+// the numbering allows it (12 for triangles otherwise); the copy-out stores are NON-TEMPORAL (K is not re-read by the
+// launch: -14..-20 %); triangles walk their tiles XCD-aware, and on scattered numberings along a Morton curve.
 // Summation order inside a tile is fixed by the instruction stream (same lanes, same addresses every
 // run), so results are bitwise reproducible although the adds are LDS atomics.
-// dynamic LDS: double img[V*plane + 32*NOUT]  (V planes of `plane` = npt*maxrow + 1 doubles)
+// dynamic LDS: double img[V*plane + 32*NOUT]  (V planes of `plane` = blocks of the largest tile, made odd)
 // ------------------------------------------------------------------------------------------
 typedef unsigned int pf_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int pf_u32x2 __attribute__((ext_vector_type(2)));
