@@ -791,6 +791,17 @@ __global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const 
     for (int q = threadIdx.x; q < clen * DC * DC; q += 64 * NW) cacc[q] = 0.0;
     __syncthreads();
     const int32_t tb = tptr[I], te = tptr[I + 1];
+    // Contributions to the DIAGONAL block (J == I: every fine node of the column couples back into its own aggregate) would
+    // all land on the same DC x DC addresses -- r02 counters: 97 % of this kernel's issue stalls wait for the LDS, 39 % of
+    // its LDS cycles are conflicts.  They are summed in registers per lane and reduced across the wave once per row.
+    constexpr bool DIAGREG = DC == 3;  // 2-D elasticity levels: -15 % on the finest one; 6 x 6 blocks (3-D) would cost 72 registers, scalar rows do not pay for the butterfly
+    double dg[DIAGREG ? DC : 1][DIAGREG ? DC : 1];
+    if constexpr (DIAGREG) {
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < DC; ++c2) dg[c][c2] = 0.0;
+    }
     for (int32_t e0 = tb + E * wave; e0 < te; e0 += E * NW) {
       const int32_t e = e0 + es;
       const bool eok = es < E && e < te;
@@ -824,8 +835,18 @@ __global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const 
           for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) {
             const int32_t J = pidx[s2];
             if (J < (int32_t)I) continue;  // A_c is symmetric: the lower triangle is mirrored by k_sa_mirror_lower
-            while (pos < clen - 1 && crow[pos] != J) ++pos;
             const double* Pm = pvals + (int64_t)s2 * DR * DC;
+            if (DIAGREG && J == (int32_t)I) {
+#pragma unroll
+              for (int c = 0; c < DC; ++c)
+#pragma unroll
+                for (int c2 = 0; c2 < DC; ++c2) {
+#pragma unroll
+                  for (int t = 0; t < DR; ++t) dg[DIAGREG ? c : 0][DIAGREG ? c2 : 0] += T[c][t] * Pm[t * DC + c2];
+                }
+              continue;
+            }
+            while (pos < clen - 1 && crow[pos] != J) ++pos;
 #pragma unroll
             for (int c = 0; c < DC; ++c)
 #pragma unroll
@@ -839,6 +860,21 @@ __global__ __launch_bounds__(64 * NW) void k_sa_galerkin_wave(int64_t nc, const 
           }
         }
       }
+    }
+    if constexpr (DIAGREG) {  // the diagonal block: butterfly over the wave (every lane ends with the same bits), one lane adds
+      int dpos = 0;
+      while (dpos < clen - 1 && crow[dpos] != (int32_t)I) ++dpos;
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < DC; ++c2) {
+          double v = dg[c][c2];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == 0)
+            __hip_atomic_fetch_add(cacc + (dpos * DC + c) * DC + c2, v, __ATOMIC_RELAXED,
+                                   NW == 1 ? __HIP_MEMORY_SCOPE_WAVEFRONT : __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     __syncthreads();
     double* dst = cvals + (int64_t)cb * DC * DC;
