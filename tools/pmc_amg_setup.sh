@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: counters of the two big kernels of the AMG numeric setup (k_sa_galerkin_wave<2,3,1>, k_sa_smooth_P<2,2,3>)
+# Runs ON THE GPU BOX: counters of the big kernels of the AMG numeric setup and cycle on the finest 2-D elasticity level
 # over tools/c5_parts.py, separate passes.   gpurun -- bash tools/pmc_amg_setup.sh
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -13,12 +13,13 @@ timeout -k 10 300 rocprofv3 --pmc TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES --kern
 timeout -k 10 300 rocprofv3 --pmc TCP_PENDING_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES --kernel-trace --output-format csv -d $OUT/g -o p -- $P > $OUT/g.log 2>&1 || echo "pass g failed"
 python3 - <<PY
 import csv, glob, collections
+WANT = ("k_sa_galerkin_wave<2, 3, 1>", "k_sa_smooth_P<2, 2, 3>", "k_sa_prolong<2, 3>", "k_sa_restrict_stream<2, 3>", "k_spmv<2, 1, 3, 640, true, float>", "k_cg_update_xr")
 acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 for sub in "abceg":
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % sub, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if "k_sa_galerkin_wave<2, 3, 1>" in k or "k_sa_smooth_P<2, 2, 3>" in k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if any(w in k for w in WANT): acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for f in glob.glob("$OUT/%s/**/*kernel_trace.csv" % sub, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
