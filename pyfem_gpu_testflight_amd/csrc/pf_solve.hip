@@ -26,6 +26,9 @@
 // SpMV shapes: <D, rows per lane, blocks per lane in flight, LDS strip entries> (10 KB strips -> 16 waves/CU)
 #define PF_SPMV1 1, 2, 6, 1280
 #define PF_SPMV2 2, 1, 3, 640
+#ifndef PF_SPMV2F
+#define PF_SPMV2F 2, 1, 6, 640  // fp32 value copy (AMG smoother): 16-byte blocks, so twice as many in flight for the same bytes
+#endif
 static constexpr int SPMV_TILE1 = 128, SPMV_TILE2 = 64;  // nodes per wave tile (64 * rows per lane)
 static constexpr int SPMV_MAXGRID = 4096;
 static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
@@ -765,8 +768,8 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
       const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
       if (ctx->d == 1 && i16) k_spmv<PF_SPMV1, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
       else if (ctx->d == 1) k_spmv<PF_SPMV1, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else if (i16) k_spmv<PF_SPMV2, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else k_spmv<PF_SPMV2, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      else if (i16) k_spmv<PF_SPMV2F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      else k_spmv<PF_SPMV2F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
     }
     PF_LAUNCH_CHECK();
     return PF_OK;
