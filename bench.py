@@ -54,6 +54,19 @@ def layout_bytes_spmv(nnz, nrows, nnodes, d, idx16=True):
     return 8 * nnz + (2 if idx16 else 4) * nblocks + 4 * nnodes + 16 * nrows
 
 
+def roof_spmv(nnz, nrows, nnodes, d, ms, ceiling=None, idx16=True):
+    """SpMV roofline entry: `achieved` / `frac` count the bytes the kernel's own layout MOVES (HBM utilisation);
+    `frac_csr_convention` counts SURVEY 8(d)'s 12 B per scalar nonzero, which the blocked layout undercuts, so it can
+    exceed 1 without any work being skipped."""
+    lay, alg = layout_bytes_spmv(nnz, nrows, nnodes, d, idx16), algorithmic_bytes_spmv(nnz, nrows)
+    gbs = lay / (ms * 1e-3) / 1e9
+    out = {"layout_bytes": int(lay), "algorithmic_bytes_csr_convention": int(alg), "avg_launch_ms": ms, "achieved_GBps": gbs,
+           "frac": gbs / HBM_PEAK_GBS, "frac_csr_convention": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if ceiling:
+        out["frac_of_measured"] = gbs / ceiling
+    return out
+
+
 def usable_cpus():
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
@@ -260,10 +273,7 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         t_apply = time.perf_counter() - t0
         Rx = h.spmv(m.R.vals, xd)
         relres = float((Rx - m.K.dot(rho)).norm() / Rx.norm())
-        sp = roof(algorithmic_bytes_spmv(h.nnz, h.nrows), ms_spmv, ceil.get("read"))
-        lay = layout_bytes_spmv(h.nnz, h.nrows, h.nnodes, 1)
-        sp["layout_bytes"] = lay
-        sp["frac_layout"] = lay / (ms_spmv * 1e-3) / 1e9 / HBM_PEAK_GBS
+        sp = roof_spmv(h.nnz, h.nrows, h.nnodes, 1, ms_spmv, ceil.get("read_nt"))
         legs["c3"] = {"workload": "Helmholtz filter r0=0.05 on 2048x2048 quads (4198401 rows, d=1)",
                       "assemble_K": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz), ms_asm, ceil.get("mix_best")),
                       "assemble_K_and_R": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, nmat=2), ms_asm2, ceil.get("mix_best")),
@@ -292,7 +302,7 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
             ms_spmv = h.time_kernel(_lib.PF_K_SPMV, 30, in0=K.vals, in1=xv, out0=yv)
             tri[tag] = {"workload": desc, "nelems": h.nelems, "elements_per_s": h.nelems / (ms * 1e-3),
                         "assemble": roof(algorithmic_bytes_assembly(h.nelems, h.nnodes, h.nnz, P=3), ms, ceil.get("mix_best")),
-                        "spmv": roof(algorithmic_bytes_spmv(h.nnz, h.nrows), ms_spmv, ceil.get("read"))}
+                        "spmv": roof_spmv(h.nnz, h.nrows, h.nnodes, 2, ms_spmv, ceil.get("read_nt"), idx16=(mesh is None))}
             if mesh == "arm":
                 rhs = h.to_device(m.compute_rhs(), torch.float64)
                 Kbc, bb = m.apply_dirichlet_bcs(K, rhs, True)
@@ -616,16 +626,17 @@ def main():
                      "algorithmic_bytes_per_launch": b_asm, "avg_launch_ms": kern_ms,
                      "frac_of_measured": (asm_gbs / ceil["mix_best"]) if ceil else None,
                      "measured_ceiling": "hbm_ceiling.mix_best" if ceil else None},
-        "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true,double>", "achieved": spmv_gbs, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS, "traffic": traffic_spmv,
+        "roofline_spmv": {"bound": "hbm", "kernel": "k_spmv<2,1,3,640,true,double>",
+                          "achieved": lay_spmv / (spmv_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": lay_spmv / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_spmv,
                           "traffic_source": None if src_spmv is None else f"replay of {src_spmv}",
-                          "algorithmic_bytes_per_launch": b_spmv, "avg_launch_ms": spmv_ms,
-                          "output_placements_ms": spmv_all, "layout_bytes_per_launch": lay_spmv,
-                          "frac_layout": lay_spmv / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                          "frac_layout_of_measured": (lay_spmv / (spmv_ms * 1e-3) / 1e9 / ceil["read"]) if ceil else None,
-                          "note": "frac counts CSR's 12 B per scalar nonzero (SURVEY 8d); frac_layout counts what the "
-                                  "2x2-block layout with 16-bit column offsets really moves (8.5 B per nonzero + "
-                                  "vectors) and is the HBM utilisation"},
+                          "layout_bytes_per_launch": lay_spmv, "avg_launch_ms": spmv_ms, "output_placements_ms": spmv_all,
+                          "frac_of_measured": (lay_spmv / (spmv_ms * 1e-3) / 1e9 / ceil["read_nt"]) if ceil else None,
+                          "algorithmic_bytes_csr_convention": b_spmv, "frac_csr_convention": spmv_gbs / HBM_PEAK_GBS,
+                          "note": "achieved / frac count what the 2x2-block layout with 16-bit column offsets MOVES (8.5 B "
+                                  "per nonzero + vectors): the HBM utilisation.  frac_csr_convention counts SURVEY 8(d)'s "
+                                  "12 B per scalar nonzero, which the layout undercuts -- it can exceed 1 with no work "
+                                  "skipped"},
         "setup_s": t_setup, "launch_ramp": ramp,
     }
     if ceil:
