@@ -7,15 +7,17 @@
 //
 //   * every rank owns one WINDOW in fine-grained device memory, shared with the other ranks of the node through
 //     hipIpcGetMemHandle / hipIpcOpenMemHandle (set up once, handles travel over torch.distributed);
-//   * k_halo_send packs the interface values and STORES them straight into the neighbours' windows over xGMI
-//     (xGMI is point-to-point: one hop to every peer of the node), writes the rank's scalars into every peer's
-//     window, fences, and raises a per-sender sequence flag with a system-scope release store;
-//   * k_halo_recv spins on the flags of its senders (system-scope acquire loads, bounded by a wall-clock timeout so
-//     that the grid always drains), then sums what arrived IN ASCENDING RANK ORDER -- every rank that shares a dof
-//     forms the same sum of the same operands, so interface copies stay bitwise identical on all ranks -- and reduces
-//     the scalars the same way (a deterministic all-reduce without a collective).
-//   Two launches per exchange on the solver's stream, nothing on the host: the whole CG loop (pf_dist_cg) is a
-//   sequence of kernel launches from C.
+//   * the SEND workgroups of k_halo_xchg pack the interface values and STORE them straight into the neighbours' windows
+//     over xGMI (xGMI is point-to-point: one hop to every peer of the node), write the rank's scalars into every peer's
+//     window, fence, and raise a per-sender sequence flag with a system-scope release store;
+//   * the RECEIVE workgroups of the same launch spin on the flags of their senders (system-scope acquire loads, bounded
+//     by a wall-clock timeout so that the grid always drains) and on a counter of this rank's own send workgroups (the
+//     vector's interface entries are overwritten only after every sender has read them), then sum what arrived IN
+//     ASCENDING RANK ORDER -- every rank that shares a dof forms the same sum of the same operands, so interface copies
+//     stay bitwise identical on all ranks -- and reduce the scalars the same way (a deterministic all-reduce without a
+//     collective).
+//   ONE launch per exchange on the solver's stream (at most 8 * 16 + 256 workgroups: senders and receivers are resident
+//   together), nothing on the host: the whole CG loop (pf_dist_cg) is a sequence of kernel launches from C.
 //
 // Synchronisation: exchanges are numbered (seq = 1, 2, ...; SPMD, every rank issues the same sequence).  Message
 // buffers are double-buffered by seq parity.  A sender may run at most one exchange ahead of a receiver (it needs
@@ -50,6 +52,8 @@ struct pf_halo {
   std::vector<void*> mapped;     // host copies for hipIpcCloseMemHandle
   int32_t* err = nullptr;        // device flag: 1 after a wait timed out (every later wait gives up at once)
   uint32_t* done = nullptr;      // (world) workgroups that finished a peer's message in the current send
+  unsigned long long* sent = nullptr;  // send workgroups that have finished READING the vector, over all exchanges so far
+  unsigned long long sent_target = 0;  // its value once every send workgroup of the exchanges issued so far is through
   uint64_t seq = 0;
   long long timeout_ticks = 1000000000LL;  // 10 s of the 100 MHz wall clock: ranks reach their first exchange skewed by
                                            // their own setup (pattern, hierarchy, code-object load)
@@ -63,14 +67,12 @@ __host__ __device__ static inline size_t halo_recv_off(int world) { return halo_
 
 // NB workgroups per peer (NB = gridDim.y): scalars to every peer, the packed values to the neighbours of the plan; the
 // workgroup that finishes a peer's message last raises that peer's flag (counted in done[peer], which it resets)
-__global__ __launch_bounds__(256) void k_halo_send(int world, int rank, int64_t cap, double* const* __restrict__ peer_win,
-                                                   int nnbr, const int32_t* __restrict__ nbr,
-                                                   const int32_t* __restrict__ nbr_ptr,
-                                                   const int32_t* __restrict__ send_idx, const double* __restrict__ v,
-                                                   const double* __restrict__ scal_in, int ns, uint64_t seq,
-                                                   uint32_t* __restrict__ done) {
-  const int peer = blockIdx.x;  // including this rank: its own scalars go through its own window too
-  const int part = blockIdx.y, nparts = gridDim.y;
+__device__ __forceinline__ void halo_send(int peer, int part, int nparts, int world, int rank, int64_t cap,
+                                          double* const* __restrict__ peer_win, int nnbr, const int32_t* __restrict__ nbr,
+                                          const int32_t* __restrict__ nbr_ptr, const int32_t* __restrict__ send_idx,
+                                          const double* __restrict__ v, const double* __restrict__ scal_in, int ns,
+                                          uint64_t seq, uint32_t* __restrict__ done, unsigned long long* __restrict__ sent) {
+  // peer includes this rank: its own scalars go through its own window too
   double* w = peer_win[peer];
   const int par = (int)(seq & 1);
   if (part == 0) {
@@ -100,17 +102,20 @@ __global__ __launch_bounds__(256) void k_halo_send(int world, int rank, int64_t 
     }
     if (last)
       __hip_atomic_store(reinterpret_cast<uint64_t*>(w) + rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // this workgroup has read everything it needs from v (the barrier above is behind every thread's loads): the
+    // receiving workgroups of the same launch may overwrite the interface entries once all senders have said so
+    __hip_atomic_fetch_add(sent, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // every workgroup waits for ALL ranks' messages of this exchange, then sums its share of the interface entries;
 // workgroup 0 also reduces the scalars.  Sums run over the contributing ranks in ascending order.
-__global__ __launch_bounds__(256) void k_halo_recv(int world, int rank, int64_t cap, double* __restrict__ win, int64_t n_if,
-                                                   const int32_t* __restrict__ if_idx,
-                                                   const int32_t* __restrict__ src_ptr,
-                                                   const int32_t* __restrict__ src_off, double* __restrict__ v,
-                                                   double* __restrict__ scal_out, int ns, uint64_t seq,
-                                                   int32_t* __restrict__ err, long long timeout_ticks) {
+__device__ __forceinline__ void halo_recv(int rb, int nrb, int world, int rank, int64_t cap, double* __restrict__ win,
+                                          int64_t n_if, const int32_t* __restrict__ if_idx,
+                                          const int32_t* __restrict__ src_ptr, const int32_t* __restrict__ src_off,
+                                          double* __restrict__ v, double* __restrict__ scal_out, int ns, uint64_t seq,
+                                          int32_t* __restrict__ err, long long timeout_ticks,
+                                          const unsigned long long* __restrict__ sent, unsigned long long sent_target) {
   __shared__ int bad;
   if (threadIdx.x == 0) bad = *err;
   __syncthreads();
@@ -122,6 +127,13 @@ __global__ __launch_bounds__(256) void k_halo_recv(int world, int rank, int64_t 
       __builtin_amdgcn_s_sleep(2);
     }
   }
+  if (threadIdx.x == 0 && !bad) {  // ... and for this rank's own senders (same launch) to be done reading v
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(sent, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < sent_target) {
+      if (wall_clock64() - t0 > timeout_ticks) { bad = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   __syncthreads();
   if (bad) {  // a peer never arrived: flag it and leave (the host raises; the grid drains)
     if (threadIdx.x == 0) *err = 1;
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256) void k_halo_recv(int world, int rank, int64_t 
   __threadfence_system();
   const int par = (int)(seq & 1);
   const double* recv = win + halo_recv_off(world) + (size_t)par * world * cap;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_if; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = rb * (int64_t)blockDim.x + threadIdx.x; i < n_if; i += (int64_t)nrb * blockDim.x) {
     const int32_t li = if_idx[i];
     const double own = v[li];
     double s = 0.0;
@@ -140,12 +152,33 @@ __global__ __launch_bounds__(256) void k_halo_recv(int world, int rank, int64_t 
     }
     v[li] = s;
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < ns) {
+  if (rb == 0 && (int)threadIdx.x < ns) {
     const double* scal = win + halo_scal_off(world) + (size_t)par * world * PF_HALO_NSCAL;
     double s = 0.0;
     for (int r = 0; r < world; ++r) s += __builtin_nontemporal_load(scal + (size_t)r * PF_HALO_NSCAL + threadIdx.x);
     scal_out[threadIdx.x] = s;
   }
+}
+
+// ONE launch per exchange: the first world * nparts workgroups send, the rest receive.  The launch is far smaller than
+// the device (at most 8 * 16 + 256 workgroups), so senders and receivers are resident together; a receiver waits for the
+// flags of all ranks AND for this rank's own senders to have read the vector before it overwrites interface entries.
+__global__ __launch_bounds__(256) void k_halo_xchg(int nparts, int world, int rank, int64_t cap, double* const* __restrict__ peer_win,
+                                                   int nnbr, const int32_t* __restrict__ nbr, const int32_t* __restrict__ nbr_ptr,
+                                                   const int32_t* __restrict__ send_idx, double* __restrict__ v,
+                                                   const double* __restrict__ scal_in, int ns, uint64_t seq,
+                                                   uint32_t* __restrict__ done, unsigned long long* __restrict__ sent,
+                                                   unsigned long long sent_target, double* __restrict__ win, int64_t n_if,
+                                                   const int32_t* __restrict__ if_idx, const int32_t* __restrict__ src_ptr,
+                                                   const int32_t* __restrict__ src_off, double* __restrict__ scal_out,
+                                                   int32_t* __restrict__ err, long long timeout_ticks) {
+  const int nsend = world * nparts;
+  if ((int)blockIdx.x < nsend)
+    halo_send((int)blockIdx.x % world, (int)blockIdx.x / world, nparts, world, rank, cap, peer_win, nnbr, nbr, nbr_ptr, send_idx, v,
+              scal_in, ns, seq, done, sent);
+  else
+    halo_recv((int)blockIdx.x - nsend, (int)gridDim.x - nsend, world, rank, cap, win, n_if, if_idx, src_ptr, src_off, v, scal_out, ns,
+              seq, err, timeout_ticks, sent, sent_target);
 }
 
 extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doubles, pf_halo** out) {
@@ -174,6 +207,8 @@ extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doub
   PF_HIP(hipMemset(h->err, 0, sizeof(int32_t)));
   PF_HIP(hipMalloc((void**)&h->done, sizeof(uint32_t) * world));
   PF_HIP(hipMemset(h->done, 0, sizeof(uint32_t) * world));
+  PF_HIP(hipMalloc((void**)&h->sent, sizeof(unsigned long long)));
+  PF_HIP(hipMemset(h->sent, 0, sizeof(unsigned long long)));
   // hipMemset of device memory may return before it ran: a peer's first flag must not be zeroed by a late memset
   PF_HIP(hipDeviceSynchronize());
   *out = h;
@@ -264,11 +299,12 @@ int pf_halo_exchange_impl(pf_halo* h, int plan, double* v, const double* scal_in
   // interface rows of a strip (4 K doubles) go through one workgroup per peer; the level-1 right-hand side of the AMG
   // cycle (~100 K doubles per peer) through up to 16
   const unsigned nparts = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.max_msg, 8192), 16));
-  k_halo_send<<<dim3(h->world, nparts), 256, 0, ctx->stream>>>(h->world, h->rank, h->cap, h->peer_win, P.nnbr, P.nbr, P.nbr_ptr,
-                                                               P.send_idx, v, scal_in, ns, seq, h->done);
   const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.n_if, 256), 256));
-  k_halo_recv<<<g, 256, 0, ctx->stream>>>(h->world, h->rank, h->cap, h->win, P.n_if, P.if_idx, P.src_ptr, P.src_off, v,
-                                          scal_out, ns, seq, h->err, h->timeout_ticks);
+  h->sent_target += (unsigned long long)h->world * nparts;
+  k_halo_xchg<<<h->world * nparts + g, 256, 0, ctx->stream>>>((int)nparts, h->world, h->rank, h->cap, h->peer_win, P.nnbr, P.nbr,
+                                                              P.nbr_ptr, P.send_idx, v, scal_in, ns, seq, h->done, h->sent,
+                                                              h->sent_target, h->win, P.n_if, P.if_idx, P.src_ptr, P.src_off,
+                                                              scal_out, h->err, h->timeout_ticks);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -310,6 +346,7 @@ extern "C" int pf_halo_destroy(pf_halo* h) {
   pf_free(h->peer_win);
   pf_free(h->err);
   pf_free(h->done);
+  pf_free(h->sent);
   if (h->win) (void)hipFree(h->win);
   delete h;
   return PF_OK;

@@ -8,11 +8,11 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/pyfem_gpu_testflight_amd
 python -m pyfem_gpu_testflight_amd.build > /dev/null
 mkdir -p /tmp/pfvar_$name
-for f in pf_pattern pf_assemble pf_solve; do
+for f in pf_pattern pf_assemble pf_solve pf_halo; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics "$@" -I $R/include -I $P/csrc -c $P/csrc/$f.hip -o /tmp/pfvar_$name/$f.o &
 done
 wait
 B=$P/build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libpyfem_hip_$name.so /tmp/pfvar_$name/pf_pattern.o /tmp/pfvar_$name/pf_assemble.o /tmp/pfvar_$name/pf_solve.o \
-  $B/pf_assemble3d.o $B/pf_tabular.o $B/pf_amg.o $B/pf_halo.o $B/pf_dist.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libpyfem_hip_$name.so /tmp/pfvar_$name/pf_pattern.o /tmp/pfvar_$name/pf_assemble.o /tmp/pfvar_$name/pf_solve.o /tmp/pfvar_$name/pf_halo.o \
+  $B/pf_assemble3d.o $B/pf_tabular.o $B/pf_amg.o $B/pf_dist.o
 echo $P/libpyfem_hip_$name.so
