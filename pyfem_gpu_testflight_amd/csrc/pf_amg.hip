@@ -572,18 +572,37 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
     for (int k = 0; k < D; ++k) acc[k] = 0.0;
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
-      for (int32_t g = c0 + lane; g < c1; g += 64) {
-        const int64_t m = idx[g];
-        const VT* a = vals + (int64_t)g * D * D;  // VT = float: the fp32 copy of the coarse operator (cycle only)
-        double xv[D];
+      // U blocks per lane in flight (column ids first, then blocks and gathers together): these levels wait for memory
+      constexpr int U = (D <= 3) ? 4 : 1;
+      for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
+        int32_t gg[U];
+        int64_t mm[U];
 #pragma unroll
-        for (int l = 0; l < D; ++l) xv[l] = (MODE == AMG_SMOOTH0) ? dinv[D * m + l] * b[D * m + l] : x[D * m + l];
+        for (int u = 0; u < U; ++u) {
+          gg[u] = min(g0 + 64 * u, c1 - 1);  // clamped: loads stay in range, the result is discarded
+          mm[u] = idx[gg[u]];
+        }
+        VT av[U][D * D];
+        double xv[U][D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-          double s = 0.0;
+        for (int u = 0; u < U; ++u) {
+          const VT* a = vals + (int64_t)gg[u] * D * D;  // VT = float: the fp32 copy of the coarse operator (cycle only)
 #pragma unroll
-          for (int l = 0; l < D; ++l) s += (double)a[k * D + l] * xv[l];
-          prod[(g - c0) * D + k] = s;
+          for (int q = 0; q < D * D; ++q) av[u][q] = a[q];
+#pragma unroll
+          for (int l = 0; l < D; ++l)
+            xv[u][l] = (MODE == AMG_SMOOTH0) ? dinv[D * mm[u] + l] * b[D * mm[u] + l] : x[D * mm[u] + l];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (g0 + 64 * u >= c1) continue;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) s += (double)av[u][k * D + l] * xv[u][l];
+            prod[(gg[u] - c0) * D + k] = s;
+          }
         }
       }
       __syncthreads();
