@@ -1098,13 +1098,45 @@ __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const 
   double s[DR];
 #pragma unroll
   for (int r = 0; r < DR; ++r) s[r] = 0.0;
-  for (int32_t q = pptr[i]; q < pptr[i + 1]; ++q) {
-    const double* Pn = pvals + (int64_t)q * DR * DC;
-    const double* e = ec + DC * (int64_t)pidx[q];
+  const int32_t qb = pptr[i], qe = pptr[i + 1];
+  if constexpr (DR * DC <= 9) {
+    // four entries at a time: their aggregate ids first, then the blocks and the coarse values together (independent
+    // loads in flight instead of one dependent chain per entry)
+    for (int32_t q0 = qb; q0 < qe; q0 += 4) {
+      int32_t qq[4];
+      int64_t JJ[4];
 #pragma unroll
-    for (int r = 0; r < DR; ++r)
+      for (int u = 0; u < 4; ++u) {
+        qq[u] = min(q0 + u, qe - 1);
+        JJ[u] = pidx[qq[u]];
+      }
+      double Pv[4][DR * DC], ev[4][DC];
 #pragma unroll
-      for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+      for (int u = 0; u < 4; ++u) {
+        const double* Pn = pvals + (int64_t)qq[u] * DR * DC;
+#pragma unroll
+        for (int k = 0; k < DR * DC; ++k) Pv[u][k] = Pn[k];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) ev[u][c] = ec[DC * JJ[u] + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (q0 + u >= qe) continue;
+#pragma unroll
+        for (int r = 0; r < DR; ++r)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) s[r] += Pv[u][r * DC + c] * ev[u][c];
+      }
+    }
+  } else {
+    for (int32_t q = qb; q < qe; ++q) {
+      const double* Pn = pvals + (int64_t)q * DR * DC;
+      const double* e = ec + DC * (int64_t)pidx[q];
+#pragma unroll
+      for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+    }
   }
 #pragma unroll
   for (int r = 0; r < DR; ++r) x[DR * i + r] += over * s[r];
