@@ -1982,13 +1982,32 @@ __global__ void k_sa_prolong_rows(int64_t nl, const int32_t* __restrict__ grow, 
   double s[DR];
 #pragma unroll
   for (int r = 0; r < DR; ++r) s[r] = 0.0;
-  for (int32_t q = pptr[g]; q < pptr[g + 1]; ++q) {
-    const double* Pn = pvals + (int64_t)q * DR * DC;
-    const double* e = ec + DC * (int64_t)pidx[q];
+  const int32_t qb = pptr[g], qe = pptr[g + 1];
+  for (int32_t q0 = qb; q0 < qe; q0 += 4) {  // four entries in flight, like k_sa_prolong
+    int32_t qq[4];
+    int64_t JJ[4];
 #pragma unroll
-    for (int r = 0; r < DR; ++r)
+    for (int u = 0; u < 4; ++u) {
+      qq[u] = min(q0 + u, qe - 1);
+      JJ[u] = pidx[qq[u]];
+    }
+    double Pv[4][DR * DC], ev[4][DC];
 #pragma unroll
-      for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+    for (int u = 0; u < 4; ++u) {
+      const double* Pn = pvals + (int64_t)qq[u] * DR * DC;
+#pragma unroll
+      for (int k = 0; k < DR * DC; ++k) Pv[u][k] = Pn[k];
+#pragma unroll
+      for (int c = 0; c < DC; ++c) ev[u][c] = ec[DC * JJ[u] + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (q0 + u >= qe) continue;
+#pragma unroll
+      for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) s[r] += Pv[u][r * DC + c] * ev[u][c];
+    }
   }
 #pragma unroll
   for (int r = 0; r < DR; ++r) x[DR * i + r] += over * s[r];
@@ -2003,13 +2022,32 @@ __global__ void k_sa_restrict_rows(int64_t nc, const int32_t* __restrict__ ltptr
   double acc[DC];
 #pragma unroll
   for (int c = 0; c < DC; ++c) acc[c] = 0.0;
-  for (int32_t e = ltptr[I]; e < ltptr[I + 1]; ++e) {
-    const double* Pn = pvals + (int64_t)ltslot[e] * DR * DC;
-    const double* rv = res + DR * (int64_t)ltnode[e];
+  const int32_t eb = ltptr[I], ee = ltptr[I + 1];
+  for (int32_t e0 = eb; e0 < ee; e0 += 4) {  // four entries in flight; ascending order of the adds kept
+    int64_t sl[4], nd[4];
 #pragma unroll
-    for (int r = 0; r < DR; ++r)
+    for (int u = 0; u < 4; ++u) {
+      const int32_t e = min(e0 + u, ee - 1);
+      sl[u] = ltslot[e];
+      nd[u] = ltnode[e];
+    }
+    double Pv[4][DR * DC], rv[4][DR];
 #pragma unroll
-      for (int c = 0; c < DC; ++c) acc[c] += Pn[r * DC + c] * rv[r];
+    for (int u = 0; u < 4; ++u) {
+      const double* Pn = pvals + sl[u] * DR * DC;
+#pragma unroll
+      for (int k = 0; k < DR * DC; ++k) Pv[u][k] = Pn[k];
+#pragma unroll
+      for (int r = 0; r < DR; ++r) rv[u][r] = res[DR * nd[u] + r];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u >= ee) continue;
+#pragma unroll
+      for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) acc[c] += Pv[u][r * DC + c] * rv[u][r];
+    }
   }
 #pragma unroll
   for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];

@@ -24,8 +24,12 @@
 #include "pf_common.h"
 
 // SpMV shapes: <D, rows per lane, blocks per lane in flight, LDS strip entries> (10 KB strips -> 16 waves/CU)
+#ifndef PF_SPMV1
 #define PF_SPMV1 1, 2, 6, 1280
+#endif
+#ifndef PF_SPMV2
 #define PF_SPMV2 2, 1, 3, 640
+#endif
 #ifndef PF_SPMV2F
 #define PF_SPMV2F 2, 1, 6, 640  // fp32 value copy (AMG smoother): 16-byte blocks, so twice as many in flight for the same bytes
 #endif
