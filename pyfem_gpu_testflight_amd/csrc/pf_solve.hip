@@ -30,6 +30,9 @@
 #ifndef PF_SPMV2
 #define PF_SPMV2 2, 1, 3, 640
 #endif
+#ifndef PF_SPMV1F
+#define PF_SPMV1F 1, 2, 6, 1280   // fp32 value copy of scalar matrices
+#endif
 #ifndef PF_SPMV2F
 #define PF_SPMV2F 2, 1, 6, 640  // fp32 value copy (AMG smoother): 16-byte blocks, so twice as many in flight for the same bytes
 #endif
@@ -773,8 +776,8 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
       if (int rc16 = ensure_idx16(ctx)) return rc16;
       const bool i16 = ctx->nidx16_state == 1;
       const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
-      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else if (ctx->d == 1) k_spmv<PF_SPMV1, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      else if (ctx->d == 1) k_spmv<PF_SPMV1F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
       else if (i16) k_spmv<PF_SPMV2F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
       else k_spmv<PF_SPMV2F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
     }
