@@ -53,6 +53,11 @@ def _vdot(a, b):
     return complex(s) if np.iscomplexobj(s) else float(s)
 
 
+class DirectSolveError(RuntimeError):
+    """method="direct" gave up: the message names the iterations spent, the true residual reached and the host
+    alternative, and is passed through _solve_linear_system unchanged (a RuntimeError, as pyfem.py:2422 raises)."""
+
+
 _PRECOND = {"none": _lib.PF_PRECOND_NONE, "jacobi": _lib.PF_PRECOND_JACOBI, "amg": _lib.PF_PRECOND_AMG}
 
 
@@ -818,7 +823,8 @@ class Assembler:
         self.rtol = DEFAULT_RTOL
         self.precond = DEFAULT_PRECOND
         self.last_iters = None
-        self.last_relres = None
+        self.last_relres = None  # relative residual of the last solve (method="direct": the TRUE ||b - K x|| / ||b||)
+        self.direct_strict = False  # True: method="direct" raises above DIRECT_QUIET instead of warning up to DIRECT_ACCEPT
 
     @time_this
     def solve(self, method="gmres"):
@@ -859,14 +865,14 @@ class Assembler:
                 x, it, rr = self._direct_by_refinement(K, b)
             else:
                 x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
-        except _lib.PyfemHipError:
-            raise  # a HIP / argument error is not a convergence failure: keep its message
+        except (_lib.PyfemHipError, DirectSolveError):
+            raise  # a HIP / argument error is not a convergence failure, and method="direct"'s message is final
         except RuntimeError as e:  # PF_E_NOCONV: "<solver> failed with code <iters>" (pyfem.py:2421-2422)
             raise RuntimeError(f"{method} failed with code {str(e).rsplit(' ', 1)[-1]}") from None
         self.last_iters, self.last_relres = it, rr
         return x if on_device else x.cpu().numpy()
 
-    def _direct_by_refinement(self, K, b):
+    def _direct_by_refinement(self, K, b, burst=None):
         """method="direct" on a symmetric K (pyfem.py:2414 calls spsolve): PCG to DIRECT_RTOL, restarted from the
         iterate reached whenever a run of DIRECT_BURST iterations ends above it.  A restart recomputes r = b - K x, so
         the recurrence residual cannot drift away from the true one (iterative refinement); ill-conditioned systems
@@ -878,7 +884,8 @@ class Assembler:
 
         hctx = K.hctx
         torch = hctx.torch
-        burst = DIRECT_BURST if self.precond == "amg" else 0  # Jacobi by request: scipy's default cap (10 n)
+        if burst is None:
+            burst = DIRECT_BURST if self.precond == "amg" else 0  # Jacobi by request: scipy's default cap (10 n)
         x, total, rr = None, 0, float("inf")
         with warnings.catch_warnings(record=True) as caught:
             warnings.simplefilter("always")
@@ -894,8 +901,14 @@ class Assembler:
             warnings.warn(w, RuntimeWarning, stacklevel=4)
         bn = float(torch.linalg.vector_norm(b))
         true_rr = float(torch.linalg.vector_norm(b - hctx.spmv(K.vals, x))) / bn if bn > 0 else 0.0
+        self.last_iters, self.last_relres = total, true_rr  # readable also when the solve is refused below
+        if self.direct_strict and not true_rr <= DIRECT_QUIET:
+            raise DirectSolveError(
+                f"direct failed with code {total}: strict mode accepts ||b - K x|| / ||b|| <= {DIRECT_QUIET:g}, PCG "
+                f"with refinement reached ||b - K x|| / ||b|| = {true_rr:.3e}; "
+                "scipy.sparse.linalg.spsolve(K, rhs) factorises the returned matrix on the host")
         if not np.isfinite(true_rr) or true_rr > DIRECT_ACCEPT:
-            raise RuntimeError(
+            raise DirectSolveError(
                 f"direct failed with code {total}: no factorisation is built on the device and PCG stopped at "
                 f"||b - K x|| / ||b|| = {true_rr:.3e} (the matrix may be indefinite or singular); "
                 "scipy.sparse.linalg.spsolve(K, rhs) factorises the returned matrix on the host")

@@ -7,6 +7,7 @@ device path behaves where it cannot do what scipy does (ADV
     ill-conditioned RAMP field and must fail with a message naming the residual on an indefinite matrix;
   * nodes no element references (pyfem.py:683-684) on a brick20 grid: Jacobi-PCG needs a diagonal for them.
 """
+import sys
 import warnings
 
 import numpy as np
@@ -117,6 +118,55 @@ def test_direct_on_an_indefinite_matrix_fails_with_the_residual(pf):
         else:  # CG may still converge on a mildly indefinite system: then the answer must be the right one
             r = Kbc.to_scipy() @ u - rhs_bc
             assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(rhs_bc)
+
+
+def test_direct_failure_message_reaches_the_caller_unchanged(pf, monkeypatch):
+    """the message of a failed method="direct" was caught by _solve_linear_system's own
+    `except RuntimeError` and rebuilt from its last word ("direct failed with code host").  Force the failure -- one
+    round of five PCG iterations cannot bring an indefinite 546-dof system to 1e-10 -- and assert on the text the
+    caller sees: the iterations spent, the true residual, the host alternative."""
+    import re
+
+    mod = sys.modules[pf.Assembler.__module__]
+    monkeypatch.setattr(mod, "DIRECT_ROUNDS", 1)
+    monkeypatch.setattr(mod, "DIRECT_BURST", 5)
+    model, (conn, X, dof_fixed, force) = _quad_model(pf, 20, 12, p=3.0)
+    rng = np.random.RandomState(5)
+    Kind = model.compute_jacobian(0.1 + 0.9 * rng.rand(X.shape[0])) - 3.0 * model.compute_jacobian(0.1 + 0.9 * rng.rand(X.shape[0]))
+    rhs = model.compute_rhs()
+    Kbc, rhs_bc = model.apply_dirichlet_bcs(Kind, rhs.copy())
+    asm = pf.Assembler(model)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with pytest.raises(RuntimeError) as ei:
+            asm._solve_linear_system(Kbc, rhs_bc, "direct")
+    msg = str(ei.value)
+    m = re.match(r"direct failed with code (\d+): .*\|\|b - K x\|\| / \|\|b\|\| = ([0-9.e+-]+|nan|inf) .*spsolve\(K, rhs\)", msg)
+    assert m, msg
+    assert 1 <= int(m.group(1)) <= 5
+    assert isinstance(ei.value, mod.DirectSolveError)
+    # the reached residual stays readable on the Assembler as well (ADVICE r2 low: callers that filter warnings)
+    assert asm.last_relres is not None and (not np.isfinite(asm.last_relres) or asm.last_relres > 1e-10)
+
+
+def test_direct_strict_restores_the_raise_above_the_quiet_level(pf, monkeypatch):
+    """Assembler.direct_strict = True: anything above DIRECT_QUIET raises instead of warning."""
+    mod = sys.modules[pf.Assembler.__module__]
+    monkeypatch.setattr(mod, "DIRECT_ROUNDS", 1)
+    monkeypatch.setattr(mod, "DIRECT_BURST", 12)
+    monkeypatch.setattr(mod, "DIRECT_ACCEPT", 1.0)  # so that only the strict rule can raise
+    model, _ = _quad_model(pf, 40, 30, p=3.0)
+    K = model.compute_jacobian(0.05 + 0.95 * np.random.RandomState(2).rand(model.nnodes))
+    rhs = model.compute_rhs()
+    K, rhs = model.apply_dirichlet_bcs(K, rhs)
+    asm = pf.Assembler(model)
+    asm.precond = "jacobi"
+    asm.direct_strict = True
+    monkeypatch.setattr(mod, "DIRECT_BURST", 12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        with pytest.raises(mod.DirectSolveError, match="strict"):
+            asm._direct_by_refinement(K, K.hctx.to_device(rhs, K.hctx.torch.float64), burst=12)
 
 
 def test_hip_errors_are_not_rewritten_as_convergence_failures(pf):
