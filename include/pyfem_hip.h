@@ -288,9 +288,9 @@ int pf_cgcg_update_ps(pf_ctx* ctx, const double* state_in, double* state_out, co
  *                          scal_out[0..ns) <- sum over all ranks of scal_in[0..ns)  (device pointers, ns <= PF_HALO_NSCAL)
  *        pf_halo_status:   synchronises; HOST out 1 if a wait timed out since creation (then every later exchange
  *                          returns at once and the results are garbage: the caller must raise)
- *        pf_dist_cg:       Chronopoulos-Gear single-reduction Jacobi-PCG over the partition, x0 = 0, entirely in C:
- *                          per iteration 3 compute launches + 1 exchange (interface sums of K z and the scalars
- *                          r.z, z.Kz, r.r); stops at ||r|| <= max(rtol ||b||, atol), read back every check_every
+ *        pf_dist_cg:       Chronopoulos-Gear single-reduction Jacobi-PCG over the partition, x0 = 0, entirely in C
+ *                          (interface sums of K z and the scalars r.z, z.Kz, r.r per iteration; see the fused
+ *                          exchange below); stops at ||r|| <= max(rtol ||b||, atol), read back every check_every
  *                          iterations.  dinv: inverse of the ASSEMBLED diagonal; own_w: 1 on the dofs this rank owns
  *                          (each dof owned once).  PF_E_NOCONV like pf_cg; PF_E_HIP if a peer never arrived.      */
 /* ---- the AMG hierarchy's pieces for a DISTRIBUTED finest level (dist.py; counterpart of the reference's pyamg
@@ -322,6 +322,12 @@ int pf_amg_p0_pattern(pf_ctx* ctx, int64_t* np_host, int64_t* nc_host, int32_t* 
 int pf_amg_prolong0_rows(pf_ctx* ctx, int64_t nl, const int32_t* grow, const double* x1, double* c_local);
 int pf_amg_restrict0_rows(pf_ctx* ctx, const int32_t* ltptr, const int32_t* ltnode, const int32_t* ltslot,
                           const double* res_local, double* b1);
+/* The same restriction streamed: pf_amg_p0_gather copies the caller's nlt entries of P0 (ltslot) into ltvals in transpose
+ * order (once per numeric setup; nlt * dofs * coarse dofs doubles), pf_amg_restrict0_stream walks (ltptr, ltnode,
+ * ltvals) like the single-GPU restriction walks its transposed copy -- 78 instead of 218 us on configuration 5.     */
+int pf_amg_p0_gather(pf_ctx* ctx, int64_t nlt, const int32_t* ltslot, double* ltvals);
+int pf_amg_restrict0_stream(pf_ctx* ctx, const int32_t* ltptr, const int32_t* ltnode, const double* ltvals,
+                            const double* res_local, double* b1);
 
 #define PF_HALO_NSCAL 8
 #define PF_HALO_HANDLE_BYTES 64
@@ -336,6 +342,25 @@ int pf_halo_exchange(pf_halo* halo, int plan, double* v, const double* scal_in, 
 int pf_halo_status(pf_halo* halo, int32_t* err_host);
 int pf_halo_set_timeout(pf_halo* halo, double seconds);
 int pf_halo_destroy(pf_halo* halo);
+/* FUSED exchange (round 3): the product kernel stores the rows of interface nodes into the neighbours' windows from its
+ * epilogue (interface tiles first, the interior while the rows travel) and the kernel that consumes the product sums
+ * them in ascending rank order -- no pack launch, no exchange launch.  pf_dist_cg and the smoother sweeps of
+ * pf_dist_pcg_amg run on it.
+ *   pf_halo_plan_fuse:     prepare plan `plan` (vectors with the context's dofs per node; 2-D models) for it: per-node
+ *                          sharer tables, the tile walk of the product, per-dof owner / interface flags from own_w
+ *                          (DEVICE, 1 on the dofs this rank owns).  Idempotent.  All fused plans of one window must
+ *                          have the same neighbour list.
+ *   pf_halo_fuse_get:      HOST copies of those tables (any output may be NULL); dims = {interface nodes, interface
+ *                          tiles, tiles, sharer entries, nodes per tile, dofs per node}.  Tests replay them.
+ *   pf_halo_set_colocated: how many ranks of the job run on this rank's device (1 in production; the tests rehearse
+ *                          several ranks on one GPU, where waiting kernels must leave room for the peers' kernels)
+ *   pf_dist_cg:            TWO launches per iteration: product + send, then scalars / wait / interface sums / fused
+ *                          vector update with the convergence test on the device (the result does not depend on
+ *                          check_every).  The plan must have been fused.                                            */
+int pf_halo_plan_fuse(pf_halo* halo, int plan, const double* own_w);
+int pf_halo_fuse_get(pf_halo* halo, int plan, int64_t* dims_host, int32_t* ifslot, int32_t* sh_ptr, int32_t* sh_peer,
+                     int32_t* sh_pos, int32_t* tperm, uint8_t* flags8);
+int pf_halo_set_colocated(pf_halo* halo, int nranks);
 int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
                const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
                int32_t* iters_host, double* relres_host);
@@ -346,7 +371,8 @@ int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const d
  *      vectors (window `halo`); plan_coarse: a plan on a second window, `halo_coarse`, over the level-1 vector, in which
  *      every rank sends the entries it contributes to to every other rank (dist.py builds both).  d1, d2: the finest level's Chebyshev-Jacobi factors on the rank's dofs
  *      (pf_amg_level0, gathered); grow / ltptr / ltnode / ltslot: as for pf_amg_prolong0_rows / pf_amg_restrict0_rows;
- *      n1: level-1 dofs.  work: 9 nrows_local + 2 n1 + 64 doubles of scratch.
+ *      n1: level-1 dofs.  work: 9 nrows_local + 2 n1 + 64 doubles of scratch.  The dof plan must have been prepared
+ *      with pf_halo_plan_fuse: every product sends its interface rows from its epilogue.
  *        pf_dist_vcycle:   z = M^-1 r (work: 4 nrows_local + 2 n1 doubles)
  *        pf_dist_pcg_amg:  single-reduction PCG, x0 = 0, stop and errors as pf_dist_cg                                   */
 typedef struct {
@@ -365,8 +391,12 @@ typedef struct {
   const int32_t* ltnode;
   const int32_t* ltslot;
   int64_t n1;
+  const float* K32;      /* fp32 copy of K for the cycle's products (pf_vals_to_f32), or NULL: the cycle reads K */
+  const double* ltvals;  /* the rank's entries of P0 in transpose order (pf_amg_p0_gather), or NULL: gathered through ltslot */
 } pf_dist_amg;
 int pf_dist_vcycle(const pf_dist_amg* a, const double* r, double* z, double* work);
+/* out[i] = (float) vals[i], i < n (device arrays): the fp32 operator copy the cycle's products read */
+int pf_vals_to_f32(pf_ctx* ctx, int64_t n, const double* vals, float* out);
 int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x, double* work, double rtol, double atol,
                     int maxiter, int check_every, int32_t* iters_host, double* relres_host);
 

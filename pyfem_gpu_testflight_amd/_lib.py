@@ -85,6 +85,8 @@ SIGNATURES = {
     "pf_amg_p0_pattern": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp]),
     "pf_amg_prolong0_rows": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "pf_amg_restrict0_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "pf_amg_p0_gather": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "pf_amg_restrict0_stream": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_vec_smooth": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "pf_halo_create": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.POINTER(_vp)]),
     "pf_halo_handle": (C.c_int, [_vp, _vp]),
@@ -94,9 +96,13 @@ SIGNATURES = {
     "pf_halo_status": (C.c_int, [_vp, C.POINTER(_i32)]),
     "pf_halo_set_timeout": (C.c_int, [_vp, _f64]),
     "pf_halo_destroy": (C.c_int, [_vp]),
+    "pf_halo_plan_fuse": (C.c_int, [_vp, C.c_int, _vp]),
+    "pf_halo_fuse_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pf_halo_set_colocated": (C.c_int, [_vp, C.c_int]),
     "pf_dist_cg": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32),
                              C.POINTER(_f64)]),
     "pf_dist_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pf_vals_to_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pf_dist_pcg_amg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
     "pf_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _f64, _f64, _f64, C.POINTER(_f64)]),
     "pf_hbm_probe": (C.c_int, [_vp, C.c_int, C.c_int, _i64, C.c_int, C.POINTER(_f64)]),
@@ -108,7 +114,7 @@ class DistAmgArgs(C.Structure):
     """pf_dist_amg of include/pyfem_hip.h."""
     _fields_ = [("local", _vp), ("global_", _vp), ("halo", _vp), ("halo_coarse", _vp), ("plan_dof", _i32), ("plan_coarse", _i32),
                 ("K", _vp), ("own_w", _vp), ("d1", _vp), ("d2", _vp), ("nl", _i64), ("grow", _vp), ("ltptr", _vp),
-                ("ltnode", _vp), ("ltslot", _vp), ("n1", _i64)]
+                ("ltnode", _vp), ("ltslot", _vp), ("n1", _i64), ("K32", _vp), ("ltvals", _vp)]
 
 
 _lib = None

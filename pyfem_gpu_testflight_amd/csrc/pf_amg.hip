@@ -1569,6 +1569,15 @@ __global__ void k_amg_to_f32(int64_t n, const double* __restrict__ a, float* __r
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = (float)a[i];
 }
 
+extern "C" int pf_vals_to_f32(pf_ctx* ctx, int64_t n, const double* vals, float* out) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(n >= 0 && vals && out, "pf_vals_to_f32: NULL argument");
+  if (n == 0) return PF_OK;
+  k_amg_to_f32<<<(unsigned)std::min<int64_t>(cdiv(n, 256), 8192), 256, 0, ctx->stream>>>(n, vals, out);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
 __global__ void k_amg_pow_init(int64_t n, double* __restrict__ v) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) v[i] = 1.0 + 0.37 * (double)((uint32_t)(i * 2654435761u) % 1000u) * 1e-3;  // fixed start vector
@@ -2094,6 +2103,34 @@ extern "C" int pf_amg_restrict0_rows(pf_ctx* ctx, const int32_t* ltptr, const in
   const unsigned g = (unsigned)cdiv(L0.nc, 256);
   if (L0.dr == 1) k_sa_restrict_rows<1, 1><<<g, 256, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltslot, L0.pvals, res_local, b1);
   else k_sa_restrict_rows<2, 3><<<g, 256, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltslot, L0.pvals, res_local, b1);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// The streamed form of the same restriction (r03: the one-thread-per-coarse-node kernel above took 218 us on
+// configuration 5's finest level against 78 us for the single-GPU k_sa_restrict_stream): the caller keeps ITS entries of
+// P0 in transpose order (pf_amg_p0_gather, once per numeric setup: np_local blocks) and they are streamed like ptvals.
+extern "C" int pf_amg_p0_gather(pf_ctx* ctx, int64_t nlt, const int32_t* ltslot, double* ltvals) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (int rc = amg_level0_sa(ctx, "pf_amg_p0_gather")) return rc;
+  PF_REQUIRE(nlt >= 0 && ltslot && ltvals, "pf_amg_p0_gather: NULL argument");
+  if (nlt == 0) return PF_OK;
+  AmgLevel& L0 = ctx->amg->L[0];
+  const int bs = L0.dr * ctx->amg->L[1].dr;
+  k_sa_transpose_vals<<<(unsigned)cdiv(nlt * bs, 256), 256, 0, ctx->stream>>>(nlt, bs, ltslot, L0.pvals, ltvals);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+extern "C" int pf_amg_restrict0_stream(pf_ctx* ctx, const int32_t* ltptr, const int32_t* ltnode, const double* ltvals,
+                                       const double* res_local, double* b1) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  if (int rc = amg_level0_sa(ctx, "pf_amg_restrict0_stream")) return rc;
+  PF_REQUIRE(ltptr && ltnode && ltvals && res_local && b1, "pf_amg_restrict0_stream: NULL argument");
+  AmgLevel& L0 = ctx->amg->L[0];
+  const unsigned g = (unsigned)std::min<int64_t>(cdiv(L0.nc, 64), 4096);
+  if (L0.dr == 1) k_sa_restrict_stream<1, 1><<<g, 64, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltvals, res_local, b1);
+  else k_sa_restrict_stream<2, 3><<<g, 64, 0, ctx->stream>>>(L0.nc, ltptr, ltnode, ltvals, res_local, b1);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -1,44 +1,45 @@
 // AMG-preconditioned PCG over the element-block partition, the whole loop in C (gfx950; no counterpart in the
 // reference, which is single process: its solve is pyfem.py:2393-2423, cg + pyamg V-cycle on one matrix).
 //
-// dist.py's dist_pcg_amg / ReplicatedHierarchy.vcycle is the same algorithm driven from Python (about 25 C-ABI calls, a
-// handful of torch scalar operations and one torch.distributed all-reduce per iteration); here the iteration is nothing
-// but kernel launches on the solver's stream, with BOTH exchanges -- the interface sums of the finest level and the
-// sum of the level-1 right-hand side over all ranks -- going through the peer-store windows of pf_halo.hip:
-//   per iteration   k_cgcg_update_xrz, the V-cycle, k_spmv (+ partials of z.Kz), k_finalize, k_dot, one exchange
-//                   (interface sums of w = K z with r.z, z.w, r.r riding along), k_cgcg_update_ps
-//   V-cycle         finest level on the rank's rows (four products with interface sums, Chebyshev-Jacobi sweeps as
-//                   pf_vec_smooth), restriction of the rows the rank owns (pf_amg_restrict0_rows), level-1 right-hand
-//                   side summed over ranks (exchange on the coarse plan), levels >= 1 redundantly on the replicated
-//                   hierarchy of the whole-mesh context (pf_amg_coarse_solve), prolongation to the rank's rows.
+// Round 3: built on the FUSED exchange (pf_halo.hip / pf_solve.hip).  Every product with the rank's matrix is ONE launch
+// that also sends the interface rows from its epilogue (interface tiles first); the Chebyshev-Jacobi sweeps and the
+// residual are epilogues of that product for all rows that are not on an interface -- exactly the single-GPU cycle's
+// launches -- and a small kernel over the interface entries (k_halo_recv_apply, skipped on a rank without neighbours)
+// finishes those once the neighbours' rows are there.  The cycle's products read an fp32 copy of the rank's matrix, as the
+// single-GPU cycle does (a->K32; NULL keeps fp64).
+//   per iteration   V-cycle, k_dot (own r.z), product + send (w = K z, partials of z.w), k_dcg_update (scalars to all ranks,
+//                   interface sums of w, p / s / x / r in one pass, convergence test on the device)
+//   V-cycle         finest level on the rank's rows: first sweep from zero, then [product+send, finish interface] x 2
+//                   (second sweep, residual), restriction of the rows the rank owns, level-1 right-hand side summed over
+//                   ranks (packed exchange on the coarse window), levels >= 1 redundantly on the replicated hierarchy
+//                   of the whole-mesh context, prolongation to the rank's rows, [product+send, finish] x 2 on the way up.
 // Two contexts take part: `local` (the rank's mesh block: K, the vectors, the halo) and `global` (the whole mesh: the
 // hierarchy); the caller binds both to one stream.
 #include "pf_common.h"
 
-static int dist_vcycle(const pf_dist_amg* a, const double* r, double* z, double* c, double* c2, double* w, double* t,
-                       double* b1, double* x1) {
+static int dist_vcycle(const pf_dist_amg* a, const double* r, double* z, double* c, double* c2, double* t, double* b1,
+                       double* x1) {
   pf_ctx* L = a->local;
   pf_ctx* G = a->global;
   const int64_t n = (int64_t)L->d * L->nnodes;
   int rc;
 #define STEP(call) do { if ((rc = (call))) return rc; } while (0)
+  // product with the smoother epilogue on the rows off the interface, raw rows on it (sent), then the interface entries
+  auto sweep = [&](const double* xin, const double* d, double* out) -> int {
+    if (int e = pf_dist_product(L, a->halo, a->plan_dof, a->K, a->K32, xin, out, false, d, r, nullptr)) return e;
+    return pf_halo_recv_apply(a->halo, a->plan_dof, xin, d, r, out);
+  };
   STEP(pf_vec_smooth(L, n, nullptr, a->d1, r, nullptr, c));            // first sweep from a zero guess
-  STEP(pf_spmv(L, a->K, c, w));
-  STEP(pf_halo_exchange_impl(a->halo, a->plan_dof, w, nullptr, 0, nullptr));
-  STEP(pf_vec_smooth(L, n, c, a->d2, r, w, c2));                       // second sweep (second Chebyshev factor)
-  STEP(pf_spmv(L, a->K, c2, w));
-  STEP(pf_halo_exchange_impl(a->halo, a->plan_dof, w, nullptr, 0, nullptr));
-  STEP(pf_vec_smooth(L, n, nullptr, nullptr, r, w, t));                // residual
-  STEP(pf_amg_restrict0_rows(G, a->ltptr, a->ltnode, a->ltslot, t, b1));
-  STEP(pf_halo_exchange_impl(a->halo_coarse, a->plan_coarse, b1, nullptr, 0, nullptr));  // level-1 right-hand side over all ranks
+  STEP(sweep(c, a->d2, c2));                                           // second sweep (second Chebyshev factor)
+  STEP(sweep(c2, nullptr, t));                                         // residual t = r - K c2
+  if (a->ltvals) STEP(pf_amg_restrict0_stream(G, a->ltptr, a->ltnode, a->ltvals, t, b1));
+  else STEP(pf_amg_restrict0_rows(G, a->ltptr, a->ltnode, a->ltslot, t, b1));
+  if (pf_halo_world(a->halo_coarse) > 1)  // level-1 right-hand side summed over all ranks
+    STEP(pf_halo_exchange_impl(a->halo_coarse, a->plan_coarse, b1, nullptr, 0, nullptr));
   STEP(pf_amg_coarse_solve(G, b1, x1));
   STEP(pf_amg_prolong0_rows(G, a->nl, a->grow, x1, c2));               // c2 += P x1
-  STEP(pf_spmv(L, a->K, c2, w));
-  STEP(pf_halo_exchange_impl(a->halo, a->plan_dof, w, nullptr, 0, nullptr));
-  STEP(pf_vec_smooth(L, n, c2, a->d2, r, w, c));                       // post-smoothing in reverse order: symmetric cycle
-  STEP(pf_spmv(L, a->K, c, w));
-  STEP(pf_halo_exchange_impl(a->halo, a->plan_dof, w, nullptr, 0, nullptr));
-  STEP(pf_vec_smooth(L, n, c, a->d1, r, w, z));
+  STEP(sweep(c2, a->d2, c));                                           // post-smoothing in reverse order: symmetric cycle
+  STEP(sweep(c, a->d1, z));
 #undef STEP
   return PF_OK;
 }
@@ -48,8 +49,9 @@ extern "C" int pf_dist_vcycle(const pf_dist_amg* a, const double* r, double* z, 
   pf_ctx* ctx = a->local;
   PF_REQUIRE(a->global && a->halo && a->halo_coarse && r && z && work && r != z, "pf_dist_vcycle: NULL argument");
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
-  double *c = work, *c2 = c + n, *w = c2 + n, *t = w + n, *b1 = t + n, *x1 = b1 + a->n1;
-  return dist_vcycle(a, r, z, c, c2, w, t, b1, x1);
+  double *c = work, *c2 = c + n, *t = c2 + 2 * n, *b1 = t + n, *x1 = b1 + a->n1;
+  PF_REQUIRE(pf_halo_fuse_of(a->halo, a->plan_dof), "pf_dist_vcycle: the dof plan was not prepared (pf_halo_plan_fuse)");
+  return dist_vcycle(a, r, z, c, c2, t, b1, x1);
 }
 
 extern "C" int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x, double* work, double rtol, double atol,
@@ -62,14 +64,15 @@ extern "C" int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x,
                  a->ltslot && b && x && work && a->n1 > 0 && a->nl == ctx->nnodes,
              "pf_dist_pcg_amg: incomplete arguments");
   PF_REQUIRE(a->global->stream == ctx->stream, "pf_dist_pcg_amg: bind both contexts to one stream (pf_ctx_set_stream)");
+  PF_REQUIRE(pf_halo_fuse_of(a->halo, a->plan_dof), "pf_dist_pcg_amg: the dof plan was not prepared (pf_halo_plan_fuse)");
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
   if (check_every <= 0) check_every = 1;
-  // work: r z w p s | c c2 wv t | b1 x1 | 64 small
+  // work: r z w p s | c c2 (unused) t | b1 x1 | 64 small
   double *r = work, *z = r + n, *w = z + n, *p = w + n, *s = p + n;
-  double *c = s + n, *c2 = c + n, *wv = c2 + n, *t = wv + n, *b1 = t + n, *x1 = b1 + a->n1, *small = x1 + a->n1;
-  double *stA = small, *stB = small + 8, *red = small + 16, *redg = small + 24, *g = small + 32;
+  double *c = s + n, *c2 = c + n, *t = c2 + 2 * n, *b1 = t + n, *x1 = b1 + a->n1, *small = x1 + a->n1;
+  double *stA = small, *stB = small + 8, *red = small + 16, *redg = small + 24;
   hipStream_t st = ctx->stream;
   PF_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, st));
   PF_HIP(hipMemsetAsync(p, 0, sizeof(double) * 2 * n, st));
@@ -86,31 +89,37 @@ extern "C" int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x,
   if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the halo exchange (timeout)");
   const double bnorm = sqrt(h[0]);
   const double tol = std::max(rtol * bnorm, atol);
+  PF_HIP(hipMemsetAsync(redg, 0, sizeof(double) * 8, st));
   double rnorm = INFINITY;
   int it = 0;
   double *state = stA, *state_next = stB;
-  while (it < maxiter) {
-    if ((rc = pf_cgcg_update_xrz(ctx, state, p, s, nullptr, a->own_w, x, r, t))) return rc;  // x += alpha p; r -= alpha s
-    if ((rc = dist_vcycle(a, r, z, c, c2, wv, t, b1, x1))) return rc;                          // z = M^-1 r
-    if ((rc = pf_spmv_dot(ctx, a->K, z, w))) return rc;                                        // w = K z, partials of z.w
-    if ((rc = pf_cgcg_reduce(ctx, red, nullptr, 0))) return rc;                                // [., delta, rr]
-    if ((rc = pf_dot(ctx, n, r, z, a->own_w, g))) return rc;                                   // gamma = r.z over owned dofs
-    PF_HIP(hipMemcpyAsync(red, g, sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = pf_halo_exchange_impl(a->halo, a->plan_dof, w, red, 3, redg))) return rc;
-    if (it % check_every == 0 || it + 1 == maxiter) {
-      PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
-      PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(a->halo), sizeof(herr), hipMemcpyDeviceToHost, st));
-      PF_HIP(hipStreamSynchronize(st));
-      if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the halo exchange (timeout)");
-      PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(a->halo_coarse), sizeof(herr), hipMemcpyDeviceToHost, st));
-      PF_HIP(hipStreamSynchronize(st));
-      if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the level-1 exchange (timeout)");
-      rnorm = sqrt(h[2]);
-      if (!(rnorm == rnorm) || rnorm <= tol) break;
+  // partials of own r.r for the first reduction (zeroed state: x, r unchanged; the z it writes is overwritten by the cycle)
+  if ((rc = pf_dist_init_partials(ctx, state, p, s, nullptr, a->own_w, x, r, z))) return rc;
+  bool stopped = false;
+  while (it < maxiter && !stopped) {
+    const int burst = std::min(check_every - it % check_every, maxiter - it);
+    for (int k = 0; k < burst; ++k, ++it) {
+      if ((rc = dist_vcycle(a, r, z, c, c2, t, b1, x1))) return rc;                              // z = M^-1 r
+      if ((rc = pf_dist_dot_gamma(ctx, r, z, a->own_w))) return rc;                              // partials of own r.z
+      if ((rc = pf_dist_product(ctx, a->halo, a->plan_dof, a->K, nullptr, z, w, true, nullptr, nullptr, redg + 3))) return rc;
+      if ((rc = pf_dist_update(ctx, a->halo, a->plan_dof, w, nullptr, true, true, it == 0, x, r, z, p, s, state, state_next, redg,
+                               it == 0, tol * tol, it)))
+        return rc;
+      std::swap(state, state_next);
     }
-    if ((rc = pf_cgcg_update_ps(ctx, state, state_next, redg, it == 0, z, w, p, s))) return rc;
-    std::swap(state, state_next);
-    ++it;
+    PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    int32_t herr1 = 0;
+    PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(a->halo), sizeof(herr), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&herr1, pf_halo_err_ptr(a->halo_coarse), sizeof(herr1), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));  // one synchronisation per read-back
+    if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the fused exchange (timeout)");
+    if (herr1) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the level-1 exchange (timeout)");
+    rnorm = sqrt(h[2]);
+    if (h[3] != 0.0) {  // converged on the device after h[4] updates
+      it = (int)h[4];
+      stopped = true;
+    }
+    if (!(rnorm == rnorm)) break;
   }
   if (iters_host) *iters_host = it;
   if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;

@@ -16,54 +16,27 @@
 //     ASCENDING RANK ORDER -- every rank that shares a dof forms the same sum of the same operands, so interface copies
 //     stay bitwise identical on all ranks -- and reduce the scalars the same way (a deterministic all-reduce without a
 //     collective).
-//   ONE launch per exchange on the solver's stream (at most 8 * 16 + 256 workgroups: senders and receivers are resident
-//   together), nothing on the host: the whole CG loop (pf_dist_cg) is a sequence of kernel launches from C.
+//   ONE launch per exchange on the solver's stream (at most PF_HALO_MAXWORLD * 16 + 256 workgroups: senders and
+//   receivers are resident together), nothing on the host.
 //
 // Synchronisation: exchanges are numbered (seq = 1, 2, ...; SPMD, every rank issues the same sequence).  Message
 // buffers are double-buffered by seq parity.  A sender may run at most one exchange ahead of a receiver (it needs
 // the receiver's message of exchange k to finish k itself), so parity k is never overwritten before it was read.
 //
-// Window layout (doubles; identical on every rank, so a sender needs no table of its peers):
-//   flag[world] (uint64) | scal[2][world][PF_HALO_NSCAL] | recv[2][world][cap]
+// Window layout: pf_common.h (flags | scalar slots | message slots, each twice: packed and fused protocol).
 // `cap` = the largest message any rank sends to one neighbour in any plan (agreed on the host).
+//
+// FUSED exchange (round 3; pf_solve.hip k_spmv<..., SEND> and k_dcg_update / k_halo_recv_apply below): the product
+// kernel itself stores the rows of interface nodes into the neighbours' windows from its epilogue -- interface tiles are
+// walked first, so the rows travel while the interior tiles are computed, and there is no pack launch -- and the kernel
+// that consumes the product waits for the flags, sums in ascending rank order and goes on with its own work (CG update,
+// smoother sweep).  A CG iteration over the partition is TWO launches.  The fused protocol has its own slots, flags and
+// sequence numbers (rseq for rows, sseq for scalars).  Slot reuse: a rank starts row message j+1 only after its
+// consumer of message j has finished, and that consumer waited for message j of every NEIGHBOUR, each of which had
+// finished consuming j-1 before it sent j: so parity (j+1)&1 is free at every neighbour.  This needs every fused plan of
+// a window to have the same neighbour list (checked in pf_halo_plan_fuse).  Scalar messages go to every rank and their
+// consumers wait for every rank: the same argument with "neighbour" replaced by "rank".
 #include "pf_common.h"
-
-#define PF_HALO_MAXPLANS 8
-
-struct pf_halo_plan {
-  int nnbr = 0;
-  int64_t max_msg = 0;           // largest message of the plan (doubles)
-  int32_t* nbr = nullptr;        // (nnbr) neighbour ranks, ascending                        [device]
-  int32_t* nbr_ptr = nullptr;    // (nnbr+1) offsets into send_idx                           [device]
-  int32_t* send_idx = nullptr;   // local vector index of every packed value                 [device]
-  int64_t n_if = 0;              // interface entries of this rank
-  int32_t* if_idx = nullptr;     // (n_if) local vector index                                [device]
-  int32_t* src_ptr = nullptr;    // (n_if+1) CSR over the contributing ranks of each entry   [device]
-  int32_t* src_off = nullptr;    // rank * cap + position in that rank's message; -1 = this rank's own value [device]
-};
-
-struct pf_halo {
-  pf_ctx* ctx = nullptr;
-  int world = 0, rank = 0;
-  int64_t cap = 0;               // doubles per (sender, parity) message slot
-  size_t win_bytes = 0;
-  double* win = nullptr;         // this rank's window (fine-grained device memory)
-  double** peer_win = nullptr;   // (world) device array of mapped window base pointers (own entry = win)
-  std::vector<void*> mapped;     // host copies for hipIpcCloseMemHandle
-  int32_t* err = nullptr;        // device flag: 1 after a wait timed out (every later wait gives up at once)
-  uint32_t* done = nullptr;      // (world) workgroups that finished a peer's message in the current send
-  unsigned long long* sent = nullptr;  // send workgroups that have finished READING the vector, over all exchanges so far
-  unsigned long long sent_target = 0;  // its value once every send workgroup of the exchanges issued so far is through
-  uint64_t seq = 0;
-  long long timeout_ticks = 1000000000LL;  // 10 s of the 100 MHz wall clock: ranks reach their first exchange skewed by
-                                           // their own setup (pattern, hierarchy, code-object load)
-  pf_halo_plan plans[PF_HALO_MAXPLANS];
-  int nplans = 0;
-};
-
-__host__ __device__ static inline size_t halo_flag_doubles(int world) { return (size_t)((world + 7) & ~7); }
-__host__ __device__ static inline size_t halo_scal_off(int world) { return halo_flag_doubles(world); }
-__host__ __device__ static inline size_t halo_recv_off(int world) { return halo_scal_off(world) + (size_t)2 * world * PF_HALO_NSCAL; }
 
 // NB workgroups per peer (NB = gridDim.y): scalars to every peer, the packed values to the neighbours of the plan; the
 // workgroup that finishes a peer's message last raises that peer's flag (counted in done[peer], which it resets)
@@ -161,7 +134,8 @@ __device__ __forceinline__ void halo_recv(int rb, int nrb, int world, int rank, 
 }
 
 // ONE launch per exchange: the first world * nparts workgroups send, the rest receive.  The launch is far smaller than
-// the device (at most 8 * 16 + 256 workgroups), so senders and receivers are resident together; a receiver waits for the
+// the device (at most PF_HALO_MAXWORLD * 16 + 256 = 1280 workgroups of 256 threads: five per compute unit), so senders
+// and receivers are resident together; a receiver waits for the
 // flags of all ranks AND for this rank's own senders to have read the vector before it overwrites interface entries.
 __global__ __launch_bounds__(256) void k_halo_xchg(int nparts, int world, int rank, int64_t cap, double* const* __restrict__ peer_win,
                                                    int nnbr, const int32_t* __restrict__ nbr, const int32_t* __restrict__ nbr_ptr,
@@ -183,14 +157,15 @@ __global__ __launch_bounds__(256) void k_halo_xchg(int nparts, int world, int ra
 
 extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doubles, pf_halo** out) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
-  PF_REQUIRE(out && world >= 1 && world <= 256 && rank >= 0 && rank < world && cap_doubles >= 0, "pf_halo_create: bad arguments");
+  PF_REQUIRE(out && world >= 1 && world <= PF_HALO_MAXWORLD && rank >= 0 && rank < world && cap_doubles >= 0,
+             "pf_halo_create: bad arguments (at most 64 ranks: one node)");
   PF_HIP(hipSetDevice(ctx->device));
   pf_halo* h = new pf_halo();
   h->ctx = ctx;
   h->world = world;
   h->rank = rank;
   h->cap = (cap_doubles + 7) & ~(int64_t)7;
-  h->win_bytes = (halo_recv_off(world) + (size_t)2 * world * h->cap) * sizeof(double);
+  h->win_bytes = halo_win_doubles(world, h->cap) * sizeof(double);
   // fine-grained: stores from a peer GPU and the flag that follows them become visible to a running kernel here
   hipError_t e = hipExtMallocWithFlags((void**)&h->win, h->win_bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
@@ -209,6 +184,8 @@ extern "C" int pf_halo_create(pf_ctx* ctx, int world, int rank, int64_t cap_doub
   PF_HIP(hipMemset(h->done, 0, sizeof(uint32_t) * world));
   PF_HIP(hipMalloc((void**)&h->sent, sizeof(unsigned long long)));
   PF_HIP(hipMemset(h->sent, 0, sizeof(unsigned long long)));
+  PF_HIP(hipMalloc((void**)&h->rows_done, sizeof(unsigned long long)));
+  PF_HIP(hipMemset(h->rows_done, 0, sizeof(unsigned long long)));
   // hipMemset of device memory may return before it ran: a peer's first flag must not be zeroed by a late memset
   PF_HIP(hipDeviceSynchronize());
   *out = h;
@@ -282,6 +259,10 @@ extern "C" int pf_halo_plan_create(pf_halo* h, int nnbr, const int32_t* nbr_rank
   if ((rc = halo_upload(ctx, if_idx, n_if, P.if_idx))) return rc;
   if ((rc = halo_upload(ctx, src_ptr, n_if ? n_if + 1 : 0, P.src_ptr))) return rc;
   if ((rc = halo_upload(ctx, off.data(), nsrc, P.src_off))) return rc;
+  P.h_nbr.assign(nbr_rank, nbr_rank + nnbr);
+  P.h_nbr_ptr.assign(nbr_ptr, nbr_ptr + (nnbr ? nnbr + 1 : 0));
+  P.h_send_idx.assign(send_idx, send_idx + (nnbr ? nbr_ptr[nnbr] : 0));
+  P.h_if_idx.assign(if_idx, if_idx + n_if);
   *plan_id = h->nplans++;
   return PF_OK;
 }
@@ -295,17 +276,20 @@ int pf_halo_exchange_impl(pf_halo* h, int plan, double* v, const double* scal_in
     PF_REQUIRE(p == h->rank || h->mapped[p], "pf_halo_exchange: not every peer's window is connected (pf_halo_connect)");
   static const pf_halo_plan none;
   const pf_halo_plan& P = plan >= 0 ? h->plans[plan] : none;
-  const uint64_t seq = ++h->seq;
+  const uint64_t seq = h->seq + 1;
   // interface rows of a strip (4 K doubles) go through one workgroup per peer; the level-1 right-hand side of the AMG
   // cycle (~100 K doubles per peer) through up to 16
   const unsigned nparts = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.max_msg, 8192), 16));
   const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(P.n_if, 256), 256));
-  h->sent_target += (unsigned long long)h->world * nparts;
+  const unsigned long long target = h->sent_target + (unsigned long long)h->world * nparts;
   k_halo_xchg<<<h->world * nparts + g, 256, 0, ctx->stream>>>((int)nparts, h->world, h->rank, h->cap, h->peer_win, P.nnbr, P.nbr,
                                                               P.nbr_ptr, P.send_idx, v, scal_in, ns, seq, h->done, h->sent,
-                                                              h->sent_target, h->win, P.n_if, P.if_idx, P.src_ptr, P.src_off,
+                                                              target, h->win, P.n_if, P.if_idx, P.src_ptr, P.src_off,
                                                               scal_out, h->err, h->timeout_ticks);
   PF_LAUNCH_CHECK();
+  // only a launch that was accepted advances the sequence: a failed one must not leave this rank ahead of its peers
+  h->seq = seq;
+  h->sent_target = target;
   return PF_OK;
 }
 
@@ -330,6 +314,220 @@ extern "C" int pf_halo_set_timeout(pf_halo* h, double seconds) {
   return PF_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// fused exchange: tables (once per plan) and the per-launch argument blocks
+// ------------------------------------------------------------------------------------------
+extern "C" int pf_halo_plan_fuse(pf_halo* h, int plan, const double* own_w) {
+  if (!h) return pf_fail(nullptr, PF_E_INVALID, "halo is NULL");
+  pf_ctx* ctx = h->ctx;
+  PF_REQUIRE(plan >= 0 && plan < h->nplans && own_w, "pf_halo_plan_fuse: bad plan / NULL ownership weights");
+  PF_REQUIRE(ctx->d == 1 || ctx->d == 2, "pf_halo_plan_fuse: the fused product exists for 1 and 2 dofs per node (2-D models)");
+  PF_HIP(hipSetDevice(ctx->device));
+  pf_halo_plan& P = h->plans[plan];
+  pf_halo_fuse& F = P.fuse;
+  if (F.d) return PF_OK;  // already fused
+  const int d = ctx->d;
+  const int64_t nn = ctx->nnodes, n = nn * d;
+  // every fused plan of a window must talk to the same neighbours (slot-reuse argument in the header comment)
+  if (h->fuse_nbr.empty() && h->rseq == 0) h->fuse_nbr = P.h_nbr;
+  PF_REQUIRE(h->fuse_nbr == P.h_nbr, "pf_halo_plan_fuse: the fused plans of one window must share their neighbour list");
+  // node-level view of the packed messages: d consecutive entries per node, node-aligned
+  std::vector<int32_t> ifslot((size_t)nn, -1);
+  std::vector<int32_t> ifnodes;
+  for (int64_t i = 0; i < (int64_t)P.h_if_idx.size(); ++i) {
+    const int32_t node = P.h_if_idx[i] / d;
+    PF_REQUIRE(node >= 0 && node < nn, "pf_halo_plan_fuse: interface entry outside the context's vectors");
+    if (ifslot[node] < 0) { ifslot[node] = 0; ifnodes.push_back(node); }
+  }
+  PF_REQUIRE((int64_t)ifnodes.size() * d == (int64_t)P.h_if_idx.size(),
+             "pf_halo_plan_fuse: the plan does not move d entries per node (a nodal plan on a dof context cannot be fused)");
+  std::sort(ifnodes.begin(), ifnodes.end());
+  for (size_t s = 0; s < ifnodes.size(); ++s) ifslot[ifnodes[s]] = (int32_t)s;
+  std::vector<int32_t> cnt(ifnodes.size() + 1, 0);
+  for (int k = 0; k < P.nnbr; ++k) {
+    const int32_t b = P.h_nbr_ptr[k], e = P.h_nbr_ptr[k + 1];
+    PF_REQUIRE((e - b) % d == 0, "pf_halo_plan_fuse: a message is not a whole number of nodes");
+    for (int32_t i = b; i < e; i += d) {
+      const int32_t v = P.h_send_idx[i];
+      PF_REQUIRE(v % d == 0 && v / d < nn && ifslot[v / d] >= 0, "pf_halo_plan_fuse: packed entry is not a node of the interface");
+      for (int j = 1; j < d; ++j) PF_REQUIRE(P.h_send_idx[i + j] == v + j, "pf_halo_plan_fuse: the entries of a node are not consecutive");
+      ++cnt[ifslot[v / d] + 1];
+    }
+  }
+  for (size_t s = 0; s < ifnodes.size(); ++s) cnt[s + 1] += cnt[s];
+  std::vector<int32_t> sh_peer((size_t)std::max<int32_t>(cnt.back(), 1)), sh_pos(sh_peer.size()), fill(cnt.begin(), cnt.end() - 1);
+  for (int k = 0; k < P.nnbr; ++k)  // neighbours ascending => every node's sharers come out in ascending rank order
+    for (int32_t i = P.h_nbr_ptr[k]; i < P.h_nbr_ptr[k + 1]; i += d) {
+      const int32_t slot = fill[ifslot[P.h_send_idx[i] / d]]++;
+      sh_peer[slot] = P.h_nbr[k];
+      sh_pos[slot] = i - P.h_nbr_ptr[k];
+    }
+  // tile walk: interface tiles first (their rows are sent while the interior is computed), the rest in the context's order
+  const int tn = d == 1 ? PF_SPMV_TILE1 : PF_SPMV_TILE2;
+  const int64_t nt = cdiv(nn, tn);
+  std::vector<int32_t> base((size_t)nt);
+  if (ctx->spmv_perm) PF_HIP(hipMemcpy(base.data(), ctx->spmv_perm, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+  else for (int64_t t = 0; t < nt; ++t) base[t] = (int32_t)t;
+  std::vector<uint8_t> has((size_t)nt, 0);
+  for (int32_t node : ifnodes) has[node / tn] = 1;
+  std::vector<int32_t> tperm;
+  tperm.reserve((size_t)nt);
+  for (int64_t t = 0; t < nt; ++t) if (has[base[t]]) tperm.push_back(base[t]);
+  const int32_t n_iftiles = (int32_t)tperm.size();
+  for (int64_t t = 0; t < nt; ++t) if (!has[base[t]]) tperm.push_back(base[t]);
+  // per-dof flags: bit 0 owned (own_w != 0), bit 1 on an interface
+  std::vector<double> ow((size_t)n);
+  PF_HIP(hipMemcpy(ow.data(), own_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> flags((size_t)n + 8, 0);
+  for (int64_t i = 0; i < n; ++i) flags[i] = ow[i] != 0.0 ? 1 : 0;
+  for (int32_t v : P.h_if_idx) flags[v] |= 2;
+  int rc;
+  if ((rc = halo_upload(ctx, ifslot.data(), nn, F.ifslot))) return rc;
+  if ((rc = halo_upload(ctx, cnt.data(), (int64_t)cnt.size(), F.sh_ptr))) return rc;
+  if ((rc = halo_upload(ctx, sh_peer.data(), (int64_t)sh_peer.size(), F.sh_peer))) return rc;
+  if ((rc = halo_upload(ctx, sh_pos.data(), (int64_t)sh_pos.size(), F.sh_pos))) return rc;
+  if ((rc = halo_upload(ctx, tperm.data(), nt, F.tperm))) return rc;
+  if ((rc = halo_upload(ctx, flags.data(), (int64_t)flags.size(), F.flags8))) return rc;
+  F.n_ifnodes = (int64_t)ifnodes.size();
+  F.n_iftiles = n_iftiles;
+  F.tile_nodes = tn;
+  F.d = d;
+  return PF_OK;
+}
+
+// HOST copies of a fused plan's tables (tests replay them: tests/test_dist_cpu.py, tests/test_gpu_dist.py).  Any output
+// may be NULL; dims_host = {n_ifnodes, n_iftiles, ntiles, nsharers, tile_nodes, d}.
+extern "C" int pf_halo_fuse_get(pf_halo* h, int plan, int64_t* dims_host, int32_t* ifslot, int32_t* sh_ptr, int32_t* sh_peer,
+                                int32_t* sh_pos, int32_t* tperm, uint8_t* flags8) {
+  if (!h) return pf_fail(nullptr, PF_E_INVALID, "halo is NULL");
+  pf_ctx* ctx = h->ctx;
+  PF_REQUIRE(plan >= 0 && plan < h->nplans && h->plans[plan].fuse.d, "pf_halo_fuse_get: the plan is not fused");
+  const pf_halo_fuse& F = h->plans[plan].fuse;
+  const int64_t nt = cdiv(ctx->nnodes, F.tile_nodes);
+  int32_t nsh = 0;
+  PF_HIP(hipMemcpy(&nsh, F.sh_ptr + F.n_ifnodes, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (dims_host) { dims_host[0] = F.n_ifnodes; dims_host[1] = F.n_iftiles; dims_host[2] = nt; dims_host[3] = nsh; dims_host[4] = F.tile_nodes; dims_host[5] = F.d; }
+  if (ifslot) PF_HIP(hipMemcpy(ifslot, F.ifslot, sizeof(int32_t) * (size_t)ctx->nnodes, hipMemcpyDeviceToHost));
+  if (sh_ptr) PF_HIP(hipMemcpy(sh_ptr, F.sh_ptr, sizeof(int32_t) * (size_t)(F.n_ifnodes + 1), hipMemcpyDeviceToHost));
+  if (sh_peer && nsh) PF_HIP(hipMemcpy(sh_peer, F.sh_peer, sizeof(int32_t) * (size_t)nsh, hipMemcpyDeviceToHost));
+  if (sh_pos && nsh) PF_HIP(hipMemcpy(sh_pos, F.sh_pos, sizeof(int32_t) * (size_t)nsh, hipMemcpyDeviceToHost));
+  if (tperm) PF_HIP(hipMemcpy(tperm, F.tperm, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+  if (flags8) PF_HIP(hipMemcpy(flags8, F.flags8, (size_t)(ctx->nnodes * F.d), hipMemcpyDeviceToHost));
+  return PF_OK;
+}
+
+const pf_halo_fuse* pf_halo_fuse_of(pf_halo* h, int plan) {
+  return (h && plan >= 0 && plan < h->nplans && h->plans[plan].fuse.d) ? &h->plans[plan].fuse : nullptr;
+}
+
+int pf_halo_fused_send(pf_halo* h, int plan, pf_spmv_send* out) {
+  pf_ctx* ctx = h->ctx;
+  PF_REQUIRE(plan >= 0 && plan < h->nplans && h->plans[plan].fuse.d, "fused exchange: the plan was not prepared (pf_halo_plan_fuse)");
+  for (int p = 0; p < h->world; ++p)
+    PF_REQUIRE(p == h->rank || h->mapped[p], "fused exchange: not every peer's window is connected (pf_halo_connect)");
+  const pf_halo_plan& P = h->plans[plan];
+  const uint64_t rseq = h->rseq + 1;
+  out->ifslot = P.fuse.ifslot;
+  out->sh_ptr = P.fuse.sh_ptr;
+  out->sh_peer = P.fuse.sh_peer;
+  out->sh_pos = P.fuse.sh_pos;
+  out->peer_win = h->peer_win;
+  out->nbr = P.nbr;
+  out->stop = nullptr;
+  out->rows_done = h->rows_done;
+  out->rseq = rseq;
+  out->slot_off = (int64_t)(halo_recv2_off(h->world, h->cap) + ((size_t)(rseq & 1) * h->world + h->rank) * h->cap);
+  out->rflag_off = (int64_t)(halo_rflag_off(h->world) + h->rank);
+  out->n_iftiles = P.fuse.n_iftiles;
+  out->nnbr = P.nnbr;
+  return PF_OK;
+}
+
+void pf_halo_fused_sent(pf_halo* h, int plan) {
+  (void)plan;
+  ++h->rseq;
+}
+
+void pf_halo_fused_recv(pf_halo* h, int plan, bool scalars, pf_halo_recv* out) {
+  static const pf_halo_plan none;
+  const pf_halo_plan& P = plan >= 0 ? h->plans[plan] : none;
+  out->win = h->win;
+  out->peer_win = h->peer_win;
+  out->nbr = P.nbr;
+  out->if_idx = P.if_idx;
+  out->src_ptr = P.src_ptr;
+  out->src_off = P.src_off;
+  out->err = h->err;
+  out->timeout_ticks = h->timeout_ticks;
+  out->n_if = P.n_if;
+  out->cap = h->cap;
+  out->rseq = plan >= 0 ? h->rseq : 0;
+  out->sseq = scalars ? h->sseq + 1 : 0;
+  out->world = h->world;
+  out->rank = h->rank;
+  out->nnbr = P.nnbr;
+}
+
+void pf_halo_fused_scal(pf_halo* h) { ++h->sseq; }
+
+// The receiving half of a fused exchange WITHOUT scalars, for the smoother sweeps of the distributed AMG cycle: the
+// product left the raw rows of the interface entries in y (and in the neighbours' windows); this finishes them,
+//   y[i] = x[i] + d[i] (b[i] - sum)      (d == NULL: y = b - sum;  b == NULL as well: y = sum)
+// with the sum over the sharing ranks in ascending rank order -- the same bits on every sharer.
+__global__ __launch_bounds__(256) void k_halo_recv_apply(pf_halo_recv rc, const double* __restrict__ x, const double* __restrict__ d,
+                                                         const double* __restrict__ b, double* __restrict__ y) {
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = *rc.err;
+  __syncthreads();
+  if ((int)threadIdx.x < rc.nnbr && !bad) {
+    const uint64_t* flag = reinterpret_cast<const uint64_t*>(rc.win) + halo_rflag_off(rc.world) + rc.nbr[threadIdx.x];
+    if (pf_wait_flag(flag, rc.rseq, rc.timeout_ticks)) bad = 1;
+  }
+  __syncthreads();
+  if (bad) {
+    if (threadIdx.x == 0) *rc.err = 1;
+    return;
+  }
+  const double* recv = rc.win + halo_recv2_off(rc.world, rc.cap) + (size_t)(rc.rseq & 1) * rc.world * rc.cap;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rc.n_if; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t li = rc.if_idx[i];
+    const double own = y[li];
+    double s = 0.0;
+    for (int32_t k = rc.src_ptr[i]; k < rc.src_ptr[i + 1]; ++k) {
+      const int32_t o = rc.src_off[k];
+      s += (o < 0) ? own : pf_ld_sys_f64(recv + o);
+    }
+    if (b) s = b[li] - s;
+    if (d) s = x[li] + d[li] * s;
+    y[li] = s;
+  }
+}
+
+int pf_halo_recv_apply(pf_halo* h, int plan, const double* x, const double* d, const double* b, double* y) {
+  pf_ctx* ctx = h->ctx;
+  const pf_halo_plan& P = h->plans[plan];
+  if (P.n_if == 0) return PF_OK;  // a rank without neighbours (one-rank runs): nothing to finish, no launch
+  pf_halo_recv rc;
+  pf_halo_fused_recv(h, plan, false, &rc);
+  const unsigned g = (unsigned)std::min<int64_t>(cdiv(P.n_if, 256), 64);
+  k_halo_recv_apply<<<g, 256, 0, ctx->stream>>>(rc, x, d, b, y);
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+int pf_halo_colocated(pf_halo* h) { return h->colocated; }
+int pf_halo_world(pf_halo* h) { return h->world; }
+
+// How many ranks of the job run on THIS rank's device.  One in production (one process per GPU); the tests rehearse
+// several ranks on one GPU, where kernels that wait for a peer must leave room for that peer's kernels to run.
+extern "C" int pf_halo_set_colocated(pf_halo* h, int nranks) {
+  if (!h) return pf_fail(nullptr, PF_E_INVALID, "halo is NULL");
+  pf_ctx* ctx = h->ctx;
+  PF_REQUIRE(nranks >= 1 && nranks <= h->world, "pf_halo_set_colocated: between 1 and the world size");
+  h->colocated = nranks;
+  return PF_OK;
+}
+
 int32_t* pf_halo_err_ptr(pf_halo* h) { return h->err; }
 pf_ctx* pf_halo_ctx(pf_halo* h) { return h->ctx; }
 
@@ -342,11 +540,14 @@ extern "C" int pf_halo_destroy(pf_halo* h) {
   for (int i = 0; i < h->nplans; ++i) {
     pf_halo_plan& P = h->plans[i];
     pf_free(P.nbr); pf_free(P.nbr_ptr); pf_free(P.send_idx); pf_free(P.if_idx); pf_free(P.src_ptr); pf_free(P.src_off);
+    pf_free(P.fuse.ifslot); pf_free(P.fuse.sh_ptr); pf_free(P.fuse.sh_peer); pf_free(P.fuse.sh_pos); pf_free(P.fuse.tperm);
+    pf_free(P.fuse.flags8);
   }
   pf_free(h->peer_win);
   pf_free(h->err);
   pf_free(h->done);
   pf_free(h->sent);
+  pf_free(h->rows_done);
   if (h->win) (void)hipFree(h->win);
   delete h;
   return PF_OK;

@@ -745,7 +745,7 @@ extern "C" int pf_pattern_build(pf_ctx* ctx, int d) {
       ctx->tiles_sorted = true;
       // the same walk for the product's tiles (64 nodes per wave for d = 2, 128 for d = 1: pf_solve.hip k_spmv)
       if (d <= 2) {
-        const int64_t ts = d == 1 ? 128 : 64, nts = cdiv(nn, ts);
+        const int64_t ts = d == 1 ? PF_SPMV_TILE1 : PF_SPMV_TILE2, nts = cdiv(nn, ts);  // k_spmv's tiles: pf_solve.hip asserts that its shapes match
         std::vector<std::pair<uint64_t, int32_t>> k2((size_t)nts);
         for (int64_t t = 0; t < nts; ++t) {
           const int64_t n0 = t * ts;

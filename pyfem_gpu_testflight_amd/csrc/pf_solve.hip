@@ -36,7 +36,13 @@
 #ifndef PF_SPMV2F
 #define PF_SPMV2F 2, 1, 6, 640  // fp32 value copy (AMG smoother): 16-byte blocks, so twice as many in flight for the same bytes
 #endif
-static constexpr int SPMV_TILE1 = 128, SPMV_TILE2 = 64;  // nodes per wave tile (64 * rows per lane)
+static constexpr int SPMV_TILE1 = PF_SPMV_TILE1, SPMV_TILE2 = PF_SPMV_TILE2;  // nodes per wave tile (64 * rows per lane)
+// the Morton tile walk (pf_pattern.hip spmv_perm), the 16-bit column offsets and the fused exchange's tile walk
+// (pf_halo_plan_fuse) are all built for these tile sizes: a shape macro with another R must not compile
+template <int D, int R, int U, int CH>
+struct SpmvShape { static constexpr int d = D, tile = 64 * R; };
+static_assert(SpmvShape<PF_SPMV1>::tile == SPMV_TILE1 && SpmvShape<PF_SPMV1F>::tile == SPMV_TILE1, "d = 1 SpMV shapes must keep 128-node tiles");
+static_assert(SpmvShape<PF_SPMV2>::tile == SPMV_TILE2 && SpmvShape<PF_SPMV2F>::tile == SPMV_TILE2, "d = 2 SpMV shapes must keep 64-node tiles");
 static constexpr int SPMV_MAXGRID = 4096;
 static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
 static constexpr int NPART = PF_NPART;   // capacity of one partial array
@@ -125,15 +131,26 @@ __device__ __forceinline__ T spmv_ld(const T* p) {
 #ifndef PF_AB_SPMV_NT2
 #define PF_AB_SPMV_NT2 1  // non-temporal loads of the fp64 2x2 value stream (only pays with whole-line accesses: PF_AB_SPMV_HALF)
 #endif
-template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double>
+// SEND (the product over an element-block partition, one process per GPU): `snd` names the interface nodes and, per
+// node, the peers that share it and its place in the message to each.  The tiles that hold interface nodes come first in
+// tperm; for their interface rows the RAW product goes to y (no smoother epilogue: the row is not complete yet) and,
+// from the same registers, straight into the neighbours' windows over xGMI; the wave that finishes the last interface
+// tile raises this rank's row flag at every neighbour.  The interior tiles follow while the rows travel.  The kernel that
+// consumes y (k_dcg_update, k_halo_recv_apply) sums the interface rows in ascending rank order.
+struct pf_spmv_nosend {};
+template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double, bool SEND = false>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
-                                             const double* __restrict__ sm_b, const int32_t* __restrict__ tperm) {
+                                             const double* __restrict__ sm_b, const int32_t* __restrict__ tperm,
+                                             const std::conditional_t<SEND, pf_spmv_send, pf_spmv_nosend> snd) {
   using V = typename Vec<D>::T;
   constexpr int TILE = 64 * R;
   __shared__ V prod[CH];
+  if constexpr (SEND) {
+    if (snd.stop && *snd.stop != 0.0) return;  // converged (pf_dist_cg): nothing is sent, and no consumer waits for it
+  }
   const int lane = threadIdx.x;
   double dacc = 0.0;
   const int64_t ntiles = (nnodes + TILE - 1) / TILE;
@@ -252,11 +269,24 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
       }
       __syncthreads();
     }
+    bool iftile = false;
+    if constexpr (SEND) iftile = tslot < snd.n_iftiles;  // wave-uniform
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t n = tile * TILE + r * 64 + lane;
       if (n < nnodes) {
-        if (sm_b) {
+        int32_t ifs = -1;
+        if constexpr (SEND) {
+          if (iftile) ifs = snd.ifslot[n];
+          if (ifs >= 0) {  // an interface row: its partial sum goes to the sharing ranks as it is
+            for (int32_t k = snd.sh_ptr[ifs]; k < snd.sh_ptr[ifs + 1]; ++k) {
+              double* dst = snd.peer_win[snd.sh_peer[k]] + snd.slot_off + snd.sh_pos[k];
+              if constexpr (D == 1) pf_st_sys_f64(dst, acc[r]);
+              else { pf_st_sys_f64(dst, acc[r].x); pf_st_sys_f64(dst + 1, acc[r].y); }
+            }
+          }
+        }
+        if (sm_b && ifs < 0) {
           if constexpr (D == 1) {
             const double res = sm_b[n] - acc[r];
             acc[r] = sm_dinv ? x[n] + sm_dinv[n] * res : res;
@@ -279,6 +309,20 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
           if (dot_part) {
             const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
             dacc += xv.x * acc[r].x + xv.y * acc[r].y;
+          }
+        }
+      }
+    }
+    if constexpr (SEND) {
+      if (iftile) {
+        pf_release_sys();  // this wave's rows have arrived before it is counted (write-back + wait: no cache is invalidated)
+        if (lane == 0) {
+          const unsigned long long prev = __hip_atomic_fetch_add(snd.rows_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (prev + 1 == (unsigned long long)snd.n_iftiles) {  // the last interface tile of this product: tell the neighbours
+            __hip_atomic_store(snd.rows_done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch (stream order)
+            for (int k = 0; k < snd.nnbr; ++k)
+              __hip_atomic_store(reinterpret_cast<uint64_t*>(snd.peer_win[snd.nbr[k]]) + snd.rflag_off, snd.rseq, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
           }
         }
       }
@@ -722,6 +766,194 @@ __global__ __launch_bounds__(256) void k_cgcg_fused(int64_t n, const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// The update kernel of the distributed single-reduction PCG (pf_dist_cg): everything between two products in ONE launch.
+//   1. block 0 sums this rank's partials (gamma = own r.z and r.r from the previous update, delta = z.Kz from the
+//      product) in a fixed order, stores the three scalars into EVERY rank's window and raises its scalar flag there;
+//   2. every block waits for the scalar flags of all ranks (bounded) and sums the scalars in rank order: the
+//      all-reduce of the iteration, deterministic, without a collective and without a launch of its own;
+//   3. the first blocks wait for the row flags of the neighbours -- the rows left the neighbours' PRODUCT kernels
+//      (k_spmv<..., SEND>) while those were still computing their interior -- and form w on the interface entries as the
+//      sum over the sharing ranks in ascending rank order (same bits on every sharer), then update those entries;
+//   4. all blocks run the fused vector update (k_cgcg_fused's arithmetic) over the dofs that are NOT on an interface
+//      (flags8 bit 1), with the ownership weight of the dot products from bit 0.
+// keep_z (AMG-PCG, pf_dist_pcg_amg): z is the V-cycle's to write; this kernel leaves it alone, and the r.z partials it
+// stores are not used (the caller forms r.z after the cycle).
+// No thread of this kernel waits for another block of the same kernel except through block 0's flag, and block 0 never
+// waits before it has sent: the grid drains whenever every rank reaches its product launch (or the timeout fires).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dcg_point(double wv, double zv, double beta, double alpha, double dv, bool has_d, double& p, double& s,
+                                          double& x, double& r, double& zn) {
+  p = zv + beta * p;
+  s = wv + beta * s;
+  x += alpha * p;
+  r -= alpha * s;
+  zn = has_d ? dv * r : r;
+}
+
+__global__ __launch_bounds__(256) void k_dcg_update(int64_t n, pf_halo_recv rc, const double* __restrict__ gpart, int ngpart,
+                                                    const double* __restrict__ rrpart, int nrrpart,
+                                                    const double* __restrict__ dpart, int ndpart,
+                                                    const double* __restrict__ state_in, double* __restrict__ state_out,
+                                                    double* __restrict__ redg, int first, double tol2, int it, int keep_z,
+                                                    const double* __restrict__ w,
+                                                    const double* __restrict__ dinv, const uint8_t* __restrict__ flg,
+                                                    double* __restrict__ z, double* __restrict__ p, double* __restrict__ s,
+                                                    double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ gamma_part, double* __restrict__ rr_part) {
+  __shared__ double sh[4];
+  __shared__ int bad;
+  __shared__ double gsum[3];
+  // redg[3] != 0: an earlier update kernel of this solve found ||r|| <= tol (every rank forms the same sum of the same
+  // scalars in the same order, so every rank stops at the same iteration): nothing is sent, waited for or updated
+  if (redg[3] != 0.0) return;
+  if (threadIdx.x == 0) bad = *rc.err;
+  const int spar = (int)(rc.sseq & 1);
+  // The loads of this thread's FIRST pair do not depend on the scalars: they are issued before the wait, so that the
+  // flag's round trip (block 0's reduction, the store into every window, xGMI) hides behind them.  At one rank's share
+  // of the 4M-quad mesh at N = 8 a thread has two pairs in all.
+  const int64_t n2 = n >> 1;
+  const uint16_t* flg2 = reinterpret_cast<const uint16_t*>(flg);
+  const int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  uint32_t f0 = 0x0202u;
+  double2 z0, w0, p0, s0, x0, r0, d0 = make_double2(1.0, 1.0);
+  if (i0 < n2) {
+    f0 = flg2[i0];
+    if (!(f0 & 0x0202u)) {
+      z0 = ld2(z, i0); w0 = ld2(w, i0); p0 = ld2s(p, i0); s0 = ld2s(s, i0); x0 = ld2s(x, i0); r0 = ld2s(r, i0);
+      if (dinv) d0 = ld2s(dinv, i0);
+    }
+  }
+  if (blockIdx.x == 0) {  // 1. this rank's scalars to every rank (the partial arrays are overwritten at the END of this
+                          //    kernel by blocks that cannot get there before block 0 has read them: they wait for its flag)
+    const double g = block_sum_partials(gpart, ngpart, sh);
+    const double dl = block_sum_partials(dpart, ndpart, sh);
+    const double rr = block_sum_partials(rrpart, nrrpart, sh);
+    if ((int)threadIdx.x < rc.world) {
+      double* pw = rc.peer_win[threadIdx.x];
+      double* dst = pw + halo_scal2_off(rc.world) + ((size_t)spar * rc.world + rc.rank) * PF_HALO_NSCAL;
+      pf_st_sys_f64(dst, g);
+      pf_st_sys_f64(dst + 1, dl);
+      pf_st_sys_f64(dst + 2, rr);
+      pf_release_sys();  // one wave of the whole launch
+      __hip_atomic_store(reinterpret_cast<uint64_t*>(pw) + halo_sflag_off(rc.world) + rc.rank, rc.sseq, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  // 2. wait for every rank's scalars
+  if ((int)threadIdx.x < rc.world && !bad) {
+    const uint64_t* flag = reinterpret_cast<const uint64_t*>(rc.win) + halo_sflag_off(rc.world) + threadIdx.x;
+    if (pf_wait_flag(flag, rc.sseq, rc.timeout_ticks)) bad = 1;
+  }
+  __syncthreads();
+  if (bad) {
+    if (threadIdx.x == 0) *rc.err = 1;
+    return;
+  }
+  if (threadIdx.x < 3) {
+    const double* sc = rc.win + halo_scal2_off(rc.world) + (size_t)spar * rc.world * PF_HALO_NSCAL + threadIdx.x;
+    double t = 0.0;
+    for (int q = 0; q < rc.world; ++q) t += pf_ld_sys_f64(sc + (size_t)q * PF_HALO_NSCAL);
+    gsum[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const double gamma_new = gsum[0], delta = gsum[1];
+  double alpha, beta;
+  if (first) {
+    beta = 0.0;
+    alpha = gamma_new / delta;
+  } else {
+    beta = gamma_new / state_in[2];
+    alpha = gamma_new / (delta - beta * gamma_new / state_in[0]);
+  }
+  const bool conv = gsum[2] <= tol2;  // the residual after `it` updates meets the tolerance: x stays as it is
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state_out[0] = alpha;
+    state_out[1] = beta;
+    state_out[2] = gamma_new;
+    redg[0] = gamma_new;
+    redg[1] = delta;
+    redg[2] = gsum[2];  // r.r of the residual after `it` updates (what the host reads)
+    redg[4] = (double)it;
+    if (conv) redg[3] = 1.0;
+  }
+  if (conv) return;
+  double s1 = 0.0, s2 = 0.0;
+  // 3. interface entries: ordered sums of the rows that arrived, then the same update
+  const int nrb = (int)min((int64_t)gridDim.x, (rc.n_if + 255) / 256);
+  if ((int)blockIdx.x < nrb) {
+    if ((int)threadIdx.x < rc.nnbr) {
+      const uint64_t* flag = reinterpret_cast<const uint64_t*>(rc.win) + halo_rflag_off(rc.world) + rc.nbr[threadIdx.x];
+      if (pf_wait_flag(flag, rc.rseq, rc.timeout_ticks)) bad = 1;
+    }
+    __syncthreads();
+    if (bad) {  // block-uniform: the vectors of this solve are invalid from here on, the host raises
+      if (threadIdx.x == 0) *rc.err = 1;
+      return;
+    }
+    const double* recv = rc.win + halo_recv2_off(rc.world, rc.cap) + (size_t)(rc.rseq & 1) * rc.world * rc.cap;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rc.n_if; i += (int64_t)nrb * blockDim.x) {
+      const int32_t li = rc.if_idx[i];
+      const double own = w[li];
+      double ws = 0.0;
+      for (int32_t k = rc.src_ptr[i]; k < rc.src_ptr[i + 1]; ++k) {
+        const int32_t o = rc.src_off[k];
+        ws += (o < 0) ? own : pf_ld_sys_f64(recv + o);
+      }
+      double pv = p[li], sv = s[li], xv = x[li], rv = r[li], zn;
+      dcg_point(ws, z[li], beta, alpha, dinv ? dinv[li] : 1.0, dinv != nullptr, pv, sv, xv, rv, zn);
+      p[li] = pv; s[li] = sv; x[li] = xv; r[li] = rv; if (!keep_z) z[li] = zn;
+      if (flg[li] & 1) { s1 += rv * zn; s2 += rv * rv; }
+    }
+  }
+  // 4. everything that is not on an interface
+  auto pair = [&](int64_t i, uint32_t f, double2 zv, double2 wv, double2 pv, double2 sv, double2 xv, double2 rv, double2 dv) {
+    double2 zn;
+    dcg_point(wv.x, zv.x, beta, alpha, dv.x, dinv != nullptr, pv.x, sv.x, xv.x, rv.x, zn.x);
+    dcg_point(wv.y, zv.y, beta, alpha, dv.y, dinv != nullptr, pv.y, sv.y, xv.y, rv.y, zn.y);
+    st2s(p, i, pv); st2s(s, i, sv); st2s(x, i, xv); st2s(r, i, rv); if (!keep_z) st2(z, i, zn);
+    if (f & 0x0001u) { s1 += rv.x * zn.x; s2 += rv.x * rv.x; }
+    if (f & 0x0100u) { s1 += rv.y * zn.y; s2 += rv.y * rv.y; }
+  };
+  auto mixed = [&](int64_t i, uint32_t f) {  // a pair that touches an interface (d = 1 meshes: a node pair with one interface node)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint32_t fc = (f >> (8 * c)) & 0xffu;
+      if (fc & 2u) continue;
+      const int64_t q = 2 * i + c;
+      double pv = p[q], sv = s[q], xv = x[q], rv = r[q], zn;
+      dcg_point(w[q], z[q], beta, alpha, dinv ? dinv[q] : 1.0, dinv != nullptr, pv, sv, xv, rv, zn);
+      p[q] = pv; s[q] = sv; x[q] = xv; r[q] = rv; if (!keep_z) z[q] = zn;
+      if (fc & 1u) { s1 += rv * zn; s2 += rv * rv; }
+    }
+  };
+  if (i0 < n2) {
+    if (!(f0 & 0x0202u)) pair(i0, f0, z0, w0, p0, s0, x0, r0, d0);
+    else mixed(i0, f0);
+  }
+  for (int64_t i = i0 + (int64_t)gridDim.x * blockDim.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t f = flg2[i];
+    if (!(f & 0x0202u)) {
+      double2 dv = make_double2(1.0, 1.0);
+      const double2 zv = ld2(z, i), wv = ld2(w, i), pv = ld2s(p, i), sv = ld2s(s, i), xv = ld2s(x, i), rv = ld2s(r, i);
+      if (dinv) dv = ld2s(dinv, i);
+      pair(i, f, zv, wv, pv, sv, xv, rv, dv);
+    } else {
+      mixed(i, f);
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0 && !(flg[n - 1] & 2)) {
+    const int64_t q = n - 1;
+    double pv = p[q], sv = s[q], xv = x[q], rv = r[q], zn;
+    dcg_point(w[q], z[q], beta, alpha, dinv ? dinv[q] : 1.0, dinv != nullptr, pv, sv, xv, rv, zn);
+    p[q] = pv; s[q] = sv; x[q] = xv; r[q] = rv; if (!keep_z) z[q] = zn;
+    if (flg[q] & 1) { s1 += rv * zn; s2 += rv * rv; }
+  }
+  block_store_partial(s1, gamma_part, sh);
+  block_store_partial(s2, rr_part, sh);
+}
+
+// ------------------------------------------------------------------------------------------
 static inline unsigned vec_grid(int64_t n) {
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 512), VEC_BLOCKS));
 }
@@ -767,8 +999,27 @@ static int ensure_idx16(pf_ctx* ctx) {
 
 // vals32 != nullptr: the product uses that fp32 copy of the values instead of vals (AMG smoother sweeps)
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
-                   const double* sm_dinv, const double* sm_b, const float* vals32) {
+                   const double* sm_dinv, const double* sm_b, const float* vals32, const pf_spmv_send* snd,
+                   const int32_t* snd_tperm) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
+  if (snd) {  // the product over a partition: interface rows leave from the epilogue (k_spmv<..., SEND>)
+    if (ctx->d != 1 && ctx->d != 2) return pf_fail(ctx, PF_E_UNSUPPORTED, "fused exchange: 1 or 2 dofs per node");
+    if (int rc16 = ensure_idx16(ctx)) return rc16;
+    const bool i16 = ctx->nidx16_state == 1;
+    const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
+#define PF_SND(SHAPE, I16_, VT_, V_) \
+    k_spmv<SHAPE, I16_, VT_, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, V_, x, y, dot_part, sm_dinv, sm_b, snd_tperm, *snd)
+    if (vals32) {
+      if (ctx->d == 1) { if (i16) PF_SND(PF_SPMV1F, true, float, vals32); else PF_SND(PF_SPMV1F, false, float, vals32); }
+      else { if (i16) PF_SND(PF_SPMV2F, true, float, vals32); else PF_SND(PF_SPMV2F, false, float, vals32); }
+    } else {
+      if (ctx->d == 1) { if (i16) PF_SND(PF_SPMV1, true, double, vals); else PF_SND(PF_SPMV1, false, double, vals); }
+      else { if (i16) PF_SND(PF_SPMV2, true, double, vals); else PF_SND(PF_SPMV2, false, double, vals); }
+    }
+#undef PF_SND
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
   if (vals32) {
     if (ctx->d == 3) {
       k_spmv3<float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals32, x, y, dot_part, sm_dinv, sm_b);
@@ -776,10 +1027,10 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
       if (int rc16 = ensure_idx16(ctx)) return rc16;
       const bool i16 = ctx->nidx16_state == 1;
       const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
-      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else if (ctx->d == 1) k_spmv<PF_SPMV1F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else if (i16) k_spmv<PF_SPMV2F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
-      else k_spmv<PF_SPMV2F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
+      else if (ctx->d == 1) k_spmv<PF_SPMV1F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
+      else if (i16) k_spmv<PF_SPMV2F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
+      else k_spmv<PF_SPMV2F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
     }
     PF_LAUNCH_CHECK();
     return PF_OK;
@@ -790,7 +1041,8 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
 #define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
   if (shape == ID && ctx->d == D_) {                                                                        \
     grid = (unsigned)std::min<int64_t>(cdiv(ctx->nnodes, 64 * R_), SPMV_MAXGRID);                            \
-    k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm); \
+    k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, \
+                                                          64 * R_ == (D_ == 1 ? SPMV_TILE1 : SPMV_TILE2) ? ctx->spmv_perm : nullptr, pf_spmv_nosend{}); \
     PF_LAUNCH_CHECK();                                                                                      \
     return PF_OK;                                                                                           \
   }
@@ -804,17 +1056,17 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
     if (int rc16 = ensure_idx16(ctx)) return rc16;
     if (ctx->nidx16_state == 1)
       k_spmv<PF_SPMV1, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
-                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
     else
-      k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
   }
   else {
     if (int rc16 = ensure_idx16(ctx)) return rc16;
     if (ctx->nidx16_state == 1)
       k_spmv<PF_SPMV2, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
-                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
     else
-      k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm);
+      k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
   }
   PF_LAUNCH_CHECK();
   return PF_OK;
@@ -1074,18 +1326,87 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
 }
 
 // ------------------------------------------------------------------------------------------
-// Distributed single-reduction PCG, the whole loop in C (dist.py dist_cg is the same algorithm driven from Python over
-// torch.distributed, kept for the gloo CPU tests and as the fallback transport).  Per iteration: k_spmv (+ partials of
-// z.Kz), k_finalize, one pf_halo exchange (2 launches: interface sums of w = K z and the three scalars), k_cgcg_fused
-// (all vector updates of the iteration in one pass): five launches.  Nothing touches the host except the residual
-// read-back every check_every iterations.
+// Distributed single-reduction (Chronopoulos-Gear) Jacobi-PCG, the whole loop in C (dist.py dist_cg is the same algorithm
+// driven from Python over torch.distributed, kept for the gloo CPU tests and as the fallback transport).
+// TWO launches per iteration (round 3; round 2: four, each behind the other):
+//   k_spmv<..., SEND>   w = K z with the partials of z.Kz; the tiles that hold interface nodes run first and store their
+//                       rows straight into the neighbours' windows, the interior follows while the rows travel
+//   k_dcg_update        scalars to every rank, wait, sum (the iteration's all-reduce); interface rows summed in rank
+//                       order; p, s, x, r, z updated in one pass; convergence tested ON THE DEVICE (every rank sees the
+//                       same bits), after which the remaining launches of a burst return at once and x stays the
+//                       converged iterate -- the result does not depend on check_every
+// Nothing touches the host except the read-back every check_every iterations.  A plan that was not fused
+// (pf_halo_plan_fuse) is an error: there is no second path.
 // ------------------------------------------------------------------------------------------
+// The two launches, for pf_dist_cg below and pf_dist_pcg_amg (pf_dist.hip):
+//   pf_dist_product  y = K x on the rank's rows with the fused send (optional smoother epilogue / fp32 values / partials
+//                    of x.y into PA_DELTA); interface entries of y hold the RAW row until the consumer has summed them
+//   pf_dist_update   k_dcg_update on the context's partial arrays.  gamma_from_dot: the r.z partials were left in
+//                    PA_GAMMA by k_dot (vec_grid blocks, AMG-PCG) instead of by the previous update (its own grid)
+int pf_dist_product(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const float* vals32, const double* x, double* y,
+                    bool dot, const double* sm_dinv, const double* sm_b, const double* stop) {
+  const pf_halo_fuse* F = pf_halo_fuse_of(halo, plan);
+  PF_REQUIRE(F && F->d == ctx->d, "fused product: the plan was not prepared (pf_halo_plan_fuse)");
+  pf_spmv_send snd;
+  if (int rc = pf_halo_fused_send(halo, plan, &snd)) return rc;
+  snd.stop = stop;
+  if (int rc = pf_launch_spmv(ctx, vals, x, y, dot ? part(ctx, PA_DELTA) : nullptr, sm_dinv, sm_b, vals32, &snd, F->tperm)) return rc;
+  pf_halo_fused_sent(halo, plan);
+  return PF_OK;
+}
+
+static unsigned dist_update_grid(pf_ctx* ctx, pf_halo* halo, int64_t n) {
+  // the update kernel's blocks wait (for scalars, for rows): when several ranks share ONE device (the rehearsal of the
+  // tests; never in production) they must all fit beside each other's product kernels
+  return std::max(1u, std::min(vec_grid(n), (unsigned)(4 * std::max(ctx->ncu, 1)) / (unsigned)std::max(pf_halo_colocated(halo), 1)));
+}
+
+int pf_dist_update(pf_ctx* ctx, pf_halo* halo, int plan, const double* w, const double* dinv, bool keep_z, bool gamma_from_dot,
+                   bool rr_from_init, double* x, double* r, double* z, double* p, double* s, const double* state_in,
+                   double* state_out, double* redg, bool first, double tol2, int it) {
+  const pf_halo_fuse* F = pf_halo_fuse_of(halo, plan);
+  PF_REQUIRE(F && F->d == ctx->d, "fused update: the plan was not prepared (pf_halo_plan_fuse)");
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  const unsigned vg = vec_grid(n), ug = dist_update_grid(ctx, halo, n);
+  const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
+  pf_halo_recv rcv;
+  pf_halo_fused_recv(halo, plan, true, &rcv);
+  // partial arrays: PA_GAMMA / PA_RR2 hold what the previous producer stored (k_cgcg_update_xrz or k_dot: vg blocks; this
+  // kernel: ug blocks); the r.z partials of a keep_z launch go to PA_RZ0, which nobody reads
+  k_dcg_update<<<ug, 256, 0, ctx->stream>>>(n, rcv, part(ctx, PA_GAMMA), (int)((gamma_from_dot || rr_from_init) ? vg : ug),
+                                            part(ctx, PA_RR2), (int)(rr_from_init ? vg : ug), part(ctx, PA_DELTA), ns, state_in,
+                                            state_out, redg, first ? 1 : 0, tol2, it, keep_z ? 1 : 0, w, dinv, F->flags8, z, p, s, x, r,
+                                            part(ctx, keep_z ? PA_RZ0 : PA_GAMMA), part(ctx, PA_RR2));
+  PF_LAUNCH_CHECK();
+  pf_halo_fused_scal(halo);
+  return PF_OK;
+}
+
+// r.z over the owned dofs into PA_GAMMA (vec_grid partials), for pf_dist_update(gamma_from_dot)
+int pf_dist_dot_gamma(pf_ctx* ctx, const double* r, const double* z, const double* own_w) {
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  k_dot<<<vec_grid(n), 256, 0, ctx->stream>>>(n, r, z, own_w, part(ctx, PA_GAMMA));
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
+// z = dinv r (dinv == NULL: z = r) and the partials of own r.z, r.r for the first reduction, with the zeroed state
+int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, const double* s, const double* dinv,
+                          const double* own_w, double* x, double* r, double* z) {
+  const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  k_cgcg_update_xrz<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state0, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
+  PF_LAUNCH_CHECK();
+  return PF_OK;
+}
+
 extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
                           const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
                           int32_t* iters_host, double* relres_host) {
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(halo && pf_halo_ctx(halo) == ctx, "pf_dist_cg: the halo belongs to another context");
   PF_REQUIRE(ctx->d && vals && b && x && own_w, "pf_dist_cg: no pattern / NULL argument");
+  const pf_halo_fuse* F = pf_halo_fuse_of(halo, plan);
+  PF_REQUIRE(F && F->d == ctx->d, "pf_dist_cg: the plan was not prepared for the fused exchange (pf_halo_plan_fuse)");
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
@@ -1099,11 +1420,10 @@ extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* va
   double *r = ctx->cgw, *z = r + n, *p = z + 2 * n, *s = p + n;
   if (int prc = cg_place_ap(ctx, vals, p, n)) return prc;  // the product's output vector, placed by measurement
   double* w = ctx->cg_ap;
-  double* small = s + n;  // [0..2] state a, [8..10] state b, [16..23] local scalars, [24..31] reduced scalars
+  double* small = s + n;  // [0..2] state a, [8..10] state b, [16..23] local scalars, [24..31] reduced scalars + stop flag
   double *stA = small, *stB = small + 8, *red = small + 16, *redg = small + 24;
   hipStream_t st = ctx->stream;
   const unsigned vg = vec_grid(n);
-  const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
   PF_HIP(hipMemsetAsync(x, 0, sizeof(double) * n, st));
   PF_HIP(hipMemsetAsync(p, 0, sizeof(double) * 2 * n + sizeof(double) * 64, st));  // p, s and the small block
   PF_HIP(hipMemcpyAsync(r, b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
@@ -1120,34 +1440,33 @@ extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* va
   if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_cg: a peer did not arrive at the halo exchange (timeout)");
   const double bnorm = sqrt(h[0]);
   const double tol = std::max(rtol * bnorm, atol);
+  PF_HIP(hipMemsetAsync(redg, 0, sizeof(double) * 8, st));
   double rnorm = INFINITY;
   int it = 0;
   double *state = stA, *state_next = stB;
-  // z = dinv r and the partials of r.z, r.r for the first reduction (alpha = 0 in the zeroed state: x, r unchanged)
-  k_cgcg_update_xrz<<<vg, 256, 0, st>>>(n, state, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
-  while (it < maxiter) {
-    rc = pf_launch_spmv(ctx, vals, z, w, part(ctx, PA_DELTA));
-    if (rc) return rc;
-    k_finalize<<<1, 256, 0, st>>>(3, part(ctx, PA_GAMMA), (int)vg, part(ctx, PA_DELTA), ns, part(ctx, PA_RR2), (int)vg, red,
-                                  nullptr, 0);
-    rc = pf_halo_exchange_impl(halo, plan, w, red, 3, redg);
-    if (rc) return rc;
-    // redg[2] = r.r of the residual after `it` updates
-    if (it % check_every == 0 || it + 1 == maxiter) {
-      PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
-      PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(halo), sizeof(herr), hipMemcpyDeviceToHost, st));
-      PF_HIP(hipStreamSynchronize(st));
-      if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_cg: a peer did not arrive at the halo exchange (timeout)");
-      rnorm = sqrt(h[2]);
-      if (!(rnorm == rnorm) || rnorm <= tol) break;
+  if ((rc = pf_dist_init_partials(ctx, state, p, s, dinv, own_w, x, r, z))) return rc;
+  bool stopped = false;
+  while (it < maxiter && !stopped) {
+    const int burst = std::min(check_every - it % check_every, maxiter - it);
+    for (int k = 0; k < burst; ++k, ++it) {
+      if ((rc = pf_dist_product(ctx, halo, plan, vals, nullptr, z, w, true, nullptr, nullptr, redg + 3))) return rc;
+      if ((rc = pf_dist_update(ctx, halo, plan, w, dinv, false, false, it == 0, x, r, z, p, s, state, state_next, redg, it == 0,
+                               tol * tol, it)))
+        return rc;
+      std::swap(state, state_next);
     }
-    // update_ps of this iteration and update_xrz of the next in one pass over the vectors
-    k_cgcg_fused<<<vg, 256, 0, st>>>(n, state, state_next, redg, it == 0, w, dinv, own_w, z, p, s, x, r, part(ctx, PA_GAMMA),
-                                     part(ctx, PA_RR2));
-    std::swap(state, state_next);
-    ++it;
+    // redg = [gamma, delta, r.r after redg[4] updates, stop flag, iteration index]
+    PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(halo), sizeof(herr), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_cg: a peer did not arrive at the fused exchange (timeout)");
+    rnorm = sqrt(h[2]);
+    if (h[3] != 0.0) {  // converged on the device after h[4] updates: the later launches of the burst were no-ops
+      it = (int)h[4];
+      stopped = true;
+    }
+    if (!(rnorm == rnorm)) break;
   }
-  PF_LAUNCH_CHECK();
   if (iters_host) *iters_host = it;
   if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;
   if (!(rnorm <= tol)) return pf_fail(ctx, PF_E_NOCONV, "cg failed with code " + std::to_string(it));  // pyfem.py:2421-2422

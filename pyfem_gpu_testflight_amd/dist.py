@@ -244,6 +244,7 @@ class HipLocalOps:
         x = self.zeros(self.n)
         iters, relres = self._lib._i32(), self._lib._f64()
         self.begin()
+        iface.fuse(own_w)
         rc = self.lib.pf_dist_cg(self.h._ctx, iface.halo._h, int(iface.plan), self._p(K), self._p(b), self._p(dinv),
                                  self._p(own_w), self._p(x), float(rtol), float(atol), int(maxiter or 0), int(check_every or 0),
                                  C.byref(iters), C.byref(relres))
@@ -419,6 +420,32 @@ class Interface:
         _all_reduce(out, self.group)
         return out
 
+    def fuse(self, own_w):
+        """Prepare this interface's plan for the FUSED exchange (csrc/pf_halo.hip pf_halo_plan_fuse): interface rows leave
+        from the product's epilogue, the consuming kernel sums them.  own_w: device tensor, 1 on the dofs this rank owns.
+        Idempotent; peer transport only."""
+        if self.transport != "peer":
+            raise RuntimeError("the fused exchange runs on the peer-store transport")
+        self.halo._check(self.halo.lib.pf_halo_plan_fuse(self.halo._h, int(self.plan), C.c_void_p(own_w.data_ptr())),
+                         "pf_halo_plan_fuse")
+
+    def fuse_tables(self):
+        """Host copies of the fused plan's tables (dict of numpy arrays) -- what tests replay."""
+        h, lib = self.halo, self.halo.lib
+        dims = (C.c_int64 * 6)()
+        z = C.c_void_p(0)
+        h._check(lib.pf_halo_fuse_get(h._h, int(self.plan), dims, z, z, z, z, z, z), "pf_halo_fuse_get")
+        nif, niftiles, nt, nsh, tn, d = (int(v) for v in dims)
+        nn = self.ops.h.nnodes
+        out = {"ifslot": np.empty(nn, np.int32), "sh_ptr": np.empty(nif + 1, np.int32), "sh_peer": np.empty(max(nsh, 1), np.int32),
+               "sh_pos": np.empty(max(nsh, 1), np.int32), "tperm": np.empty(nt, np.int32), "flags8": np.empty(nn * d, np.uint8)}
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        h._check(lib.pf_halo_fuse_get(h._h, int(self.plan), dims, p(out["ifslot"]), p(out["sh_ptr"]), p(out["sh_peer"]),
+                                      p(out["sh_pos"]), p(out["tperm"]), p(out["flags8"])), "pf_halo_fuse_get")
+        out["sh_peer"], out["sh_pos"] = out["sh_peer"][:nsh], out["sh_pos"][:nsh]
+        out.update(n_ifnodes=nif, n_iftiles=niftiles, ntiles=nt, tile_nodes=tn, d=d)
+        return out
+
     def sibling(self, d):
         """The same partition's interface for vectors with d entries per node, sharing this one's window."""
         return Interface(self.ops, self.part, self.group, d=d, transport=self.transport, halo=self.halo)
@@ -465,8 +492,13 @@ class PeerHalo:
             why = f"{type(e).__name__}: {e}"
         import socket
 
+        try:  # which physical device this rank runs on: ranks that share one (the tests' rehearsal) must make room for each other
+            props = ops.torch.cuda.get_device_properties(ops.device)
+            devid = str(getattr(props, "uuid", "")) or f"index{ops.device.index}"
+        except Exception:
+            devid = f"index{getattr(ops.device, 'index', 0)}"
         info = [None] * world
-        dist.all_gather_object(info, (handle, socket.gethostname(), why), group=group)
+        dist.all_gather_object(info, (handle, socket.gethostname(), why, devid), group=group)
         ok = all(i[0] is not None for i in info) and len({i[1] for i in info}) == 1
         if ok:
             try:
@@ -482,6 +514,8 @@ class PeerHalo:
             if h is not None:
                 h.close()
             return None
+        same_dev = sum(1 for i in info if i[3] == devid)
+        h._check(h.lib.pf_halo_set_colocated(h._h, int(same_dev)), "pf_halo_set_colocated")
         dist.barrier(group=group)  # every window is mapped everywhere before anybody stores into one
         return h
 
@@ -747,6 +781,14 @@ class ReplicatedHierarchy:
         a.nl, a.grow = int(self.grow.numel()), p(self.grow)
         a.ltptr, a.ltnode, a.ltslot = p(self._lt[0]), p(self._lt[1]), p(self._lt[2])
         a.n1 = int(self.b1.numel())
+        # the cycle's products read an fp32 copy of the rank's matrix, as the single-GPU cycle does (csrc/pf_amg.hip)
+        if getattr(self, "_K32", None) is None or self._K32.numel() != K.numel():
+            self._K32 = ops.torch.empty(K.numel(), dtype=ops.torch.float32, device=ops.device)
+        ops.begin()
+        ops._call("pf_vals_to_f32", ops._lib._i64(K.numel()), p(K), p(self._K32))
+        a.K32 = p(self._K32)
+        a.ltvals = p(self._ltvals)
+        iface.fuse(own_w)  # every product of the loop sends its interface rows from its epilogue
         return a
 
     def setup(self, Kg_vals, reuse=False):
@@ -761,6 +803,11 @@ class ReplicatedHierarchy:
             self.b1, self.x1 = self.ops.zeros(n1.value), self.ops.zeros(n1.value)
         if self._lt is None:
             self._local_transpose()
+        # this rank's entries of P0 in transpose order, streamed by the restriction (values change with the matrix)
+        nlt = int(self._lt[2].numel())
+        if getattr(self, "_ltvals", None) is None:
+            self._ltvals = self.ops.zeros(max(nlt, 1) * (n1.value // self.nc) * self.part.d)
+        self._gcall("pf_amg_p0_gather", self.ops._lib._i64(nlt), p(self._lt[2]), p(self._ltvals))
         return self
 
     def vcycle(self, K, r, z, iface, own_w):

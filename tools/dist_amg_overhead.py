@@ -1,13 +1,14 @@
 """Cost of the partitioned AMG-PCG driver on ONE rank against the single-GPU pf_cg with the same hierarchy, on the
-2048 x 1024 plane-stress system with a RAMP density field (configuration 5's matrix): what the Python-orchestrated V-cycle
-and the whole-mesh-length restriction / prolongation cost before any communication.
-   python tools/dist_amg_overhead.py  ->  one JSON line (profiles/r02_dist_amg_overhead.jsonl)"""
+2048 x 1024 plane-stress system with a RAMP density field (configuration 5's matrix), and where the difference goes
+(the pieces of PartitionedElasticity.solve, each synchronised).
+   python tools/dist_amg_overhead.py  ->  one JSON line (profiles/r03_dist_amg_overhead.jsonl)"""
 import json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pyfem_gpu_testflight_amd import pyfem
-from pyfem_gpu_testflight_amd.dist import PartitionedElasticity
+from pyfem_gpu_testflight_amd.dist import PartitionedElasticity, dist_pcg_amg
 nx, ny = 2048, 1024
+RTOL = float(os.environ.get("RTOL", "1e-8"))
 c = pyfem.ProblemCreator(nx + 1, ny + 1)
 conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
 q = pyfem.QuadratureBilinear2D(); b = pyfem.BasisBilinear2D(q)
@@ -19,16 +20,33 @@ def single():
     K = model.compute_jacobian(rho_d)
     rhs = model.hctx.to_device(model.compute_rhs(), torch.float64)
     K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
-    asm = pyfem.Assembler(model); asm.rtol = 1e-8
+    asm = pyfem.Assembler(model); asm.rtol = RTOL
     u = asm._solve_linear_system(K, rhs, "cg")
     return asm.last_iters
 pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, p=5.0, rank=0, world=1)
+rho_l = pm.local_nodal(rho)
 def parted():
-    pm.solve(rho=rho, rtol=1e-8, precond="amg")
+    pm.solve(rho=rho_l, rtol=RTOL, precond="amg")
     return pm.last_iters
-out = {"mesh": f"{nx}x{ny} quads, RAMP p=5"}
+def pieces():
+    t = {}
+    def lap(name, t0):
+        torch.cuda.synchronize(); t[name] = time.perf_counter() - t0; return time.perf_counter()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    K = pm.compute_jacobian(rho_l); t0 = lap("assemble_local", t0)
+    rhs = pm.ops.from_numpy(pm.model.compute_rhs(), torch.float64); t0 = lap("rhs_upload", t0)
+    K, bb = pm.apply_dirichlet_bcs(K, rhs); t0 = lap("bcs_local", t0)
+    hier = pm._hierarchy_for(pm._global_rho(rho_l)); t0 = lap("whole_mesh_assembly_bcs_and_numeric_setup", t0)
+    x, it, rr = dist_pcg_amg(pm.ops, K.vals, bb, pm.own_w, pm.iface, hier, rtol=RTOL); t0 = lap("pcg_loop", t0)
+    t["iters"] = it
+    return t
+out = {"mesh": f"{nx}x{ny} quads, RAMP p=5", "rtol": RTOL}
 for name, fn in (("single_gpu_pf_cg_amg", single), ("partitioned_driver_one_rank", parted)):
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter(); it = fn(); torch.cuda.synchronize()
-    out[name + "_s"] = time.perf_counter() - t0; out[name + "_iters"] = it
+    fn(); fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); it = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    out[name + "_s"] = min(ts); out[name + "_all_s"] = ts; out[name + "_iters"] = it
+out["ratio"] = out["partitioned_driver_one_rank_s"] / out["single_gpu_pf_cg_amg_s"]
+pieces(); out["pieces_s"] = pieces()
 print(json.dumps(out), flush=True)

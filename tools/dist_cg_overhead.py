@@ -2,7 +2,7 @@
 mesh and on a 1/8 strip of it (the share of one GPU at N = 8: 2048 x 256 quads).  Three drivers of the SAME
 single-reduction iteration: pf_cg (3 launches per iteration), pf_dist_cg (the native loop over the peer-store exchange:
 6 launches, the exchange kernels run with a window that has no peers) and dist.py's Python loop (ctypes launches +
-torch for the scalars).   python tools/dist_cg_overhead.py  ->  one JSON line per mesh (profiles/r02_dist_cg_overhead.jsonl)"""
+torch for the scalars).   python tools/dist_cg_overhead.py  ->  one JSON line per mesh (profiles/r03_dist_cg_overhead.jsonl)"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
