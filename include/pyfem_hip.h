@@ -361,6 +361,17 @@ int pf_halo_plan_fuse(pf_halo* halo, int plan, const double* own_w);
 int pf_halo_fuse_get(pf_halo* halo, int plan, int64_t* dims_host, int32_t* ifslot, int32_t* sh_ptr, int32_t* sh_peer,
                      int32_t* sh_pos, int32_t* tperm, uint8_t* flags8);
 int pf_halo_set_colocated(pf_halo* halo, int nranks);
+/* The fused plan's tables from HOST arrays, no GPU involved (csrc/pf_hostlogic.h; the CPU tests replay a fused exchange
+ * over gloo with them).  Outputs sized by the caller: ifslot nnodes, sh_ptr n_if/d + 1, sh_peer / sh_pos nbr_ptr[nnbr]/d,
+ * tperm ceil(nnodes / tile_nodes), flags8 nnodes*d; any may be NULL.  dims = {interface nodes, interface tiles, tiles,
+ * sharer entries}.  base_perm (tile walk to refine) and own_w may be NULL. */
+int pf_host_fuse_tables_c(int64_t nnodes, int d, int tile_nodes, int nnbr, const int32_t* nbr, const int32_t* nbr_ptr,
+                          const int32_t* send_idx, int64_t n_if, const int32_t* if_idx, const int32_t* base_perm,
+                          const double* own_w, int32_t* ifslot, int32_t* sh_ptr, int32_t* sh_peer, int32_t* sh_pos,
+                          int32_t* tperm, uint8_t* flags8, int64_t* dims);
+/* y = K x over the partition through the fused exchange (plan prepared with pf_halo_plan_fuse): product + send, then the
+ * interface sums in ascending rank order.  Same result, bit for bit, as pf_spmv followed by pf_halo_exchange. */
+int pf_dist_spmv(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* x, double* y);
 int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
                const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
                int32_t* iters_host, double* relres_host);

@@ -99,6 +99,9 @@ SIGNATURES = {
     "pf_halo_plan_fuse": (C.c_int, [_vp, C.c_int, _vp]),
     "pf_halo_fuse_get": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pf_halo_set_colocated": (C.c_int, [_vp, C.c_int]),
+    "pf_dist_spmv": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "pf_host_fuse_tables_c": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _vp]),
     "pf_dist_cg": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32),
                              C.POINTER(_f64)]),
     "pf_dist_vcycle": (C.c_int, [_vp, _vp, _vp, _vp]),

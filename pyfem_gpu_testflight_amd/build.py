@@ -42,7 +42,7 @@ def build(force=False, verbose=True, experiments=False):
     flags = FLAGS + (["-DPF_EXPERIMENTS", "-DPF_SPMV_SWEEP"] if experiments else [])
     lib = LIB_EXP if experiments else LIB
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "pf_common.h"), os.path.join(INC, "pyfem_hip.h")]
+    headers = [os.path.join(CSRC, "pf_common.h"), os.path.join(CSRC, "pf_hostlogic.h"), os.path.join(INC, "pyfem_hip.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -37,6 +37,7 @@
 // a window to have the same neighbour list (checked in pf_halo_plan_fuse).  Scalar messages go to every rank and their
 // consumers wait for every rank: the same argument with "neighbour" replaced by "rank".
 #include "pf_common.h"
+#include "pf_hostlogic.h"
 
 // NB workgroups per peer (NB = gridDim.y): scalars to every peer, the packed values to the neighbours of the plan; the
 // workgroup that finishes a peer's message last raises that peer's flag (counted in done[peer], which it resets)
@@ -331,56 +332,25 @@ extern "C" int pf_halo_plan_fuse(pf_halo* h, int plan, const double* own_w) {
   // every fused plan of a window must talk to the same neighbours (slot-reuse argument in the header comment)
   if (h->fuse_nbr.empty() && h->rseq == 0) h->fuse_nbr = P.h_nbr;
   PF_REQUIRE(h->fuse_nbr == P.h_nbr, "pf_halo_plan_fuse: the fused plans of one window must share their neighbour list");
-  // node-level view of the packed messages: d consecutive entries per node, node-aligned
-  std::vector<int32_t> ifslot((size_t)nn, -1);
-  std::vector<int32_t> ifnodes;
-  for (int64_t i = 0; i < (int64_t)P.h_if_idx.size(); ++i) {
-    const int32_t node = P.h_if_idx[i] / d;
-    PF_REQUIRE(node >= 0 && node < nn, "pf_halo_plan_fuse: interface entry outside the context's vectors");
-    if (ifslot[node] < 0) { ifslot[node] = 0; ifnodes.push_back(node); }
-  }
-  PF_REQUIRE((int64_t)ifnodes.size() * d == (int64_t)P.h_if_idx.size(),
-             "pf_halo_plan_fuse: the plan does not move d entries per node (a nodal plan on a dof context cannot be fused)");
-  std::sort(ifnodes.begin(), ifnodes.end());
-  for (size_t s = 0; s < ifnodes.size(); ++s) ifslot[ifnodes[s]] = (int32_t)s;
-  std::vector<int32_t> cnt(ifnodes.size() + 1, 0);
-  for (int k = 0; k < P.nnbr; ++k) {
-    const int32_t b = P.h_nbr_ptr[k], e = P.h_nbr_ptr[k + 1];
-    PF_REQUIRE((e - b) % d == 0, "pf_halo_plan_fuse: a message is not a whole number of nodes");
-    for (int32_t i = b; i < e; i += d) {
-      const int32_t v = P.h_send_idx[i];
-      PF_REQUIRE(v % d == 0 && v / d < nn && ifslot[v / d] >= 0, "pf_halo_plan_fuse: packed entry is not a node of the interface");
-      for (int j = 1; j < d; ++j) PF_REQUIRE(P.h_send_idx[i + j] == v + j, "pf_halo_plan_fuse: the entries of a node are not consecutive");
-      ++cnt[ifslot[v / d] + 1];
-    }
-  }
-  for (size_t s = 0; s < ifnodes.size(); ++s) cnt[s + 1] += cnt[s];
-  std::vector<int32_t> sh_peer((size_t)std::max<int32_t>(cnt.back(), 1)), sh_pos(sh_peer.size()), fill(cnt.begin(), cnt.end() - 1);
-  for (int k = 0; k < P.nnbr; ++k)  // neighbours ascending => every node's sharers come out in ascending rank order
-    for (int32_t i = P.h_nbr_ptr[k]; i < P.h_nbr_ptr[k + 1]; i += d) {
-      const int32_t slot = fill[ifslot[P.h_send_idx[i] / d]]++;
-      sh_peer[slot] = P.h_nbr[k];
-      sh_pos[slot] = i - P.h_nbr_ptr[k];
-    }
-  // tile walk: interface tiles first (their rows are sent while the interior is computed), the rest in the context's order
+  // the tables themselves are host logic without HIP (pf_hostlogic.h: built and run under ASan / UBSan by the CPU tests)
   const int tn = d == 1 ? PF_SPMV_TILE1 : PF_SPMV_TILE2;
   const int64_t nt = cdiv(nn, tn);
-  std::vector<int32_t> base((size_t)nt);
-  if (ctx->spmv_perm) PF_HIP(hipMemcpy(base.data(), ctx->spmv_perm, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
-  else for (int64_t t = 0; t < nt; ++t) base[t] = (int32_t)t;
-  std::vector<uint8_t> has((size_t)nt, 0);
-  for (int32_t node : ifnodes) has[node / tn] = 1;
-  std::vector<int32_t> tperm;
-  tperm.reserve((size_t)nt);
-  for (int64_t t = 0; t < nt; ++t) if (has[base[t]]) tperm.push_back(base[t]);
-  const int32_t n_iftiles = (int32_t)tperm.size();
-  for (int64_t t = 0; t < nt; ++t) if (!has[base[t]]) tperm.push_back(base[t]);
-  // per-dof flags: bit 0 owned (own_w != 0), bit 1 on an interface
+  std::vector<int32_t> base;
+  if (ctx->spmv_perm) {
+    base.resize((size_t)nt);
+    PF_HIP(hipMemcpy(base.data(), ctx->spmv_perm, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost));
+  }
   std::vector<double> ow((size_t)n);
   PF_HIP(hipMemcpy(ow.data(), own_w, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> flags((size_t)n + 8, 0);
-  for (int64_t i = 0; i < n; ++i) flags[i] = ow[i] != 0.0 ? 1 : 0;
-  for (int32_t v : P.h_if_idx) flags[v] |= 2;
+  std::vector<int32_t> ifslot, cnt, sh_peer, sh_pos, tperm;
+  std::vector<uint8_t> flags;
+  int32_t n_iftiles = 0;
+  const std::string why = pf_host_fuse_tables(nn, d, tn, P.nnbr, P.h_nbr.data(), P.h_nbr_ptr.data(), P.h_send_idx.data(),
+                                              (int64_t)P.h_if_idx.size(), P.h_if_idx.data(), base.empty() ? nullptr : base.data(),
+                                              ow.data(), ifslot, cnt, sh_peer, sh_pos, tperm, n_iftiles, flags);
+  PF_REQUIRE(why.empty(), "pf_halo_plan_fuse: " + why);
+  if (sh_peer.empty()) { sh_peer.push_back(0); sh_pos.push_back(0); }
+  const int64_t n_ifnodes = (int64_t)cnt.size() - 1;
   int rc;
   if ((rc = halo_upload(ctx, ifslot.data(), nn, F.ifslot))) return rc;
   if ((rc = halo_upload(ctx, cnt.data(), (int64_t)cnt.size(), F.sh_ptr))) return rc;
@@ -388,10 +358,33 @@ extern "C" int pf_halo_plan_fuse(pf_halo* h, int plan, const double* own_w) {
   if ((rc = halo_upload(ctx, sh_pos.data(), (int64_t)sh_pos.size(), F.sh_pos))) return rc;
   if ((rc = halo_upload(ctx, tperm.data(), nt, F.tperm))) return rc;
   if ((rc = halo_upload(ctx, flags.data(), (int64_t)flags.size(), F.flags8))) return rc;
-  F.n_ifnodes = (int64_t)ifnodes.size();
+  F.n_ifnodes = n_ifnodes;
   F.n_iftiles = n_iftiles;
   F.tile_nodes = tn;
   F.d = d;
+  return PF_OK;
+}
+
+// The same tables from HOST arrays, no GPU involved (outputs sized by the caller: ifslot nnodes, sh_ptr n_if/d + 1,
+// sh_peer / sh_pos nbr_ptr[nnbr]/d, tperm ceil(nnodes / tile_nodes), flags8 nnodes*d; dims = {interface nodes, interface
+// tiles, tiles, sharer entries}).  tests/test_dist_cpu.py replays a fused exchange over gloo with them.
+extern "C" int pf_host_fuse_tables_c(int64_t nnodes, int d, int tile_nodes, int nnbr, const int32_t* nbr, const int32_t* nbr_ptr,
+                                     const int32_t* send_idx, int64_t n_if, const int32_t* if_idx, const int32_t* base_perm,
+                                     const double* own_w, int32_t* ifslot, int32_t* sh_ptr, int32_t* sh_peer, int32_t* sh_pos,
+                                     int32_t* tperm, uint8_t* flags8, int64_t* dims) {
+  std::vector<int32_t> a, b, c, e, t;
+  std::vector<uint8_t> f;
+  int32_t nift = 0;
+  const std::string why = pf_host_fuse_tables(nnodes, d, tile_nodes, nnbr, nbr, nbr_ptr, send_idx, n_if, if_idx, base_perm, own_w, a, b,
+                                              c, e, t, nift, f);
+  if (!why.empty()) return pf_fail(nullptr, PF_E_INVALID, "pf_host_fuse_tables: " + why);
+  if (ifslot) std::copy(a.begin(), a.end(), ifslot);
+  if (sh_ptr) std::copy(b.begin(), b.end(), sh_ptr);
+  if (sh_peer) std::copy(c.begin(), c.end(), sh_peer);
+  if (sh_pos) std::copy(e.begin(), e.end(), sh_pos);
+  if (tperm) std::copy(t.begin(), t.end(), tperm);
+  if (flags8) std::copy(f.begin(), f.begin() + nnodes * d, flags8);
+  if (dims) { dims[0] = (int64_t)b.size() - 1; dims[1] = nift; dims[2] = (int64_t)t.size(); dims[3] = (int64_t)c.size(); }
   return PF_OK;
 }
 

@@ -1399,6 +1399,18 @@ int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, co
   return PF_OK;
 }
 
+// y = K x over the partition, complete on return of the stream: the fused product (interface rows sent from its epilogue)
+// followed by the ordered interface sums.  The building block the loops below are made of, exported for the self-test of
+// the fused exchange (dist.py compares it bit for bit with pf_spmv + the packed exchange) and for callers' own loops.
+extern "C" int pf_dist_spmv(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* x, double* y) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(halo && pf_halo_ctx(halo) == ctx, "pf_dist_spmv: the halo belongs to another context");
+  PF_REQUIRE(ctx->d && vals && x && y && x != y, "pf_dist_spmv: no pattern / NULL argument / x aliases y");
+  PF_HIP(hipSetDevice(ctx->device));
+  if (int rc = pf_dist_product(ctx, halo, plan, vals, nullptr, x, y, false, nullptr, nullptr, nullptr)) return rc;
+  return pf_halo_recv_apply(halo, plan, nullptr, nullptr, nullptr, y);
+}
+
 extern "C" int pf_dist_cg(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const double* b, const double* dinv,
                           const double* own_w, double* x, double rtol, double atol, int maxiter, int check_every,
                           int32_t* iters_host, double* relres_host) {

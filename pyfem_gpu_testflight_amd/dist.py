@@ -244,7 +244,6 @@ class HipLocalOps:
         x = self.zeros(self.n)
         iters, relres = self._lib._i32(), self._lib._f64()
         self.begin()
-        iface.fuse(own_w)
         rc = self.lib.pf_dist_cg(self.h._ctx, iface.halo._h, int(iface.plan), self._p(K), self._p(b), self._p(dinv),
                                  self._p(own_w), self._p(x), float(rtol), float(atol), int(maxiter or 0), int(check_every or 0),
                                  C.byref(iters), C.byref(relres))
@@ -423,11 +422,57 @@ class Interface:
     def fuse(self, own_w):
         """Prepare this interface's plan for the FUSED exchange (csrc/pf_halo.hip pf_halo_plan_fuse): interface rows leave
         from the product's epilogue, the consuming kernel sums them.  own_w: device tensor, 1 on the dofs this rank owns.
-        Idempotent; peer transport only."""
+        Idempotent.  With more than one rank the fused product is checked ONCE against pf_spmv + the packed exchange,
+        bit for bit, on every rank (every rank calls this at the same point); if any rank fails, the interface falls back
+        to the torch.distributed transport on all of them and False is returned -- the callers then run their Python
+        loops instead of the C loops that need the fused exchange."""
         if self.transport != "peer":
-            raise RuntimeError("the fused exchange runs on the peer-store transport")
+            return False
+        if getattr(self, "_fused", False):
+            return True
         self.halo._check(self.halo.lib.pf_halo_plan_fuse(self.halo._h, int(self.plan), C.c_void_p(own_w.data_ptr())),
                          "pf_halo_plan_fuse")
+        self._fused = True
+        if self.world > 1 and not self._fused_self_test():
+            self._fused = False
+            self.halo, self.plan, self.transport = None, -1, "p2p"
+            self._setup_p2p()
+            return False
+        return True
+
+    def dist_spmv(self, K, x, y):
+        """y = K x complete over the partition through the fused exchange (pf_dist_spmv)."""
+        ops = self.ops
+        ops.begin()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        self.halo._check(self.halo.lib.pf_dist_spmv(ops.h._ctx, self.halo._h, int(self.plan), p(K), p(x), p(y)), "pf_dist_spmv")
+        return y
+
+    def _fused_self_test(self):
+        import torch.distributed as dist
+
+        ops, torch = self.ops, self.ops.torch
+        ok = True
+        try:
+            g = torch.Generator(device="cpu").manual_seed(77 + self.rank)
+            K = torch.rand(ops.h.nnz, generator=g, dtype=torch.float64).to(ops.device)
+            gd = ops.from_numpy((self.part.nodes[:, None] * self.d + np.arange(self.d)).ravel().astype(np.float64), torch.float64)
+            for k in range(3):  # three row messages: both slot parities written, read, overwritten and read again
+                x = 1.0 + 1e-3 * (k + 1) * torch.sin(gd * (0.37 + k))  # consistent: a function of the GLOBAL dof
+                y_fused, y_ref = torch.empty_like(x), torch.empty_like(x)
+                self.dist_spmv(K, x, y_fused)
+                ops.spmv(K, x, y_ref)
+                self.halo.exchange(self.plan, y_ref)
+                self.halo.check()
+                ok = ok and bool(torch.equal(y_fused, y_ref))
+        except Exception as e:  # noqa: BLE001
+            PeerHalo.last_failure = f"fused self-test: {type(e).__name__}: {e}"
+            ok = False
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(ok), group=self.group)
+        if not all(flags) and not PeerHalo.last_failure:
+            PeerHalo.last_failure = "fused self-test: the fused product differs from pf_spmv + packed exchange on some rank"
+        return all(flags)
 
     def fuse_tables(self):
         """Host copies of the fused plan's tables (dict of numpy arrays) -- what tests replay."""
@@ -616,7 +661,7 @@ def dist_cg(ops, K, b, dinv, own_w, iface, rtol=1e-8, atol=0.0, maxiter=None, ch
     n = ops.n
     if native is None:
         native = iface.transport == "peer" and hasattr(ops, "dist_cg_native")
-    if native:
+    if native and iface.fuse(own_w):  # the C loop runs on the fused exchange; a failed self-test leaves the Python loop
         return ops.dist_cg_native(iface, K, b, dinv, own_w, rtol, atol, maxiter, check_every)
     if hasattr(ops, "begin"):
         ops.begin()
@@ -788,7 +833,9 @@ class ReplicatedHierarchy:
         ops._call("pf_vals_to_f32", ops._lib._i64(K.numel()), p(K), p(self._K32))
         a.K32 = p(self._K32)
         a.ltvals = p(self._ltvals)
-        iface.fuse(own_w)  # every product of the loop sends its interface rows from its epilogue
+        if not iface.fuse(own_w):  # every product of the C loop sends its interface rows from its epilogue
+            return None
+        a.halo, a.plan_dof = iface.halo._h, int(iface.plan)
         return a
 
     def setup(self, Kg_vals, reuse=False):

@@ -209,3 +209,109 @@ def test_exchange_tables_line_up_without_a_handshake(kind, world, d):
     for r, p in enumerate(parts):
         gd = (p.nodes[:, None] * d + np.arange(d)).ravel()
         assert np.array_equal(results[r], expect[gd]), r
+
+
+def _fused_tables(part, d, tile_nodes):
+    """The fused plan's tables from libpyfem_hip.so's HOST builder (pf_host_fuse_tables_c: no GPU involved) for this
+    rank's exchange tables."""
+    import ctypes as C
+
+    from pyfem_gpu_testflight_amd import _lib
+
+    lib = _lib.load()
+    t = part.exchange_tables(d)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    nbr, nbr_ptr, send, ifx = i32(t["nbr_rank"]), i32(t["nbr_ptr"]), i32(t["send_idx"]), i32(t["if_idx"])
+    nn = part.nnodes_local
+    own_w = np.repeat(part.owned_mask_nodes.astype(np.float64), d)
+    nt = -(-nn // tile_nodes)
+    out = {"ifslot": np.empty(nn, np.int32), "sh_ptr": np.empty(ifx.size // d + 1, np.int32),
+           "sh_peer": np.empty(max(send.size // d, 1), np.int32), "sh_pos": np.empty(max(send.size // d, 1), np.int32),
+           "tperm": np.empty(nt, np.int32), "flags8": np.empty(nn * d, np.uint8)}
+    dims = (C.c_int64 * 4)()
+    rc = lib.pf_host_fuse_tables_c(nn, d, tile_nodes, int(nbr.size), p(nbr), p(nbr_ptr), p(send), int(ifx.size), p(ifx), None,
+                                   p(own_w), p(out["ifslot"]), p(out["sh_ptr"]), p(out["sh_peer"]), p(out["sh_pos"]),
+                                   p(out["tperm"]), p(out["flags8"]), dims)
+    assert rc == 0, lib.pf_last_error(None)
+    out.update(n_ifnodes=int(dims[0]), n_iftiles=int(dims[1]), ntiles=int(dims[2]), nsharers=int(dims[3]), tables=t)
+    out["sh_peer"], out["sh_pos"] = out["sh_peer"][:out["nsharers"]], out["sh_pos"][:out["nsharers"]]
+    return out
+
+
+def _fused_worker(rank, world, port, kind):
+    """One FUSED exchange replayed over gloo with the product's own tables: the 'product' walks the tiles in tperm order
+    and, for interface nodes, drops the raw row into the message slot of every sharer (sh_peer / sh_pos: what
+    k_spmv<..., SEND> stores over xGMI); the 'consumer' sums in ascending rank order through the plan's src tables
+    (k_dcg_update / k_halo_recv_apply).  Must equal, bit for bit, dist.py's packed exchange and the global product."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyfem_oracle as orc
+        from pyfem_gpu_testflight_amd.dist import ElementBlockPartition, Interface
+        from tests._cpu_ops import NumpyLocalOps
+
+        etype, conn, X, dof_fixed, vals, force = _problem(kind)
+        d, tile = 2, 64
+        part = ElementBlockPartition(conn, X.shape[0], world, rank, d)
+        F = _fused_tables(part, d, tile)
+        t = F["tables"]
+        n = d * part.nnodes_local
+        Kl = orc.assemble_csr(orc.elasticity_Ke(X[part.nodes], part.conn_local.astype(np.int64), etype),
+                              orc.create_conn_dof(part.conn_local.astype(np.int64), d))
+        vg = np.random.RandomState(3).rand(d * X.shape[0])
+        raw = Kl.dot(vg[part.global_dofs()])  # this rank's product: partial sums on interface rows
+        # --- product side: tile walk, interface tiles first; rows of interface nodes go to the sharers' slots
+        assert sorted(F["tperm"]) == list(range(F["ntiles"]))
+        msgs = {int(r): np.full(int(t["nbr_ptr"][i + 1] - t["nbr_ptr"][i]), np.nan) for i, r in enumerate(t["nbr_rank"])}
+        sent_nodes = 0
+        for pos, tl in enumerate(F["tperm"]):
+            for node in range(tl * tile, min(part.nnodes_local, (tl + 1) * tile)):
+                s = F["ifslot"][node]
+                if s < 0:
+                    continue
+                assert pos < F["n_iftiles"], "an interface node outside the tiles that are walked first"
+                sent_nodes += 1
+                for k in range(F["sh_ptr"][s], F["sh_ptr"][s + 1]):
+                    msgs[int(F["sh_peer"][k])][F["sh_pos"][k]:F["sh_pos"][k] + d] = raw[d * node:d * node + d]
+        assert sent_nodes == F["n_ifnodes"] == t["if_idx"].size // d
+        assert all(not np.isnan(m).any() for m in msgs.values())  # every slot of every message was written exactly by the walk
+        # --- the wire (xGMI stores in the product): one message per neighbour
+        recv = {r: np.empty_like(m) for r, m in msgs.items()}
+        ops_ = []
+        for r in msgs:
+            ops_.append(dist.P2POp(dist.isend, torch.from_numpy(msgs[r]), r))
+            ops_.append(dist.P2POp(dist.irecv, torch.from_numpy(recv[r]), r))
+        if ops_:
+            for w in dist.batch_isend_irecv(ops_):
+                w.wait()
+        # --- consumer side: ordered sums through the plan's tables
+        y = raw.copy()
+        for i, li in enumerate(t["if_idx"]):
+            acc = 0.0
+            for q in range(t["src_ptr"][i], t["src_ptr"][i + 1]):
+                sr = int(t["src_rank"][q])
+                acc += raw[li] if sr == rank else recv[sr][t["src_pos"][q]]
+            y[li] = acc
+        # the packed exchange of dist.py on the same input: same bits
+        ops = NumpyLocalOps(n)
+        ref = torch.from_numpy(raw.copy())
+        Interface(ops, part).sum(ref)
+        assert np.array_equal(y, ref.numpy())
+        Kg = orc.assemble_csr(orc.elasticity_Ke(X, conn, etype), orc.create_conn_dof(conn, d))
+        assert np.abs(y - Kg.dot(vg)[part.global_dofs()]).max() < 1e-12 * np.abs(Kg.data).max()
+        # flags: bit 0 owner (lowest sharing rank), bit 1 interface; every global dof owned exactly once
+        fl = F["flags8"]
+        assert np.array_equal(fl & 1, part.own_weight.astype(np.uint8)) and np.array_equal((fl >> 1) & 1, (part.multiplicity > 1).astype(np.uint8))
+        tot = torch.zeros(d * X.shape[0], dtype=torch.float64)
+        tot[torch.from_numpy(part.global_dofs())] += torch.from_numpy((fl & 1).astype(np.float64))
+        dist.all_reduce(tot)
+        assert bool((tot == 1).all())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "quad"), (3, "tri")])
+def test_fused_exchange_replayed_over_gloo(world, kind):
+    mp.spawn(_fused_worker, args=(world, _free_port(), kind), nprocs=world, join=True)
