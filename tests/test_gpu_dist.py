@@ -277,3 +277,62 @@ def test_configuration5_solve_two_ranks_against_one():
     import torch.multiprocessing as mp
 
     mp.spawn(_worker_c5, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_c4(rank, world, port):
+    """BASELINE configuration 4 ("1 -> 8 element partition" of the refined torque arm) across ranks at FULL size:
+    arm.inp red-refined five times (2.55 M triangles, all detJ < 0: a negative definite K), centroid-ordered element
+    blocks, AMG-PCG over the peer transport against the single-context solve of examples/torque_arm/arm.py:19-48."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyfem_gpu_testflight_amd import meshtools, pyfem
+        from pyfem_gpu_testflight_amd.dist import PartitionedElasticity
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        g = np.load(os.path.join(root, "tests", "golden", "arm_tri.npz"))
+        X, conn = g["X"], g["conn"].astype(np.int64)
+        sets = {"fixed": np.unique(g["dof_fixed"] // 2), "load": g["force_nodes"].astype(np.int64)}
+        for _ in range(5):
+            X, conn, sets = meshtools.red_refine_tri(X, conn, sets)
+        assert conn.shape[0] == 2553856
+        dof_fixed = np.stack([2 * sets["fixed"], 2 * sets["fixed"] + 1], axis=1).ravel()
+        fv = g["force_vals"][0]
+        force = {int(nn): [float(fv[0]), float(fv[1])] for nn in sets["load"]}
+        q = pyfem.QuadratureTriangle2D()
+        b = pyfem.BasisTriangle2D(q)
+        pm = PartitionedElasticity(X, conn, dof_fixed, None, force, q, b, elem_order="centroid")
+        assert pm.iface.transport == "peer" and pm.iface.n > 0
+        assert abs(pm.nelems_local - conn.shape[0] / world) <= 1
+        x = pm.solve(precond="amg")  # default tolerance
+        it_dist = pm.last_iters
+        u = pm.gather_global(x).cpu().numpy()
+        # interface copies carry the same bits on both ranks
+        mine = torch.full((2 * X.shape[0],), float("nan"), dtype=torch.float64, device=x.device)
+        mine[torch.from_numpy(pm.part.global_dofs()).to(x.device)] = x
+        lo, hi = torch.nan_to_num(mine, nan=float("inf")), torch.nan_to_num(mine, nan=float("-inf"))
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert bool((lo == hi).all()), "interface copies differ between ranks"
+        if rank == 0:
+            model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+            asm = pyfem.Assembler(model)
+            u_one = asm.solve(method="cg")
+            assert np.abs(u - u_one).max() < 1e-8 * np.abs(u_one).max()
+            assert it_dist <= 1.3 * asm.last_iters + 1, (it_dist, asm.last_iters)
+            f = model.compute_rhs()
+            assert f @ u < 0  # negative definite K: the reference keeps the sign of detJ (SURVEY A.5)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configuration4_refined_arm_two_ranks_against_one():
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_c4, args=(2, _free_port()), nprocs=2, join=True)

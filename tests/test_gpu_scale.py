@@ -156,6 +156,58 @@ def test_c2_full_size_u_against_manufactured_solution(pf, orc, precond):
     assert err < U_TOL, f"{precond}: max error {err:.2e} after {it} iterations"
 
 
+# ---- the metric mesh itself (BASELINE.json: "4M-quad plane-stress") -------------------------------------------------
+def test_metric_mesh_operator_and_u_against_manufactured_solution(pf, orc):
+    """2048x2048 quads, 8 396 802 dofs: the workload `value` and the CG rate of bench.py are quoted on (it
+    was only ever run by the bench).  The reference's own bar at its own size: tests/test_elasticity.py:23-51 (K against
+    ref_plane_stress, u against the direct solve); examples/SciTech2023/verification/verify.py:37-38 at scale.
+      * u from AMG-PCG and from Jacobi-PCG against a manufactured u* (b = K u* from the ORACLE's element matrices);
+      * the assembled operator: HIP K v against the oracle's element-by-element K v at 1e-10 max|K| ||v||_inf;
+      * rigid-body null space, symmetry, positive definiteness, gather == atomic scatter."""
+    from pyfem_gpu_testflight_amd import _lib
+
+    n = 2048
+    conn, X = orc.structured_mesh(n + 1, n + 1, "quad")
+    dof_fixed, _ = orc.elasticity_problem(n + 1, n + 1)
+    assert conn.shape[0] == 4194304 and 2 * X.shape[0] == 8396802
+    err, it = _manufactured_elasticity(pf, orc, X, conn, dof_fixed, "quad", seed=9, precond="amg", cache_key="metric")
+    assert err < U_TOL, f"amg: max error {err:.2e} after {it} iterations"
+    assert it < 40
+    err, itj = _manufactured_elasticity(pf, orc, X, conn, dof_fixed, "quad", seed=9, precond="jacobi", cache_key="metric")
+    assert err < U_TOL, f"jacobi: max error {err:.2e} after {itj} iterations"
+    assert itj > 50 * it
+    # the operator itself, against the same oracle product
+    b = _B_CACHE["metric"]
+    ustar = _smooth_field(X, 9)
+    q, bs = _qb(pf, "quad")
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, {0: [0.0, 0.0]}, q, bs)
+    h = model.hctx
+    torch = h.torch
+    K = model.compute_jacobian()
+    assert h.nnz == 151044100
+    kmax = float(K.vals.abs().max())
+    Kv = h.spmv(K.vals, h.to_device(ustar, torch.float64)).cpu().numpy()
+    assert np.abs(Kv - b).max() <= 1e-10 * kmax * np.abs(ustar).max()
+    Xd = h.to_device(X, torch.float64)
+    modes = torch.zeros(3, h.nrows, dtype=torch.float64, device=h.device)
+    modes[0, 0::2] = 1.0
+    modes[1, 1::2] = 1.0
+    modes[2, 0::2] = -(Xd[:, 1] - Xd[:, 1].mean())
+    modes[2, 1::2] = Xd[:, 0] - Xd[:, 0].mean()
+    for m in modes:
+        assert float(h.spmv(K.vals, m.contiguous()).abs().max()) <= 1e-9 * kmax * float(m.abs().max())
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    x, y = (torch.rand(h.nrows, generator=gen, dtype=torch.float64).to(h.device) for _ in range(2))
+    sxy, syx = float(x.dot(h.spmv(K.vals, y))), float(y.dot(h.spmv(K.vals, x)))
+    assert abs(sxy - syx) <= 1e-12 * abs(sxy)
+    assert float(x.dot(h.spmv(K.vals, x))) > 0.0
+    model.scatter_mode = _lib.PF_SCATTER_ATOMIC
+    Ka = model.compute_jacobian()
+    model.scatter_mode = _lib.PF_SCATTER_GATHER
+    assert float((Ka.vals - K.vals).abs().max()) <= 1e-12 * kmax
+    _B_CACHE.pop("metric", None)
+
+
 # ---- C3 ---------------------------------------------------------------------------------------------------------
 def test_c3_helmholtz_apply_against_sparse_lu_and_full_size_properties(pf, orc):
     """tests/test_helmholtz.py:11-44 at 1024x1024 against the oracle's factorised filter (the reference's own check),
