@@ -322,42 +322,62 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
         filtr = pyfem.Helmholtz(0.05, X, conn, qq, bq)
         model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, qq, bq, p=5.0)
-        filtr.rtol = 1e-8
         h = model.hctx
-        xk = h.to_device(np.random.default_rng(0).uniform(1e-3, 1, X.shape[0]), torch.float64)
-        asm = pyfem.Assembler(model)
-        asm.rtol = 1e-8
+        # a ParOpt-free loop -- design x_k = uniform(1e-3, 1) seeded with k, a fresh field every iteration
+        xs = [h.to_device(np.random.default_rng(k).uniform(1e-3, 1, X.shape[0]), torch.float64) for k in range(4)]
 
-        def iteration():
+        def iteration(xk):
+            """topo.py's two callbacks, in its order.  evalObjCon (:50-67): rho = filtr.apply(x); obj, u =
+            model.compliance(rho); con = volume(rho).  evalObjConGradient (:69-75): rho = filtr.apply(x) AGAIN (the kept
+            result: Helmholtz.apply), g = filtr.apply_gradient(compliance_grad(rho, u)), A = -filtr.apply_gradient(
+            volume_grad(rho)).  Everything stays in HBM."""
             torch.cuda.synchronize()
             t = [time.perf_counter()]
             rho = filtr.apply(xk).clamp(1e-3, 1.0)
             torch.cuda.synchronize()
             t.append(time.perf_counter())
             K = model.compute_jacobian(rho)
-            rhs = h.to_device(model.compute_rhs(), torch.float64)
+            rhs = model.compute_rhs_device()
             K, rhs = model.apply_dirichlet_bcs(K, rhs, True)
             torch.cuda.synchronize()
             t.append(time.perf_counter())
             u = asm._solve_linear_system(K, rhs, "cg")
             comp = float(rhs.dot(u))
+            vol = float(model.volume(rho))
             torch.cuda.synchronize()
             t.append(time.perf_counter())
-            g = model.compliance_grad(rho, u)  # device tensors in -> device tensor out (fused sensitivity kernel)
-            for _ in range(3):
-                filtr.apply_gradient(g)
+            rho2 = filtr.apply(xk).clamp(1e-3, 1.0)
+            reused = filtr.last_reused
+            g = filtr.apply_gradient(model.compliance_grad(rho2, u))
+            it_g = filtr.last_iters
+            a = -filtr.apply_gradient(model.volume_grad(rho2))
             torch.cuda.synchronize()
             t.append(time.perf_counter())
-            return t, comp
+            return t, comp, vol, reused, it_g, (g, a)
 
-        iteration()  # builds the graph-only AMG hierarchies once per mesh and loads every kernel
-        iteration()  # and brings the device to its steady clocks (see Timer)
-        t, comp = iteration()
-        legs["c5"] = {"workload": "one topology-optimisation inner iteration, 2048x1024 quads, nodal density, RAMP p=5, "
-                                  "AMG-PCG rtol 1e-8 (third iteration: hierarchies cached, device warm)",
-                      "filter_apply_s": t[1] - t[0], "filter_iters": filtr.last_iters, "assemble_bc_s": t[2] - t[1],
-                      "elasticity_solve_s": t[3] - t[2], "elasticity_cg_iters": asm.last_iters, "compliance": comp,
-                      "sensitivity_and_three_filter_gradients_s": t[4] - t[3], "iteration_total_s": t[4] - t[0]}
+        c5 = {"workload": "one topology-optimisation inner iteration in topo.py's call order (evalObjCon + evalObjConGradient), "
+                          "2048x1024 quads, nodal density, RAMP p=5; a new random design every iteration, hierarchies' graph "
+                          "parts cached, device warm; every phase synchronised"}
+        for tag, rtol in (("default_rtol", pyfem.DEFAULT_RTOL), ("rtol_1e-8", 1e-8)):
+            asm = pyfem.Assembler(model)
+            asm.rtol = filtr.rtol = rtol
+            iteration(xs[0])  # builds the graph-only AMG hierarchies once per mesh and loads every kernel
+            iteration(xs[1])  # and brings the device to its steady clocks (see Timer)
+            best = None
+            for xk in xs[2:]:
+                t, comp, vol, reused, it_g, _ = iteration(xk)
+                row = {"rtol": rtol, "filter_apply_s": t[1] - t[0], "filter_iters": it_g, "assemble_rhs_bc_s": t[2] - t[1],
+                       "elasticity_solve_s": t[3] - t[2], "elasticity_cg_iters": asm.last_iters, "compliance": comp, "volume": vol,
+                       "second_filter_apply_reused": bool(reused),
+                       "second_apply_sensitivity_and_two_filter_gradients_s": t[4] - t[3], "iteration_total_s": t[4] - t[0]}
+                if best is None or row["iteration_total_s"] < best["iteration_total_s"]:
+                    best = row
+            c5[tag] = best
+        c5["iteration_total_s"] = c5["default_rtol"]["iteration_total_s"]
+        c5["note"] = ("default_rtol = the product's default (1e-11 on ||r||/||b||: what keeps max|u - u*| <= 1e-8 max|u*| on this "
+                      "mesh, tests/test_gpu_scale.py, tools/stop_rule_probe.py); rtol_1e-8 = the reference's own stopping rule "
+                      "(pyfem.py:1827), which leaves ~1e-5 on u here.  iteration_total_s is the default-tolerance time.")
+        legs["c5"] = c5
     return legs
 
 

@@ -60,7 +60,10 @@ struct AmgLevel {
   int32_t* tptr = nullptr;   // (nc+1) transpose pattern: entries of each coarse column, ascending node
   int32_t* tnode = nullptr;  // (np) fine node of the entry
   int32_t* tslot = nullptr;  // (np) its index into pidx / pvals
-  double* ptvals = nullptr;  // (np) the same blocks in transpose order (streamed by the restriction)
+  double* ptvals = nullptr;  // (np) the same blocks in transpose order (streamed by the restriction); PF_AMG_FP32=0 only
+  float* pvals32 = nullptr;  // fp32 copies for the CYCLE's transfers (default): prolongation reads pvals32, restriction streams
+  float* ptvals32 = nullptr; //   ptvals32 = its transpose copy -- the same rounded values, so the cycle stays symmetric.  The
+                             //   Galerkin products and the distributed gathers read the fp64 pvals.
   int64_t np = 0;
   int32_t max_crow = 0;      // longest row of the next level's graph
   bool sa = false;           // this level's transfer uses the stored smoothed P (else the tentative P on the fly)
@@ -785,20 +788,21 @@ __global__ void k_sa_mirror_lower(int64_t nc, const int32_t* __restrict__ cptr, 
 }
 
 // ptvals[e] = pvals[tslot[e]]: P in transpose order, so that the restriction streams it
+template <typename PT>
 __global__ void k_sa_transpose_vals(int64_t np, int bs, const int32_t* __restrict__ tslot,
-                                    const double* __restrict__ pvals, double* __restrict__ ptvals) {
+                                    const double* __restrict__ pvals, PT* __restrict__ ptvals) {
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (q >= np * bs) return;
   const int64_t e = q / bs;
-  ptvals[q] = pvals[(int64_t)tslot[e] * bs + (q - e * bs)];
+  ptvals[q] = (PT)pvals[(int64_t)tslot[e] * bs + (q - e * bs)];
 }
 
 // restriction as a streamed block product with P^T (same scheme as k_amg_spmv: 64 coarse rows per wave tile,
 // lanes stream the tile's contiguous entries, products parked in LDS, lane-per-row sums)
-template <int DR, int DC>
+template <int DR, int DC, typename PT = double>
 __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int32_t* __restrict__ tptr,
                                                            const int32_t* __restrict__ tnode,
-                                                           const double* __restrict__ ptvals,
+                                                           const PT* __restrict__ ptvals,
                                                            const double* __restrict__ resid, double* __restrict__ bc) {
   constexpr int CH = 512;
   __shared__ double prod[CH * DC];
@@ -829,9 +833,9 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
         double Pv[U][DR * DC], rv[U][DR];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const double* Pn = ptvals + (int64_t)ee[u] * DR * DC;
+          const PT* Pn = ptvals + (int64_t)ee[u] * DR * DC;
 #pragma unroll
-          for (int q = 0; q < DR * DC; ++q) Pv[u][q] = Pn[q];
+          for (int q = 0; q < DR * DC; ++q) Pv[u][q] = (double)Pn[q];
 #pragma unroll
           for (int r = 0; r < DR; ++r) rv[u][r] = resid[DR * nn[u] + r];
         }
@@ -862,10 +866,10 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
 // The same restriction with one wave per coarse row, for levels whose columns of P are long and few (3-D: ~200
 // entries per coarse node, 1331 coarse nodes on the second level of 96^3 blocks -- 21 tiles of 64 rows left the
 // stream kernel on 21 waves, 300 us per call).  Lanes stride over the column, fixed-order wave sum: deterministic.
-template <int DR, int DC>
+template <int DR, int DC, typename PT = double>
 __global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int32_t* __restrict__ tptr,
                                                           const int32_t* __restrict__ tnode,
-                                                          const double* __restrict__ ptvals,
+                                                          const PT* __restrict__ ptvals,
                                                           const double* __restrict__ resid, double* __restrict__ bc) {
   const int lane = threadIdx.x & 63;
   const int64_t I = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -875,14 +879,14 @@ __global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int3
   for (int c = 0; c < DC; ++c) acc[c] = 0.0;
   for (int32_t e = tptr[I] + lane; e < tptr[I + 1]; e += 64) {
     const int64_t n = tnode[e];
-    const double* Pn = ptvals + (int64_t)e * DR * DC;
+    const PT* Pn = ptvals + (int64_t)e * DR * DC;
     double rv[DR];
 #pragma unroll
     for (int r = 0; r < DR; ++r) rv[r] = resid[DR * n + r];
 #pragma unroll
     for (int r = 0; r < DR; ++r)
 #pragma unroll
-      for (int c = 0; c < DC; ++c) acc[c] += Pn[r * DC + c] * rv[r];
+      for (int c = 0; c < DC; ++c) acc[c] += (double)Pn[r * DC + c] * rv[r];
   }
 #pragma unroll
   for (int c = 0; c < DC; ++c)
@@ -894,9 +898,9 @@ __global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int3
 }
 
 // x_n += over * sum_J P[n,J] e_J
-template <int DR, int DC>
+template <int DR, int DC, typename PT = double>
 __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
-                             const double* __restrict__ pvals, const double* __restrict__ ec, double* __restrict__ x,
+                             const PT* __restrict__ pvals, const double* __restrict__ ec, double* __restrict__ x,
                              double over) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -918,9 +922,9 @@ __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const 
       double Pv[4][DR * DC], ev[4][DC];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const double* Pn = pvals + (int64_t)qq[u] * DR * DC;
+        const PT* Pn = pvals + (int64_t)qq[u] * DR * DC;
 #pragma unroll
-        for (int k = 0; k < DR * DC; ++k) Pv[u][k] = Pn[k];
+        for (int k = 0; k < DR * DC; ++k) Pv[u][k] = (double)Pn[k];
 #pragma unroll
         for (int c = 0; c < DC; ++c) ev[u][c] = ec[DC * JJ[u] + c];
       }
@@ -935,12 +939,12 @@ __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const 
     }
   } else {
     for (int32_t q = qb; q < qe; ++q) {
-      const double* Pn = pvals + (int64_t)q * DR * DC;
+      const PT* Pn = pvals + (int64_t)q * DR * DC;
       const double* e = ec + DC * (int64_t)pidx[q];
 #pragma unroll
       for (int r = 0; r < DR; ++r)
 #pragma unroll
-        for (int c = 0; c < DC; ++c) s[r] += Pn[r * DC + c] * e[c];
+        for (int c = 0; c < DC; ++c) s[r] += (double)Pn[r * DC + c] * e[c];
     }
   }
 #pragma unroll
@@ -1217,7 +1221,7 @@ void pf_amg_free(pf_ctx* ctx) {
     if (Lv.owns_xy) pf_free(Lv.xy);
     pf_free(Lv.dinv); pf_free(Lv.dinv2); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
     pf_free(Lv.pptr); pf_free(Lv.pidx); pf_free(Lv.pvals); pf_free(Lv.tptr); pf_free(Lv.tnode); pf_free(Lv.tslot);
-    pf_free(Lv.ptvals);
+    pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
   }
   pf_free(H->dense_inv);
@@ -1304,7 +1308,6 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
       if (rc) return rc;
       if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s (%s)\n", l, now() - t_c, dptr_c ? "device" : "host");
       PF_HIP(hipMalloc(&Lv.pvals, sizeof(double) * Lv.np * Lv.dr * dc));
-      PF_HIP(hipMalloc(&Lv.ptvals, sizeof(double) * Lv.np * Lv.dr * dc));
       PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
     }
     Lv.max_crow = 0;
@@ -1372,6 +1375,10 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
 
 __global__ void k_amg_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ o) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) o[i] = (float)a[i];
+}
+
+__global__ void k_round_f32(int64_t n, double* __restrict__ a) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] = (double)(float)a[i];
 }
 
 extern "C" int pf_vals_to_f32(pf_ctx* ctx, int64_t n, const double* vals, float* out) {
@@ -1495,7 +1502,17 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
             k_sa_galerkin<DR_, DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, \
                                                                 Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals); \
           const int bs_ = DR_ * DC_;                                                                             \
-          k_sa_transpose_vals<<<(unsigned)cdiv(Lv.np * bs_, 256), 256, 0, ctx->stream>>>(Lv.np, bs_, Lv.tslot, Lv.pvals, Lv.ptvals); \
+          const size_t nb_ = (size_t)std::max<int64_t>(Lv.np * bs_, 1);                                          \
+          if (fp32) {  /* the cycle's transfers read fp32 copies (row order for P, transpose order for P^T) */    \
+            if (!Lv.pvals32) PF_HIP(hipMalloc(&Lv.pvals32, sizeof(float) * nb_));                                \
+            if (!Lv.ptvals32) PF_HIP(hipMalloc(&Lv.ptvals32, sizeof(float) * nb_));                              \
+            k_amg_to_f32<<<(unsigned)std::min<int64_t>(cdiv(Lv.np * bs_, 256), 8192), 256, 0, ctx->stream>>>(Lv.np * bs_, Lv.pvals, Lv.pvals32); \
+            k_sa_transpose_vals<float><<<(unsigned)cdiv(Lv.np * bs_, 256), 256, 0, ctx->stream>>>(Lv.np, bs_, Lv.tslot, Lv.pvals, Lv.ptvals32); \
+          } else {                                                                                               \
+            pf_free(Lv.pvals32); pf_free(Lv.ptvals32);                                                           \
+            if (!Lv.ptvals) PF_HIP(hipMalloc(&Lv.ptvals, sizeof(double) * nb_));                                 \
+            k_sa_transpose_vals<double><<<(unsigned)cdiv(Lv.np * bs_, 256), 256, 0, ctx->stream>>>(Lv.np, bs_, Lv.tslot, Lv.pvals, Lv.ptvals); \
+          }                                                                                                      \
         } while (0)
         if (Lv.dr == 1) { PF_SAP(2, 1, 1); PF_SAG(1, 1); }
         else if (H->dim == 3 && Lv.dr == 3) { PF_SAP(3, 3, 6); PF_SAG(3, 6); }
@@ -1654,11 +1671,14 @@ static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, do
     if (Lv.sa) {
 #define PF_SAR(DR_, DC_)                                                                                    \
   do {                                                                                                      \
-    if (Lv.np >= 48 * Lv.nc) /* long columns, few of them: a wave per coarse row */                          \
-      k_sa_restrict_wave<DR_, DC_><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
-    else                                                                                                    \
-      k_sa_restrict_stream<DR_, DC_><<<(unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, \
-                                                                                                       Lv.ptvals, o, out); \
+    const unsigned gs_ = (unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096);                                 \
+    if (Lv.np >= 48 * Lv.nc) { /* long columns, few of them: a wave per coarse row */                        \
+      if (Lv.ptvals32) k_sa_restrict_wave<DR_, DC_, float><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out); \
+      else k_sa_restrict_wave<DR_, DC_, double><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
+    } else {                                                                                                 \
+      if (Lv.ptvals32) k_sa_restrict_stream<DR_, DC_, float><<<gs_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out); \
+      else k_sa_restrict_stream<DR_, DC_, double><<<gs_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
+    }                                                                                                        \
   } while (0)
       if (Lv.dr == 1) PF_SAR(1, 1);
       else if (H->dim == 3 && Lv.dr == 3) PF_SAR(3, 6);
@@ -1683,7 +1703,11 @@ static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, do
     const unsigned g = (unsigned)cdiv(Lv.n, 256);
     const double over = Lv.sa ? H->over_sa : H->over;
     if (Lv.sa) {
-#define PF_SAO(DR_, DC_) k_sa_prolong<DR_, DC_><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, xc, c, over)
+#define PF_SAO(DR_, DC_)                                                                                              \
+  do {                                                                                                                \
+    if (Lv.pvals32) k_sa_prolong<DR_, DC_, float><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals32, xc, c, over); \
+    else k_sa_prolong<DR_, DC_, double><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, xc, c, over);  \
+  } while (0)
       if (Lv.dr == 1) PF_SAO(1, 1);
       else if (H->dim == 3 && Lv.dr == 3) PF_SAO(3, 6);
       else if (H->dim == 3) PF_SAO(6, 6);
@@ -1786,9 +1810,9 @@ extern "C" int pf_amg_prolong0(pf_ctx* ctx, const double* x1, double* c) {
 //                        P[e]^T res_local[ltnode[e]]; (ltptr, ltnode, ltslot) is the transpose pattern of those rows,
 //                        ltslot the entry's index in pvals.  Columns without such entries get 0.  One thread per
 //                        coarse node, entries in ascending local node order: deterministic.
-template <int DR, int DC>
+template <int DR, int DC, typename PT = double>
 __global__ void k_sa_prolong_rows(int64_t nl, const int32_t* __restrict__ grow, const int32_t* __restrict__ pptr,
-                                  const int32_t* __restrict__ pidx, const double* __restrict__ pvals,
+                                  const int32_t* __restrict__ pidx, const PT* __restrict__ pvals,
                                   const double* __restrict__ ec, double* __restrict__ x, double over) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= nl) return;
@@ -1808,9 +1832,9 @@ __global__ void k_sa_prolong_rows(int64_t nl, const int32_t* __restrict__ grow, 
     double Pv[4][DR * DC], ev[4][DC];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const double* Pn = pvals + (int64_t)qq[u] * DR * DC;
+      const PT* Pn = pvals + (int64_t)qq[u] * DR * DC;
 #pragma unroll
-      for (int k = 0; k < DR * DC; ++k) Pv[u][k] = Pn[k];
+      for (int k = 0; k < DR * DC; ++k) Pv[u][k] = (double)Pn[k];
 #pragma unroll
       for (int c = 0; c < DC; ++c) ev[u][c] = ec[DC * JJ[u] + c];
     }
@@ -1893,8 +1917,13 @@ extern "C" int pf_amg_prolong0_rows(pf_ctx* ctx, int64_t nl, const int32_t* grow
   AmgLevel& L0 = H->L[0];
   if (nl == 0) return PF_OK;
   const unsigned g = (unsigned)cdiv(nl, 256);
-  if (L0.dr == 1) k_sa_prolong_rows<1, 1><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
-  else k_sa_prolong_rows<2, 3><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
+  if (L0.pvals32) {  // the cycle's transfers read the fp32 copy, like the single-GPU cycle: the same operator
+    if (L0.dr == 1) k_sa_prolong_rows<1, 1, float><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals32, x1, c_local, H->over_sa);
+    else k_sa_prolong_rows<2, 3, float><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals32, x1, c_local, H->over_sa);
+  } else {
+    if (L0.dr == 1) k_sa_prolong_rows<1, 1, double><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
+    else k_sa_prolong_rows<2, 3, double><<<g, 256, 0, ctx->stream>>>(nl, grow, L0.pptr, L0.pidx, L0.pvals, x1, c_local, H->over_sa);
+  }
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -1922,7 +1951,10 @@ extern "C" int pf_amg_p0_gather(pf_ctx* ctx, int64_t nlt, const int32_t* ltslot,
   if (nlt == 0) return PF_OK;
   AmgLevel& L0 = ctx->amg->L[0];
   const int bs = L0.dr * ctx->amg->L[1].dr;
-  k_sa_transpose_vals<<<(unsigned)cdiv(nlt * bs, 256), 256, 0, ctx->stream>>>(nlt, bs, ltslot, L0.pvals, ltvals);
+  k_sa_transpose_vals<double><<<(unsigned)cdiv(nlt * bs, 256), 256, 0, ctx->stream>>>(nlt, bs, ltslot, L0.pvals, ltvals);
+  if (L0.pvals32) {  // the single-GPU cycle restricts with the fp32-rounded blocks: round the gathered copy the same way
+    k_round_f32<<<(unsigned)std::min<int64_t>(cdiv(nlt * bs, 256), 8192), 256, 0, ctx->stream>>>(nlt * bs, ltvals);
+  }
   PF_LAUNCH_CHECK();
   return PF_OK;
 }

@@ -577,6 +577,22 @@ class LinearElasticity(ModelBase):
         self.rhs[self.dof_each_node[nodes].flatten()] = np.array(list(self.nodal_force.values())).flatten()
         return self.rhs
 
+    def compute_rhs_device(self):
+        """The right-hand side a fresh model's compute_rhs() returns -- zeros with the point loads assigned
+        (pyfem.py:1761-1768) -- as a NEW device tensor, without the 8 bytes per dof of host upload compute_rhs() costs the
+        device path (0.6 of the 0.9 ms that assembly + conditions take at configuration 5's size).  Built once from
+        nodal_force and cloned; what host code wrote into model.rhs by hand is not in it (compute_rhs() keeps that
+        reference behaviour)."""
+        torch = self.hctx.torch
+        if getattr(self, "_rhs_dev", None) is None:
+            t = torch.zeros(self.ndof, dtype=torch.float64, device=self.hctx.device)
+            nodes = list(self.nodal_force.keys())
+            if nodes:
+                idx = torch.as_tensor(np.asarray(self.dof_each_node[nodes]).flatten(), dtype=torch.int64, device=self.hctx.device)
+                t[idx] = torch.as_tensor(np.array(list(self.nodal_force.values()), dtype=float).flatten(), device=self.hctx.device)
+            self._rhs_dev = t
+        return self._rhs_dev.clone()
+
     def _rho_device(self, rho):
         torch = self.hctx.torch
         if isinstance(rho, torch.Tensor):
@@ -635,6 +651,15 @@ class LinearElasticity(ModelBase):
         """ref: pyfem.py:1798-1834."""
         assert solver == "direct" or solver == "cg" or solver == "gmres"
         K = self.compute_jacobian(rho)
+        torch = self.hctx.torch
+        if isinstance(rho, torch.Tensor):  # a device density (the optimisation loop keeps its fields in HBM): nothing
+            rhs = self.compute_rhs_device()  # crosses PCIe -- (c, u) with u a device tensor
+            K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
+            asm = getattr(self, "_asm", None) or Assembler(self)
+            asm.rtol = getattr(self, "rtol", asm.rtol)
+            u = asm._solve_linear_system(K, rhs, solver)
+            self.last_iters = asm.last_iters
+            return float(rhs.dot(u)), u
         rhs = self.compute_rhs()
         K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
         asm = Assembler(self)
@@ -647,7 +672,10 @@ class LinearElasticity(ModelBase):
         return rho.sum() / self.nnodes
 
     def volume_grad(self, rho):
-        """ref: pyfem.py:1862-1870."""
+        """ref: pyfem.py:1862-1870 (device density in -> device tensor out)."""
+        torch = self.hctx.torch
+        if isinstance(rho, torch.Tensor):
+            return torch.full((self.nnodes,), 1.0 / self.nnodes, dtype=torch.float64, device=rho.device)
         return np.ones(self.nnodes) / self.nnodes
 
     @time_this
@@ -688,6 +716,9 @@ class Helmholtz(ModelBase):
         self.rtol = DEFAULT_RTOL
         self.precond = DEFAULT_PRECOND
         self.last_iters = 0
+        self.reuse_forward = True   # apply(x) of an unchanged device tensor returns the kept result (see apply)
+        self._last_apply = None
+        self.last_reused = False
 
     def _solve(self, b_dev):
         pc = _PRECOND[self.precond]
@@ -699,11 +730,22 @@ class Helmholtz(ModelBase):
 
     @time_this
     def apply(self, x):
-        """ref: pyfem.py:2102-2107."""
+        """ref: pyfem.py:2102-2107.  The optimisation callbacks filter the SAME design twice per iteration (evalObjCon and
+        evalObjConGradient both start with filtr.apply(x), topo.py:52, 71): for a device tensor the last result is kept
+        and returned again (a fresh clone) while the tensor object and its version counter are unchanged -- any in-place
+        write to x bumps the counter, a new tensor is a new object; numpy inputs are always solved."""
         torch = self.hctx.torch
         on_device = isinstance(x, torch.Tensor)
+        if on_device and self.reuse_forward:
+            c = self._last_apply
+            if c is not None and c[0] is x and c[1] == x._version and c[3] == (self.rtol, self.precond):
+                self.last_iters, self.last_reused = c[4], True
+                return c[2].clone()
         xd = x if on_device else self.hctx.to_device(x, torch.float64)
         rho = self._solve(self.hctx.spmv(self.R.vals, xd))
+        self.last_reused = False
+        if on_device and self.reuse_forward:
+            self._last_apply = (x, x._version, rho.clone(), (self.rtol, self.precond), self.last_iters)
         return rho if on_device else rho.cpu().numpy()
 
     @time_this
