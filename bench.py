@@ -348,9 +348,9 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
             t.append(time.perf_counter())
             rho2 = filtr.apply(xk).clamp(1e-3, 1.0)
             reused = filtr.last_reused
-            g = filtr.apply_gradient(model.compliance_grad(rho2, u))
+            g, a = filtr.apply_gradient_pair(model.compliance_grad(rho2, u), model.volume_grad(rho2))  # topo.py:73-74, concurrently
+            a = -a
             it_g = filtr.last_iters
-            a = -filtr.apply_gradient(model.volume_grad(rho2))
             torch.cuda.synchronize()
             t.append(time.perf_counter())
             return t, comp, vol, reused, it_g, (g, a)

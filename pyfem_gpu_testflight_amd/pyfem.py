@@ -757,6 +757,50 @@ class Helmholtz(ModelBase):
         gx = self.hctx.spmv(self.RT.vals, self._solve(gd))
         return gx if on_device else gx.cpu().numpy()
 
+    def apply_gradient_pair(self, g1, g2):
+        """(apply_gradient(g1), apply_gradient(g2)) -- the two gradient filters evalObjConGradient issues back to back
+        (topo.py:73-74) -- solved CONCURRENTLY: the second runs on a twin context (same mesh, same K, its own hierarchy
+        and work vectors, built on first use) from a second host thread on its own HIP stream.  An AMG-PCG iteration of
+        the filter is two fifths bandwidth (the finest level's products) and three fifths dependent-launch latency of
+        the small coarse levels; two independent solves fill each other's gaps (measured: the pair in ~1.4x the time of
+        one, bench.py c5).  Device tensors in, device tensors out; numpy inputs are solved one after the other."""
+        torch = self.hctx.torch
+        if not (isinstance(g1, torch.Tensor) and isinstance(g2, torch.Tensor)):
+            return self.apply_gradient(g1), self.apply_gradient(g2)
+        import threading
+
+        if getattr(self, "_twin", None) is None:
+            self._twin = Helmholtz(self.r0, self.X, self.conn, self.quadrature, self.basis, device=self.hctx.device.index)
+            self._pair_streams = (torch.cuda.Stream(device=self.hctx.device), torch.cuda.Stream(device=self.hctx.device))
+        twin = self._twin
+        twin.rtol, twin.precond = self.rtol, self.precond
+        main = torch.cuda.current_stream(self.hctx.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        out, err = [None, None], [None, None]
+
+        def work(i, filt, g, stream):
+            try:
+                with torch.cuda.stream(stream):
+                    stream.wait_event(ready)
+                    out[i] = filt.apply_gradient(g)
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the calling thread
+                err[i] = e
+
+        t = threading.Thread(target=work, args=(1, twin, g2, self._pair_streams[1]))
+        t.start()
+        work(0, self, g1, self._pair_streams[0])
+        t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        for i in (0, 1):
+            main.wait_stream(self._pair_streams[i])
+            out[i].record_stream(main)
+            (g1, g2)[i].record_stream(self._pair_streams[i])
+        self.last_iters = max(self.last_iters, twin.last_iters)
+        return out[0], out[1]
+
     @time_this
     def compute_rhs(self, x):
         """ref: pyfem.py:2118-2120."""

@@ -1422,3 +1422,39 @@ def test_user_defined_basis_runs_on_the_table_driven_kernels(pf, orc):
         orc.create_conn_dof(conn, 3)), rhs, dof_fixed, None, True)
     u = pf.Assembler(model).solve(method="cg")
     assert relmax(u, spsolve(Kbc.tocsc(), rbc)) < U_TOL
+
+
+def test_filter_forward_reuse_and_concurrent_gradient_pair(pf):
+    """The two device-side shortcuts of the optimisation callbacks (topo.py:50-75): apply(x) of an unchanged device tensor
+    returns the kept result (and solves again after ANY in-place write to x or for another tensor), and
+    apply_gradient_pair solves the two gradient filters concurrently on a twin context -- same bits as one after the
+    other, because each solve is the same deterministic kernel sequence on its own context."""
+    import torch
+
+    c = pf.ProblemCreator(97, 61)
+    conn, X, x0 = c.create_helmhotz_problem()
+    q = pf.QuadratureBilinear2D()
+    filtr = pf.Helmholtz(0.08, X, conn, q, pf.BasisBilinear2D(q))
+    h = filtr.hctx
+    x = h.to_device(x0, torch.float64)
+    r1 = filtr.apply(x)
+    assert not filtr.last_reused
+    r2 = filtr.apply(x)
+    assert filtr.last_reused and torch.equal(r1, r2) and r2.data_ptr() != r1.data_ptr()
+    r2.mul_(2.0)  # the caller may do what it likes with a returned tensor
+    assert torch.equal(filtr.apply(x), r1)
+    x.add_(0.25)  # in-place write: version counter moves, the kept result is stale
+    r3 = filtr.apply(x)
+    assert not filtr.last_reused and not torch.equal(r3, r1)
+    assert float((r3 - r1 - 0.25).abs().max()) < 1e-9  # the filter preserves constants (K 1 = R 1)
+    r4 = filtr.apply(x.clone())  # another tensor object with the same content: solved, same bits
+    assert not filtr.last_reused and torch.equal(r4, r3)
+    assert np.allclose(filtr.apply(x0 + 0.25), r3.cpu().numpy(), rtol=0, atol=1e-12)  # numpy: always solved
+    g1 = torch.cos(7 * h.to_device(X[:, 0].copy(), torch.float64)) + 0.3
+    g2 = torch.full_like(g1, 1.0 / X.shape[0])
+    a1, a2 = filtr.apply_gradient(g1), filtr.apply_gradient(g2)
+    for _ in range(3):
+        b1, b2 = filtr.apply_gradient_pair(g1, g2)
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    n1, n2 = filtr.apply_gradient_pair(g1.cpu().numpy(), g2.cpu().numpy())
+    assert np.array_equal(n1, a1.cpu().numpy()) and np.array_equal(n2, a2.cpu().numpy())
