@@ -411,21 +411,8 @@ int pf_vals_to_f32(pf_ctx* ctx, int64_t n, const double* vals, float* out);
 int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x, double* work, double rtol, double atol,
                     int maxiter, int check_every, int32_t* iters_host, double* relres_host);
 
-/* ---- timing helper: average device time (ms) of `reps` back-to-back launches of one
- *      kernel family on the ctx stream, measured with HIP events (bench.py roofline leg). -- */
-enum { PF_K_ASSEMBLE_ELASTICITY = 0, PF_K_SPMV = 1, PF_K_ASSEMBLE_HELMHOLTZ = 2 };
-int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in0, const double* in1,
-                   double* out0, double E, double nu, double p, double* ms_host);
-
-/* ---- HBM ceiling of THIS device in THIS process (bench.py: `frac_of_measured` next to the spec-sheet fraction).
- *      Streams `nbytes` of scratch (allocated and freed inside) `reps` times with persistent waves that each walk whole
- *      64 KiB runs with 16-byte lane accesses (the friendliest walk: scattered 1 KiB pieces reach a third less);
- *      ms_host = average milliseconds per pass (HIP events).  No counterpart in the reference.
- *      mode PF_HBM_FILL: write only;  PF_HBM_READ: read only;  PF_HBM_MIX: one quarter read, three quarters
- *      written (the byte mix of the quad assembly: K written once, records + coordinates read).
- *      nt: 0 plain accesses, 1 non-temporal loads and stores, 2 non-temporal stores only (what the assembly does). */
-enum { PF_HBM_FILL = 0, PF_HBM_READ = 1, PF_HBM_MIX = 2 };
-int pf_hbm_probe(pf_ctx* ctx, int mode, int nt, int64_t nbytes, int reps, double* ms_host);
+/* Measurement helpers of bench.py (pf_time_kernel, pf_hbm_probe) are NOT part of the drop-in boundary: they are declared in
+ * pyfem_hip_bench.h and live in their own translation unit (csrc/pf_bench.hip). */
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libpyfem_hip.so")
-SOURCES = ["pf_pattern.hip", "pf_assemble.hip", "pf_assemble3d.hip", "pf_tabular.hip", "pf_solve.hip", "pf_amg.hip", "pf_halo.hip", "pf_dist.hip"]
+SOURCES = ["pf_pattern.hip", "pf_assemble.hip", "pf_assemble3d.hip", "pf_tabular.hip", "pf_solve.hip", "pf_amg.hip", "pf_halo.hip", "pf_dist.hip", "pf_bench.hip"]
 LIB_EXP = os.path.join(PKG, "libpyfem_hip_exp.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
@@ -42,7 +42,7 @@ def build(force=False, verbose=True, experiments=False):
     flags = FLAGS + (["-DPF_EXPERIMENTS", "-DPF_SPMV_SWEEP"] if experiments else [])
     lib = LIB_EXP if experiments else LIB
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "pf_common.h"), os.path.join(CSRC, "pf_hostlogic.h"), os.path.join(INC, "pyfem_hip.h")]
+    headers = [os.path.join(CSRC, "pf_common.h"), os.path.join(CSRC, "pf_hostlogic.h"), os.path.join(INC, "pyfem_hip.h"), os.path.join(INC, "pyfem_hip_bench.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
