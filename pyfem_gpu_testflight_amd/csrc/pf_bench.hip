@@ -12,8 +12,10 @@ extern "C" int pf_time_kernel(pf_ctx* ctx, int which, int reps, const double* in
   PF_HIP(hipEventCreate(&e0));
   PF_HIP(hipEventCreate(&e1));
   int rc = PF_OK;
-  for (int pass = 0; pass < 2 && rc == PF_OK; ++pass) {  // pass 0 = warm-up
-    const int nrep = pass ? reps : 1;
+  // pass 0 = warm-up ON THE TIMED KERNEL: after the device has run another kernel (or idled) the first ~100 launches are up
+  // to 10 % slower (profiles/r03_spmv_placement.md, r02_launch_series.json); one warm-up launch measured that ramp
+  for (int pass = 0; pass < 2 && rc == PF_OK; ++pass) {
+    const int nrep = pass ? reps : std::max(reps, 100);
     PF_HIP(hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < nrep && rc == PF_OK; ++i) {
       if (which == PF_K_ASSEMBLE_ELASTICITY && ctx->ndims == 3) rc = pf_assemble_elasticity3d(ctx, E, nu, p, in0, out0);

@@ -1187,47 +1187,19 @@ static double host_sum(const double* v, int n) {
   return s;
 }
 
-// Where the product's OUTPUT vector lies relative to the value array decides between two times of the same launch
-// (2x2 blocks, 8.4 M dofs: 0.208 against 0.235 ms, reproducible per pair of allocations, no pattern in the virtual
-// addresses: DESIGN 3.2, tools/spmv_placement.py).  pf_cg owns that vector, so it places it by measurement: three
-// candidate allocations, a few products into each, keep the fastest.  Once per context and size (about 4 ms at 8.4 M
-// dofs; skipped below 1 M dofs, where the iteration is launch-bound).
+// The product's output vector of the PCG loops, owned by the context.  Round 2 "placed it by measurement" (three candidate
+// allocations, the fastest of a few launches each kept), on the belief that the product runs at two speeds depending on
+// where its OUTPUT lies.  Round 3 took that apart (profiles/r03_spmv_placement.md): in a warm process every output
+// allocation gives the same time to 0.4 %; what the three-candidate timing saw was the ramp of the first ~100 launches
+// after the device switches kernels, and the real two-speed effect (0.212 against 0.235 ms) belongs to the MATRIX value
+// buffer, which the caller owns.  So: one allocation, no measurement.
 static int cg_place_ap(pf_ctx* ctx, const double* vals, double* xprobe, int64_t n) {
+  (void)vals;
+  (void)xprobe;
   if (ctx->cg_ap && ctx->cg_ap_n == n) return PF_OK;
   pf_free(ctx->cg_ap);
   ctx->cg_ap_n = 0;
-  constexpr int NC = 3;
-  double* cand[NC] = {nullptr, nullptr, nullptr};
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  int best = 0, rc = PF_OK;
-  auto body = [&]() -> int {
-    for (int c = 0; c < NC; ++c) PF_HIP(hipMalloc(&cand[c], sizeof(double) * n));
-    if (n < ((int64_t)1 << 20)) return PF_OK;
-    PF_HIP(hipMemsetAsync(xprobe, 0, sizeof(double) * n, ctx->stream));
-    PF_HIP(hipEventCreate(&e0));
-    PF_HIP(hipEventCreate(&e1));
-    float tbest = 0.f;
-    for (int c = 0; c < NC; ++c) {
-      int r2 = PF_OK;
-      for (int i = 0; i < 2 && !r2; ++i) r2 = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
-      PF_HIP(hipEventRecord(e0, ctx->stream));
-      for (int i = 0; i < 4 && !r2; ++i) r2 = pf_launch_spmv(ctx, vals, xprobe, cand[c], nullptr);
-      PF_HIP(hipEventRecord(e1, ctx->stream));
-      PF_HIP(hipEventSynchronize(e1));
-      if (r2) return r2;
-      float ms = 0.f;
-      PF_HIP(hipEventElapsedTime(&ms, e0, e1));
-      if (c == 0 || ms < tbest) { tbest = ms; best = c; }
-    }
-    return PF_OK;
-  };
-  rc = body();
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  for (int c = 0; c < NC; ++c)
-    if ((rc || c != best) && cand[c]) (void)hipFree(cand[c]);
-  if (rc) return rc;
-  ctx->cg_ap = cand[best];
+  PF_HIP(hipMalloc(&ctx->cg_ap, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
   ctx->cg_ap_n = n;
   return PF_OK;
 }
