@@ -1599,6 +1599,12 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0) {
   double* cur[AMG_MAX_LEVELS];
   double* oth[AMG_MAX_LEVELS];
   int rc;
+  // (Round 3 tried the levels below a few thousand nodes in ONE single-workgroup launch -- two sweeps, residual,
+  // restriction, dense solve, prolongation, two sweeps, __syncthreads between the phases -- to replace 15-22 dependent
+  // launches of ~5.5 us.  One compute unit needs 3-8 us per phase itself (two or three dependent trips to a cold L2 per
+  // phase, ~130 GB/s of L2 bandwidth): k_amg_tail took 119 us for the filter's three smallest levels and 53 us for the
+  // elasticity hierarchy's two, against 82 - 120 us as launches; solves 6.5 against 5.9 ms and 25.5 against 25.4 ms
+  // (profiles/r03_vcycle_tail_ab.jsonl).  Not kept.)
   // down
   for (int l = l0; l < Lc; ++l) {
     AmgLevel& Lv = H->L[l];
