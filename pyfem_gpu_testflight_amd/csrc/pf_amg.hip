@@ -65,6 +65,15 @@ struct AmgLevel {
   float* ptvals32 = nullptr; //   ptvals32 = its transpose copy -- the same rounded values, so the cycle stays symmetric.  The
                              //   Galerkin products and the distributed gathers read the fp64 pvals.
   int64_t np = 0;
+  // two-step Galerkin product (A P first): pattern of A P, row n = the aggregates in the rows of P of n's neighbours
+  int32_t* apptr = nullptr;  // (n+1)
+  int32_t* apidx = nullptr;  // (nap) aggregate ids, ascending per row
+  int32_t* aprow = nullptr;  // (nap) the row of every entry
+  double* apvals = nullptr;  // (nap) blocks of dr x dc(next level)
+  int64_t nap = 0;
+  int32_t* gptr = nullptr;   // (next level's nblk + 1) gather plan of P^T (A P): the (P block, A P block) pairs of every coarse
+  int2* gpair = nullptr;     //   entry (I, J >= I), in ascending fine-node order; entries below the diagonal have none
+  int64_t ngpair = 0;
   int32_t max_crow = 0;      // longest row of the next level's graph
   bool sa = false;           // this level's transfer uses the stored smoothed P (else the tentative P on the fly)
   // work vectors
@@ -93,6 +102,7 @@ struct pf_amg {
   double cheb = 4.4;            // PF_AMG_CHEB: the two sweeps target [lambda_max / cheb, lambda_max]; <= 1: equal factors
   double over_sa = 1.0;         // the same for levels with a smoothed prolongator: no over-correction needed
   double omega_scale = 1.0;
+  bool two_step = true;         // Galerkin products as P^T (A P) (k_sa_ap, k_sa_ptap); PF_AMG_TWOSTEP=0 (experiments): one sweep
 };
 
 // host-side graph logic (greedy aggregation, coarse graphs, host fallback of the prolongator patterns): pf_hostlogic.h --
@@ -359,7 +369,11 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_wave(int64_t nc, const int3
 //   AMG_SMOOTH y = x + dinv .* (b - A x)     (one damped-Jacobi sweep, y != x)
 //   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv2 .* (b - A x1)
 enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
-template <int D, int MODE, typename VT>
+// TR = rows per wave tile.  64 on the large levels (bandwidth); 16 on the small ones (n <= AMG_SMALL_LEVEL), where a tile's
+// ~25 x 64 entries took two to four dependent chunks and the kernel 8 - 9 us of pure latency against ~5.5 us with a
+// single chunk per wave and four times as many waves (r03).
+static constexpr int64_t AMG_SMALL_LEVEL = 65536;
+template <int D, int MODE, typename VT, int TR = 64>
 __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
                                                  const int32_t* __restrict__ idx, const VT* __restrict__ vals,
                                                  const double* __restrict__ x, double* __restrict__ y,
@@ -368,13 +382,13 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
   constexpr int CH = 448;
   __shared__ double prod[CH * D];
   const int lane = threadIdx.x;
-  const int64_t ntiles = (n + 63) / 64;
+  const int64_t ntiles = (n + TR - 1) / TR;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t i = tile * 64 + lane;
-    const bool valid = i < n;
+    const int64_t i = tile * TR + lane;
+    const bool valid = lane < TR && i < n;
     const int32_t rb = valid ? ptr[i] : 0, re = valid ? ptr[i + 1] : 0;
     const int32_t base = __shfl(rb, 0);
-    const int32_t end = ptr[min(n, (tile + 1) * 64)];
+    const int32_t end = ptr[min(n, (tile + 1) * TR)];
     double acc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) acc[k] = 0.0;
@@ -799,7 +813,7 @@ __global__ void k_sa_transpose_vals(int64_t np, int bs, const int32_t* __restric
 
 // restriction as a streamed block product with P^T (same scheme as k_amg_spmv: 64 coarse rows per wave tile,
 // lanes stream the tile's contiguous entries, products parked in LDS, lane-per-row sums)
-template <int DR, int DC, typename PT = double>
+template <int DR, int DC, typename PT = double, int TR = 64>
 __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int32_t* __restrict__ tptr,
                                                            const int32_t* __restrict__ tnode,
                                                            const PT* __restrict__ ptvals,
@@ -807,13 +821,13 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
   constexpr int CH = 512;
   __shared__ double prod[CH * DC];
   const int lane = threadIdx.x;
-  const int64_t ntiles = (nc + 63) / 64;
+  const int64_t ntiles = (nc + TR - 1) / TR;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t I = tile * 64 + lane;
-    const bool valid = I < nc;
+    const int64_t I = tile * TR + lane;
+    const bool valid = lane < TR && I < nc;
     const int32_t rb = valid ? tptr[I] : 0, re = valid ? tptr[I + 1] : 0;
     const int32_t base = __shfl(rb, 0);
-    const int32_t end = tptr[min(nc, (tile + 1) * 64)];
+    const int32_t end = tptr[min(nc, (tile + 1) * TR)];
     double acc[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) acc[c] = 0.0;
@@ -963,11 +977,12 @@ __global__ void k_amg_to_dense(int64_t n, const int32_t* __restrict__ ptr, const
       for (int l = 0; l < D; ++l) A[(D * i + k) * m + D * (int64_t)idx[g] + l] = vals[(int64_t)g * D * D + k * D + l];
 }
 
+template <int T>  // T x T entries per thread: T = 4 covers m <= 128 (the 108 dofs of a 36-node plane coarsest level), 5 the cap
 __global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ A, int m) {
   // in-place Gauss-Jordan without pivoting (definite matrix); rows/cols with a zero pivot are treated as identity.
   // The matrix lives in registers: thread (ty, tx) owns the entries (ty + 32 a, tx + 32 b); each step the owners of
   // the pivot row and column publish them through LDS (double-buffered: one barrier per step).
-  constexpr int T = (AMG_COARSEST_DOFS + 31) / 32;
+  static_assert(T * 32 >= 128 && (AMG_COARSEST_DOFS + 31) / 32 <= 5, "dense inverse tiles");
   __shared__ double piv_row[2][T * 32];
   __shared__ double piv_col[2][T * 32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1128,6 +1143,165 @@ __global__ void k_sa_crow(int64_t nc, const int32_t* __restrict__ tptr, const in
     for (int k = 0; k < cnt; ++k) cidx[cptr[I] + k] = arr[k];
 }
 
+// rows of A P: the aggregates in the rows of P of node n's neighbours (count pass, then fill pass)
+__global__ void k_sa_aprow(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                           const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx, int32_t* __restrict__ count,
+                           const int32_t* __restrict__ apptr, int32_t* __restrict__ apidx, int32_t* __restrict__ flag) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t arr[SA_PCAP];
+  int cnt = 0;
+  bool ok = true;
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+    const int32_t m = idx[g];
+    for (int32_t s2 = pptr[m]; s2 < pptr[m + 1]; ++s2) ok = sa_insert(arr, cnt, SA_PCAP, pidx[s2]) && ok;
+  }
+  if (!ok) flag[0] = 1;
+  if (count) count[i] = cnt;
+  else
+    for (int k = 0; k < cnt; ++k) apidx[apptr[i] + k] = arr[k];
+}
+
+// ---- Galerkin product in two steps (round 3) ----------------------------------------------------------------------
+// k_sa_galerkin_wave forms P^T A P in one sweep: every (fine node of the column, neighbour, entry of the neighbour's row
+// of P) triple adds a block into an LDS image of the coarse row -- 630 triples per row on quads, most of them onto a
+// handful of addresses: 97 % of its issue stalls waited for the LDS, 39 % of the LDS cycles were same-address conflicts
+// (profiles/r02_pmc_amg_setup.txt), 2.56 ms on configuration 5's finest level.  Two steps with NO atomics instead:
+//   k_sa_ap     (A P)[n, J] = sum_m A[n, m] P[m, J]: one lane per (n, J) entry of the pattern of A P; it walks the row of A
+//               and looks J up in the (<= 4-entry, sorted) row of P of each neighbour
+//   k_sa_ptap   C[I, J] = sum_{n in column I of P} P[n, I]^T (A P)[n, J], J >= I: one lane per (I, J) entry of the coarse
+//               graph; which (P block, A P block) pairs it sums is a GATHER PLAN built once per pattern (k_sa_gplan: 113
+//               pairs per coarse row on quads, 8 bytes each) -- looking J up in the rows of A P inside the numeric kernel
+//               cost a dozen dependent loads per fine node (first version: 1.8 ms).  Every output block is accumulated in
+//               registers by its own lane in ascending fine-node order (deterministic) and written once;
+//               k_sa_mirror_lower fills the lower triangle as before.
+template <int DR, int DC>
+__global__ __launch_bounds__(256) void k_sa_ap(int64_t nap, const int32_t* __restrict__ aprow, const int32_t* __restrict__ apidx,
+                                              const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                              const double* __restrict__ vals, const int32_t* __restrict__ pptr,
+                                              const int32_t* __restrict__ pidx, const double* __restrict__ pvals,
+                                              double* __restrict__ apvals) {
+  // one lane per entry (n, J) of the pattern of A P; the entries of a node are consecutive, so the ~10 lanes of a node read
+  // the same row of A and the same rows of P (broadcast loads).  aprow[q] = n (a bisection of apptr cost 21 dependent loads;
+  // 16 lanes per node with a loop over the row's entries was twice as slow again: r03)
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nap) return;
+  const int64_t i = aprow[q];
+  const int32_t J = apidx[q];
+  double acc[DR][DC];
+#pragma unroll
+  for (int r = 0; r < DR; ++r)
+#pragma unroll
+    for (int c = 0; c < DC; ++c) acc[r][c] = 0.0;
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+    const int32_t m = idx[g];
+    int32_t s2 = pptr[m];
+    const int32_t se = pptr[m + 1];
+    while (s2 < se && pidx[s2] < J) ++s2;
+    if (s2 == se || pidx[s2] != J) continue;
+    const double* a = vals + (int64_t)g * DR * DR;
+    const double* Pm = pvals + (int64_t)s2 * DR * DC;
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < DR; ++tt) sacc += a[r * DR + tt] * Pm[tt * DC + c];
+        acc[r][c] += sacc;
+      }
+  }
+  double* dst = apvals + q * DR * DC;
+#pragma unroll
+  for (int r = 0; r < DR; ++r)
+#pragma unroll
+    for (int c = 0; c < DC; ++c) dst[r * DC + c] = acc[r][c];
+}
+
+__global__ void k_sa_aprow_of(int64_t n, const int32_t* __restrict__ apptr, int32_t* __restrict__ aprow) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int32_t k = apptr[i]; k < apptr[i + 1]; ++k) aprow[k] = (int32_t)i;
+}
+
+// Gather plan of the second step, once per pattern: one wave per coarse row I, lane k = the row's k-th entry J_k; the
+// column of I is walked in ascending fine-node order and every lane with J_k >= I notes, for each fine node whose row of
+// A P holds J_k, the pair (slot of P[n, I], slot of (A P)[n, J_k]).  count != NULL: count pass, else fill pass.
+__global__ __launch_bounds__(64) void k_sa_gplan(int64_t nc, const int32_t* __restrict__ tptr, const int32_t* __restrict__ tnode,
+                                                 const int32_t* __restrict__ tslot, const int32_t* __restrict__ apptr,
+                                                 const int32_t* __restrict__ apidx, const int32_t* __restrict__ cptr,
+                                                 const int32_t* __restrict__ cidx, int32_t* __restrict__ count,
+                                                 const int32_t* __restrict__ gptr, int2* __restrict__ gpair) {
+  const int lane = threadIdx.x;
+  for (int64_t I = blockIdx.x; I < nc; I += gridDim.x) {
+    const int32_t cb = cptr[I], clen = cptr[I + 1] - cb;
+    for (int32_t k0 = 0; k0 < clen; k0 += 64) {  // rows longer than a wave: 64 entries at a time
+      const int32_t k = k0 + lane;
+      const int32_t J = k < clen ? cidx[cb + k] : -1;
+      const bool mine = J >= (int32_t)I;
+      int32_t cnt = 0;
+      const int32_t gb = (!count && mine) ? gptr[cb + k] : 0;
+      for (int32_t e = tptr[I]; e < tptr[I + 1]; ++e) {
+        const int64_t nd = tnode[e];
+        const int32_t ab = apptr[nd], ae = apptr[nd + 1];
+        if (!mine) continue;
+        int32_t s2 = ab;
+        while (s2 < ae && apidx[s2] < J) ++s2;
+        if (s2 == ae || apidx[s2] != J) continue;
+        if (!count) gpair[gb + cnt] = make_int2(tslot[e], s2);
+        ++cnt;
+      }
+      if (count && k < clen) count[cb + k] = cnt;
+    }
+  }
+}
+
+template <int DR, int DC>
+__global__ __launch_bounds__(256) void k_sa_ptap(int64_t nq, const int32_t* __restrict__ gptr, const int2* __restrict__ gpair,
+                                                const double* __restrict__ pvals, const double* __restrict__ apvals,
+                                                double* __restrict__ cvals) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int32_t gb = gptr[q], ge = gptr[q + 1];
+  if (gb == ge) return;  // below the diagonal (k_sa_mirror_lower) -- an entry on or above it always has its own aggregate's nodes
+  double acc[DC][DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int c2 = 0; c2 < DC; ++c2) acc[c][c2] = 0.0;
+  for (int32_t g0 = gb; g0 < ge; g0 += 2) {  // two pairs in flight
+    int2 pr[2];
+    double Pn[2][DR * DC], AP[2][DR * DC];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) pr[u] = gpair[min(g0 + u, ge - 1)];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double* p1 = pvals + (int64_t)pr[u].x * DR * DC;
+      const double* p2 = apvals + (int64_t)pr[u].y * DR * DC;
+#pragma unroll
+      for (int k = 0; k < DR * DC; ++k) { Pn[u][k] = p1[k]; AP[u][k] = p2[k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (g0 + u >= ge) continue;
+#pragma unroll
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < DC; ++c2) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < DR; ++r) sacc += Pn[u][r * DC + c] * AP[u][r * DC + c2];
+          acc[c][c2] += sacc;
+        }
+    }
+  }
+  double* dst = cvals + q * DC * DC;
+#pragma unroll
+  for (int c = 0; c < DC; ++c)
+#pragma unroll
+    for (int c2 = 0; c2 < DC; ++c2) dst[c * DC + c2] = acc[c][c2];
+}
+
 static int sa_scan(pf_ctx* ctx, int32_t* in, int32_t* out, int64_t n) {
   size_t need = 0;
   PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, ctx->stream));
@@ -1201,6 +1375,56 @@ static int sa_pattern_device(pf_ctx* ctx, AmgLevel& Lv, int64_t n, const int32_t
   PF_HIP(hipMemcpyAsync(cptr.data(), dptr_c, sizeof(int32_t) * (nc + 1), hipMemcpyDeviceToHost, st));
   if (total) PF_HIP(hipMemcpyAsync(cidx.data(), didx_c, sizeof(int32_t) * total, hipMemcpyDeviceToHost, st));
   PF_HIP(hipStreamSynchronize(st));
+  // rows of A P for the two-step Galerkin product (k_sa_ap / k_sa_ptap); rows beyond the cap leave the one-step kernel in use
+  {
+    int32_t* apptr = nullptr;
+    int32_t* apidx = nullptr;
+    PF_HIP(hipMalloc(&apptr, sizeof(int32_t) * (n + 1)));
+    PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nmax, st));
+    PF_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+    k_sa_aprow<<<gn, 128, 0, st>>>(n, d_ptr, d_idx, pptr, pidx, cnt, nullptr, nullptr, flag);
+    int rc2 = sa_scan(ctx, cnt, apptr, n + 1);
+    int32_t tot2 = 0, f2 = 0;
+    if (rc2 == PF_OK) {
+      PF_HIP(hipMemcpyAsync(&tot2, apptr + n, sizeof(tot2), hipMemcpyDeviceToHost, st));
+      PF_HIP(hipMemcpyAsync(&f2, flag, sizeof(f2), hipMemcpyDeviceToHost, st));
+      PF_HIP(hipStreamSynchronize(st));
+    }
+    if (rc2 == PF_OK && !f2 && tot2 > 0) {
+      PF_HIP(hipMalloc(&apidx, sizeof(int32_t) * (size_t)tot2));
+      k_sa_aprow<<<gn, 128, 0, st>>>(n, d_ptr, d_idx, pptr, pidx, nullptr, apptr, apidx, flag);
+      PF_HIP(hipGetLastError());
+      Lv.apptr = apptr; Lv.apidx = apidx; Lv.nap = tot2;
+      PF_HIP(hipMalloc(&Lv.aprow, sizeof(int32_t) * (size_t)tot2));
+      k_sa_aprow_of<<<gn, 128, 0, st>>>(n, apptr, Lv.aprow);
+      // gather plan of P^T (A P) over the coarse graph just built (count, scan, fill)
+      int32_t *gcnt = nullptr, *gptr = nullptr;
+      int2* gpair = nullptr;
+      const int64_t nq = total;  // entries of the coarse graph
+      PF_HIP(hipMalloc(&gcnt, sizeof(int32_t) * (size_t)(nq + 1)));
+      PF_HIP(hipMalloc(&gptr, sizeof(int32_t) * (size_t)(nq + 1)));
+      PF_HIP(hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)(nq + 1), st));
+      const unsigned gw = (unsigned)std::min<int64_t>(nc, 1 << 20);
+      k_sa_gplan<<<gw, 64, 0, st>>>(nc, tptr, tnode, tslot, apptr, apidx, dptr_c, didx_c, gcnt, nullptr, nullptr);
+      int rc3 = sa_scan(ctx, gcnt, gptr, nq + 1);
+      int32_t tot3 = 0;
+      if (rc3 == PF_OK) {
+        PF_HIP(hipMemcpyAsync(&tot3, gptr + nq, sizeof(tot3), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+      }
+      (void)hipFree(gcnt);
+      if (rc3 == PF_OK && tot3 > 0) {
+        PF_HIP(hipMalloc(&gpair, sizeof(int2) * (size_t)tot3));
+        k_sa_gplan<<<gw, 64, 0, st>>>(nc, tptr, tnode, tslot, apptr, apidx, dptr_c, didx_c, nullptr, gptr, gpair);
+        PF_HIP(hipGetLastError());
+        Lv.gptr = gptr; Lv.gpair = gpair; Lv.ngpair = tot3;
+      } else {
+        (void)hipFree(gptr);
+      }
+    } else {
+      (void)hipFree(apptr);
+    }
+  }
   (void)hipFree(cnt); (void)hipFree(cur); (void)hipFree(flag);
   Lv.pptr = pptr; Lv.pidx = pidx; Lv.tptr = tptr; Lv.tnode = tnode; Lv.tslot = tslot;
   Lv.np = np;
@@ -1221,7 +1445,7 @@ void pf_amg_free(pf_ctx* ctx) {
     if (Lv.owns_xy) pf_free(Lv.xy);
     pf_free(Lv.dinv); pf_free(Lv.dinv2); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
     pf_free(Lv.pptr); pf_free(Lv.pidx); pf_free(Lv.pvals); pf_free(Lv.tptr); pf_free(Lv.tnode); pf_free(Lv.tslot);
-    pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32);
+    pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32); pf_free(Lv.apptr); pf_free(Lv.apidx); pf_free(Lv.aprow); pf_free(Lv.apvals); pf_free(Lv.gptr); pf_free(Lv.gpair);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
   }
   pf_free(H->dense_inv);
@@ -1308,6 +1532,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
       if (rc) return rc;
       if (verbose) fprintf(stderr, "[pf_amg] level %d: smoothed-prolongator and coarse patterns %.3f s (%s)\n", l, now() - t_c, dptr_c ? "device" : "host");
       PF_HIP(hipMalloc(&Lv.pvals, sizeof(double) * Lv.np * Lv.dr * dc));
+      if (Lv.apptr) PF_HIP(hipMalloc(&Lv.apvals, sizeof(double) * (size_t)Lv.nap * Lv.dr * dc));
       PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging vectors go out of scope
     }
     Lv.max_crow = 0;
@@ -1356,10 +1581,13 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
     return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
                           Lv.vals32);
   }
-  const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, 64), 4096);
+  const bool small = Lv.n <= AMG_SMALL_LEVEL;
+  const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, small ? 16 : 64), 4096);
 #define PF_AS(D_, M_)                                                                                               \
   do {                                                                                                              \
-    if (Lv.vals32) k_amg_spmv<D_, M_, float><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    if (Lv.vals32 && small) k_amg_spmv<D_, M_, float, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    else if (Lv.vals32) k_amg_spmv<D_, M_, float><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    else if (small) k_amg_spmv<D_, M_, double, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
     else k_amg_spmv<D_, M_, double><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
   } while (0)
 #define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
@@ -1443,6 +1671,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   H->numeric_ok = false;
   H->L[0].vals = const_cast<double*>(vals);
   if (const char* e = pf_exp_env("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
+  if (const char* e = pf_exp_env("PF_AMG_TWOSTEP")) H->two_step = atoi(e) != 0;
   if (const char* e = pf_exp_env("PF_AMG_OVER")) H->over = atof(e);
   if (const char* e = pf_exp_env("PF_AMG_OVER_SA")) H->over_sa = atof(e);
   if (const char* e = pf_exp_env("PF_AMG_CHEB")) H->cheb = atof(e);
@@ -1490,7 +1719,13 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 #define PF_SAG(DR_, DC_)                                                                                         \
         do {                                                                                                     \
           const int gw_ = std::max(4, std::min(32, Lv.max_row));                                                 \
-          if (Lv.max_crow <= 64) {                                                                               \
+          if (Lv.gpair && Lv.apvals && H->two_step) { /* A P first, then P^T (A P) through the gather plan: no atomics */ \
+            k_sa_ap<DR_, DC_><<<(unsigned)cdiv(Lv.nap, 256), 256, 0, ctx->stream>>>(Lv.nap, Lv.aprow, Lv.apidx, Lv.ptr, Lv.idx, \
+                                                                                    Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Lv.apvals); \
+            k_sa_ptap<DR_, DC_><<<(unsigned)cdiv(Nx.nblk, 256), 256, 0, ctx->stream>>>(Nx.nblk, Lv.gptr, Lv.gpair, Lv.pvals, \
+                                                                                       Lv.apvals, Nx.vals);     \
+            k_sa_mirror_lower<DC_><<<g, 128, 0, ctx->stream>>>(Lv.nc, Nx.ptr, Nx.idx, Nx.vals);                  \
+          } else if (Lv.max_crow <= 64) {                                                                        \
             if (Lv.np >= 48 * Lv.nc)                                                                             \
               k_sa_galerkin_wave<DR_, DC_, 4><<<(unsigned)std::min<int64_t>(Lv.nc, 65536), 256, 0, ctx->stream>>>( \
                   Lv.nc, Lv.tptr, Lv.tnode, Lv.tslot, Lv.ptr, Lv.idx, Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Nx.ptr, Nx.idx, Nx.vals, gw_); \
@@ -1559,7 +1794,8 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
     else if (C.dr == 6) k_amg_to_dense<6><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
     else k_amg_to_dense<3><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
-    k_amg_dense_invert<<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
+    if (H->dense_m <= 128) k_amg_dense_invert<4><<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
+    else k_amg_dense_invert<5><<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
     PF_LAUNCH_CHECK();
   }
   double h[AMG_MAX_LEVELS + 3];
@@ -1681,6 +1917,10 @@ static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, do
     if (Lv.np >= 48 * Lv.nc) { /* long columns, few of them: a wave per coarse row */                        \
       if (Lv.ptvals32) k_sa_restrict_wave<DR_, DC_, float><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out); \
       else k_sa_restrict_wave<DR_, DC_, double><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
+    } else if (Lv.nc <= AMG_SMALL_LEVEL) { /* a small next level: 16 coarse rows per wave, one chunk each */  \
+      const unsigned g16_ = (unsigned)std::min<int64_t>(cdiv(Lv.nc, 16), 4096);                               \
+      if (Lv.ptvals32) k_sa_restrict_stream<DR_, DC_, float, 16><<<g16_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out); \
+      else k_sa_restrict_stream<DR_, DC_, double, 16><<<g16_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
     } else {                                                                                                 \
       if (Lv.ptvals32) k_sa_restrict_stream<DR_, DC_, float><<<gs_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out); \
       else k_sa_restrict_stream<DR_, DC_, double><<<gs_, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out); \
