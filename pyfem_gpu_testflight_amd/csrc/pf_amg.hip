@@ -1574,11 +1574,11 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
 
 // which: 0 -> first factor (dinv), 1 -> second (dinv2); AMG_SMOOTH0 uses dinv for its first sweep and dinv2 for the second
 static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y, int mode = AMG_AX,
-                    const double* b = nullptr, int which = 0) {
+                    const double* b = nullptr, int which = 0, double* dot_part = nullptr) {
   const double* dv = which ? Lv.dinv2 : Lv.dinv;
   if (level == 0) {
     if (mode == AMG_SMOOTH0) return pf_fail(ctx, PF_E_INVALID, "amg_spmv: AMG_SMOOTH0 is a coarse-level mode");
-    return pf_launch_spmv(ctx, Lv.vals, x, y, nullptr, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
+    return pf_launch_spmv(ctx, Lv.vals, x, y, dot_part, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
                           Lv.vals32);
   }
   const bool small = Lv.n <= AMG_SMALL_LEVEL;
@@ -1826,7 +1826,8 @@ static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, do
 
 // l0 = 0: the whole cycle on (r, z).  l0 = 1: levels >= 1 only, from L[1].b to L[1].x (r, z unused): the part of the
 // cycle every rank runs redundantly when the finest level is distributed (dist.py).
-static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0) {
+static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz_part = nullptr, bool* rz_done = nullptr) {
+  if (rz_done) *rz_done = false;
   pf_amg* H = ctx->amg;
   if (!H) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: no hierarchy");
   hipStream_t st = ctx->stream;
@@ -1896,7 +1897,10 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0) {
     double* o = oth[l];
     if ((rc = amg_prolong_level(ctx, H, l, Nx.x, c))) return rc;
     for (int s = H->nsmooth - 1; s >= 0; --s) {  // ... and the reverse order on the way up: the cycle stays symmetric
-      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1))) return rc;
+      // the finest level's LAST sweep writes z: the caller's r.z partials come out of its epilogue (b = r)
+      double* dp = (l == 0 && s == 0 && rz_part) ? rz_part : nullptr;
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1, dp))) return rc;
+      if (dp && rz_done) *rz_done = true;
       std::swap(c, o);
     }
     PF_LAUNCH_CHECK();
@@ -1970,7 +1974,7 @@ static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, do
   return PF_OK;
 }
 
-int pf_amg_apply(pf_ctx* ctx, const double* r, double* z) { return amg_cycle(ctx, r, z, 0); }
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part, bool* rz_done) { return amg_cycle(ctx, r, z, 0, rz_part, rz_done); }
 
 int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap) {
   pf_amg* H = ctx->amg;

@@ -298,5 +298,6 @@ int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, co
                           const double* own_w, double* x, double* r, double* z);
 void pf_amg_free(pf_ctx* ctx);
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse);   // PF_E_UNSUPPORTED: matrix not positive definite
-int pf_amg_apply(pf_ctx* ctx, const double* r, double* z);
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part = nullptr, bool* rz_done = nullptr);  // rz_part: partials of
+                                                                    // r.z from the last sweep (one per product wave) when *rz_done
 int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);

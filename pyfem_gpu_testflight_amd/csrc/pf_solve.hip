@@ -99,7 +99,7 @@ __device__ __forceinline__ void block_store_partial(double s, double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// y = A x ; optionally dot_part[blockIdx.x] = sum over this wave's rows of x_i y_i
+// y = A x ; optionally dot_part[blockIdx.x] = sum over this wave's rows of x_i y_i (b_i y_i with a smoother epilogue)
 //   smoother epilogues for the AMG cycle (no extra pass over the vectors): with sm_b and sm_dinv
 //   y = x + dinv .* (b - A x) (one damped-Jacobi sweep, y != x), with sm_b alone y = b - A x.
 //   R = node rows per lane (tile = 64*R nodes), U = blocks per lane in flight, CH = LDS strip entries.
@@ -301,13 +301,15 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
             acc[r] = res;
           }
         }
+        // partials: x.y for a plain product (p.Ap of CG); with a smoother epilogue b.y -- the r.z of AMG-PCG when this is
+        // the cycle's last sweep (b = r, y = z): no separate dot kernel, no extra pass over r and z
         if constexpr (D == 1) {
           y[n] = acc[r];
-          if (dot_part) dacc += x[n] * acc[r];
+          if (dot_part) dacc += (sm_b ? sm_b[n] : x[n]) * acc[r];
         } else {
           *reinterpret_cast<double2*>(y + 2 * n) = acc[r];
           if (dot_part) {
-            const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
+            const double2 xv = *reinterpret_cast<const double2*>((sm_b ? sm_b : x) + 2 * n);
             dacc += xv.x * acc[r].x + xv.y * acc[r].y;
           }
         }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(64) void k_spmv3(int64_t nnodes, const int32_t* __r
           out = sm_dinv ? x[q] + sm_dinv[q] * res : res;
         }
         y[q] = out;
-        if (dot_part) dacc += x[q] * out;
+        if (dot_part) dacc += (sm_b ? sm_b[q] : x[q]) * out;
       }
     }
   }
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* _
                                                       const double* __restrict__ p, const double* __restrict__ Ap,
                                                       const double* __restrict__ dinv, double* __restrict__ x,
                                                       double* __restrict__ r, double* __restrict__ z,
-                                                      double* __restrict__ rz_new_part, double* __restrict__ rr_part) {
+                                                      double* __restrict__ rz_new_part, double* __restrict__ rr_part, int write_z) {
+  // write_z == 0 (AMG-PCG): z and r.z are the V-cycle's to produce; this kernel neither stores z nor its r.z partials
   __shared__ double sh[4];
   const double rz = block_sum_partials(rz_part, n_rz, sh);
   const double pAp = block_sum_partials(pAp_part, n_pAp, sh);
@@ -564,7 +567,8 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* _
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
     rv.x -= alpha * av.x; rv.y -= alpha * av.y;
     if (dinv) { const double2 dv = ld2s(dinv, i); zv.x = dv.x * rv.x; zv.y = dv.y * rv.y; } else zv = rv;
-    st2s(x, i, xv); st2s(r, i, rv); st2(z, i, zv);
+    st2s(x, i, xv); st2s(r, i, rv);
+    if (write_z) st2(z, i, zv);
     s1 += rv.x * zv.x + rv.y * zv.y;
     s2 += rv.x * rv.x + rv.y * rv.y;
   }
@@ -574,21 +578,21 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* _
     const double ri = r[i] - alpha * Ap[i];
     r[i] = ri;
     const double zi = dinv ? dinv[i] * ri : ri;
-    z[i] = zi;
+    if (write_z) z[i] = zi;
     s1 += ri * zi;
     s2 += ri * ri;
   }
-  block_store_partial(s1, rz_new_part, sh);
+  if (write_z) block_store_partial(s1, rz_new_part, sh);
   block_store_partial(s2, rr_part, sh);
 }
 
 // beta = rz_new/rz_old; p = z + beta p
-__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* __restrict__ rz_new_part,
-                                                     const double* __restrict__ rz_old_part, int n_rz,
+__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* __restrict__ rz_new_part, int n_new,
+                                                     const double* __restrict__ rz_old_part, int n_old,
                                                      const double* __restrict__ z, double* __restrict__ p) {
   __shared__ double sh[4];
-  const double rzn = block_sum_partials(rz_new_part, n_rz, sh);
-  const double rzo = block_sum_partials(rz_old_part, n_rz, sh);
+  const double rzn = block_sum_partials(rz_new_part, n_new, sh);
+  const double rzo = block_sum_partials(rz_old_part, n_old, sh);
   const double beta = rzn / rzo;
   const int64_t n2 = n >> 1;
   PF_VEC_LOOP(i, n2) {
@@ -1251,11 +1255,19 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   if (rc) return rc;
   k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
   PF_LAUNCH_CHECK();
+  // AMG-PCG: the r.z partials come out of the cycle's last sweep (one per product wave: ns of them); k_dot only when the
+  // hierarchy has a single level and the cycle ends without a product
+  int nrz = (int)vg;
+  auto cycle = [&](double* rz_part) -> int {
+    bool dotted = false;
+    if (int e = pf_amg_apply(ctx, r, z, rz_part, &dotted)) return e;
+    if (dotted) nrz = ns;
+    else { k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, rz_part); nrz = (int)vg; }
+    return PF_OK;
+  };
   if (amg) {  // z = M^-1 r by one V-cycle, p = z, r.z
-    rc = pf_amg_apply(ctx, r, z);
-    if (rc) return rc;
+    if ((rc = cycle(part(ctx, PA_RZ0)))) return rc;
     PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-    k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, part(ctx, PA_RZ0));
     PF_LAUNCH_CHECK();
   }
   static thread_local double h[2 * NPART];
@@ -1273,14 +1285,11 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
       double* rz_new = part(ctx, cur ? PA_RZ0 : PA_RZ1);
       rc = pf_launch_spmv(ctx, vals, p, Ap, part(ctx, PA_PAP));  // Ap = A p, partials of p.Ap
       if (rc) return rc;
-      k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, (int)vg, part(ctx, PA_PAP), ns, p, Ap, dinv, x, r, z, rz_new,
-                                         part(ctx, PA_RR));
-      if (amg) {
-        rc = pf_amg_apply(ctx, r, z);
-        if (rc) return rc;
-        k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, rz_new);
-      }
-      k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, rz_old, (int)vg, z, p);
+      const int nrz_old = nrz;
+      k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, nrz_old, part(ctx, PA_PAP), ns, p, Ap, dinv, x, r, z, rz_new,
+                                         part(ctx, PA_RR), amg ? 0 : 1);
+      if (amg && (rc = cycle(rz_new))) return rc;
+      k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, nrz, rz_old, nrz_old, z, p);
       cur ^= 1;
     }
     PF_LAUNCH_CHECK();
