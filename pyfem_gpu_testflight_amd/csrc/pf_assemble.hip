@@ -169,6 +169,15 @@ __device__ __forceinline__ void load_conn(const int32_t* __restrict__ conn, int6
 //   point():  accumulate the quadrature sums S (NS per coupled node)
 //   finish(): apply the constant material matrix once
 // ------------------------------------------------------------------------------------------
+// RAMP factor at one quadrature point: rho_q = sum_l N_l rho_l (utils.py:204-221), rho_q / (1 + p (1 - rho_q)) (pyfem.py:1944)
+template <int P>
+__device__ __forceinline__ double ramp_at(double p, const double N[P], const double rho_e[P]) {
+  double rq = N[0] * rho_e[0];
+#pragma unroll
+  for (int l = 1; l < P; ++l) rq = fma(N[l], rho_e[l], rq);
+  return rq * fast_rcp(fma(p, 1.0 - rq, 1.0));
+}
+
 struct ElasticityParams {
   double c11, c12, c33, p;     // C0 = E/(1-nu^2) [[1,nu,0],[nu,1,0],[0,0,(1-nu)/2]]  (pyfem.py:1746-1750)
   const double* rho;           // nodal density or nullptr
@@ -185,10 +194,7 @@ struct Elasticity {
                                                const Own& own, double S[P][NS]) {
     double s = det * w;
     if constexpr (RHO) {
-      double rq = N[0] * rho_e[0];
-#pragma unroll
-      for (int l = 1; l < P; ++l) rq = fma(N[l], rho_e[l], rq);  // utils.py:204-221
-      s *= rq * fast_rcp(fma(pr.p, 1.0 - rq, 1.0));              // RAMP, pyfem.py:1944
+      s *= ramp_at<P>(pr.p, N, rho_e);
     }
     const double gx = s * own.Nxa, gy = s * own.Nya;
 #pragma unroll
@@ -258,10 +264,7 @@ struct Poisson {
                                                const Own& own, double S[P][NS]) {
     double s = det * w;
     if constexpr (RHO) {
-      double rq = N[0] * rho_e[0];
-#pragma unroll
-      for (int l = 1; l < P; ++l) rq = fma(N[l], rho_e[l], rq);
-      s *= rq * fast_rcp(fma(pr.p, 1.0 - rq, 1.0));
+      s *= ramp_at<P>(pr.p, N, rho_e);
     }
     const double gx = s * own.Nxa, gy = s * own.Nya;
 #pragma unroll
@@ -394,8 +397,7 @@ struct V4Rec {        // stage B: the lane's visit record + the tile's row point
 
 template <int P, bool RHO>
 struct V4Visit {      // stage C: what the quadrature needs (gathers in flight during the previous tile)
-  Elem<P> el;
-  double rho_e[P];
+  Elem<P> el;         // (the nodal densities are NOT part of the two ping-pong sets: see v4_load_rho)
   uint32_t w;         // packed positions
   int32_t roff;       // first block of the lane's node inside the tile segment
   bool active;
@@ -480,15 +482,6 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
       const double2 p3 = buf_ld_f64x2(RX, (uint32_t)o3 * 16u);
       C.el.x[3] = p3.x; C.el.y[3] = p3.y;
     }
-    if constexpr (RHO) {
-      C.rho_e[0] = buf_ld_f64(Rrho, (uint32_t)n * 8u);
-      C.rho_e[1] = buf_ld_f64(Rrho, (uint32_t)o1 * 8u);
-      C.rho_e[2] = buf_ld_f64(Rrho, (uint32_t)o2 * 8u);
-      if constexpr (P == 4) C.rho_e[3] = buf_ld_f64(Rrho, (uint32_t)o3 * 8u);
-    } else {
-#pragma unroll
-      for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
-    }
     return;
   }
   // Triangles never read rec.z.  hipcc then hands that register of the in-flight 16-byte load to a temporary, and the
@@ -513,14 +506,35 @@ __device__ __forceinline__ void v4_load_visit(const V4Rec& B, pf_rsrc RX, pf_rsr
     const double2 p3 = buf_ld_f64x2(RX, (uint32_t)B.rec.z * 16u);
     C.el.x[3] = p3.x; C.el.y[3] = p3.y;
   }
-  if constexpr (RHO) {
-    C.rho_e[0] = buf_ld_f64(Rrho, n * 8u);
-    C.rho_e[1] = buf_ld_f64(Rrho, (uint32_t)B.rec.x * 8u);
-    C.rho_e[2] = buf_ld_f64(Rrho, (uint32_t)B.rec.y * 8u);
-    if constexpr (P == 4) C.rho_e[3] = buf_ld_f64(Rrho, (uint32_t)B.rec.z * 8u);
+}
+
+// The nodal densities of the lane's (rotated) element, from the record B of the tile they belong to.  ONE register set for
+// them, not one per ping-pong visit set: the densities of tile j + 1 are gathered right after the quadrature of tile j has
+// consumed those of tile j (v4_tile), into the same registers, and arrive during tile j's LDS adds and copy-out.  With
+// them inside both visit sets the density kernel needed 136-138 VGPRs, now 132-134: still three waves per SIMD (12 per CU
+// against the 16 of the density-free kernel; 0.296 ms = 0.58 of the HBM peak either way, r03).  Two ways to the last six
+// registers were built and measured and are NOT kept: compiling the kernel for four waves per SIMD
+// (amdgpu_waves_per_eu: 128 VGPRs + 24 bytes of scratch per lane) ran at 0.369 ms, the spills sit in the quadrature loop;
+// parking the four RAMP factors in LDS so that the densities die before the loop made the scheduler hoist the reads
+// back to the top (154 VGPRs; 144 with compiler barriers between the points).
+template <int P, int REC>
+__device__ __forceinline__ void v4_load_rho(const V4Rec& B, pf_rsrc Rrho, double rho_e[P]) {
+  if constexpr (REC == 8) {
+    const uint32_t d0 = (uint32_t)B.rec.x, d1 = (uint32_t)B.rec.y;
+    const int32_t n = B.n0 + rec_slot<8, P>(d1);
+    const int32_t o1 = n + (P == 4 ? ((int32_t)(d0 << 19) >> 19) : ((int32_t)(d0 << 16) >> 16));
+    const int32_t o2 = n + (P == 4 ? ((int32_t)(d0 << 6) >> 19) : ((int32_t)d0 >> 16));
+    const int32_t o3 = n + ((int32_t)(((d0 >> 26) | ((d1 & 127u) << 6)) << 19) >> 19);
+    rho_e[0] = buf_ld_f64(Rrho, (uint32_t)n * 8u);
+    rho_e[1] = buf_ld_f64(Rrho, (uint32_t)o1 * 8u);
+    rho_e[2] = buf_ld_f64(Rrho, (uint32_t)o2 * 8u);
+    if constexpr (P == 4) rho_e[3] = buf_ld_f64(Rrho, (uint32_t)o3 * 8u);
   } else {
-#pragma unroll
-    for (int b = 0; b < P; ++b) C.rho_e[b] = 1.0;
+    const uint32_t n = (uint32_t)(B.n0 + (int)(((uint32_t)B.rec.w >> 26) & 31));
+    rho_e[0] = buf_ld_f64(Rrho, n * 8u);
+    rho_e[1] = buf_ld_f64(Rrho, (uint32_t)B.rec.x * 8u);
+    rho_e[2] = buf_ld_f64(Rrho, (uint32_t)B.rec.y * 8u);
+    if constexpr (P == 4) rho_e[3] = buf_ld_f64(Rrho, (uint32_t)B.rec.z * 8u);
   }
 }
 
@@ -567,7 +581,8 @@ __device__ int g_abl_mask = 0;
 template <int P, class Phys, bool RHO, int NOUT, bool COMB, int REC>
 __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V4Tile& Tcur,
                                         const V4Visit<P, RHO>& Cuse, double* img, int plane, int lane,
-                                        double* __restrict__ out0, double* __restrict__ out1) {
+                                        double* __restrict__ out0, double* __restrict__ out1, double rho_e[P],
+                                        const V4Rec& Bnext, pf_rsrc Rrho) {
   constexpr int V = Phys::V;
   // clear the image (the previous tile's copy-out reads are complete: one wave, LDS executes in order)
 #ifdef PF_EXPERIMENTS
@@ -591,7 +606,7 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
         for (int k = 0; k < V; ++k) v[b][k] = Cuse.el.x[b] + (double)k * Cuse.el.y[b];
     } else
 #endif
-    element_rows_core<P, Phys, RHO>(pr, Cuse.el, Cuse.rho_e, 0, v);  // the lane's node is local node 0 (rotated record)
+    element_rows_core<P, Phys, RHO>(pr, Cuse.el, rho_e, 0, v);  // the lane's node is local node 0 (rotated record)
     double* row = img + Cuse.roff;
     bool add_diag = true;
     if constexpr (COMB) {
@@ -633,6 +648,10 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
       }
     }
   }
+
+  // the NEXT tile's densities into the registers this tile's quadrature has just released (unconditional, like every
+  // prefetch of this kernel; lanes without a pair read in-range nodes)
+  if constexpr (RHO) v4_load_rho<P, REC>(Bnext, Rrho, rho_e);
 
   // copy-out: one buffer resource that covers exactly the tile's segment; pieces past its end are dropped by the
   // hardware, so the store COUNT is static (NOUT > 0: hipcc can then count what is in flight behind a prefetch and
@@ -709,17 +728,18 @@ __device__ __forceinline__ void v4_tile(const typename Phys::Params& pr, const V
 #ifndef PF_AB_TILE_ORDER
 #define PF_AB_TILE_ORDER ((P == 3 || ctx->tiles_sorted) ? 2 : 1)  // 2 XCD-aware round-robin (triangles: -20 %; Morton-sorted tiles), 1 plain round-robin (quads: -4 %), 0 contiguous run per wave
 #endif
+#ifndef PF_AB_COMB_MINV
+#define PF_AB_COMB_MINV 2  // ... and for the two-plane (K, R) Helmholtz quads as well (4: 2x2 blocks only, the r02 state)
+#endif
 #ifndef PF_AB_QUAD_COMB
 #define PF_AB_QUAD_COMB 1  // the diagonal pre-reduction for the 2x2-block quad kernels too (tools/build_variant.sh A/B: 0)
 #endif
-template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V == 4))>
-__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane,
-                                                    const double* __restrict__ X,
-                                                    const int32_t* __restrict__ nptr,
-                                                    const int4* __restrict__ tile_desc,
-                                                    const int4* __restrict__ vis_rec, int64_t nvis, int32_t strided,
-                                                    typename Phys::Params pr, double* __restrict__ out0,
-                                                    double* __restrict__ out1) {
+template <int P, class Phys, bool RHO, int NOUT, int REC, bool COMB = (P == 3 || (PF_AB_QUAD_COMB && Phys::V >= PF_AB_COMB_MINV))>
+__device__ __forceinline__ void v4_kernel_body(int64_t nnodes, int64_t ntiles, int32_t plane, const double* __restrict__ X,
+                                               const int32_t* __restrict__ nptr, const int4* __restrict__ tile_desc,
+                                               const int4* __restrict__ vis_rec, int64_t nvis, int32_t strided,
+                                               const typename Phys::Params& pr, double* __restrict__ out0,
+                                               double* __restrict__ out1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* const img = reinterpret_cast<double*>(smem);  // V planes of `plane` doubles (odd: the planes start on different banks)
   const int lane = threadIdx.x;
@@ -745,14 +765,18 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
   V4Rec Ba = v4_load_rec<REC>(T0, lane, vis_rec, nptr);
   V4Rec Bb = v4_load_rec<REC>(T1, lane, vis_rec, nptr);
   V4Visit<P, RHO> Ca, Cb;
+  double rho_e[P];
+#pragma unroll
+  for (int b = 0; b < P; ++b) rho_e[b] = 1.0;
   v4_load_visit<P, RHO, REC>(Ba, RX, Rrho, Ca);
+  if constexpr (RHO) v4_load_rho<P, REC>(Ba, Rrho, rho_e);
   // Make the prologue's loads land here.  Otherwise the loop header merges "Bb's record is the youngest
   // load" (prologue: needs vmcnt(0)) with "NOUT stores are younger than it" (back edge: a partial count is
   // enough) into one conservative vmcnt(0) that the steady state then pays on every trip.
   asm volatile("" ::"v"(Bb.rec.x), "v"(Bb.rec.y), "v"(Bb.rec.z), "v"(Bb.rec.w), "v"(Bb.rp));
   asm volatile("" ::"v"(Ca.el.x[0]), "v"(Ca.el.x[1]), "v"(Ca.el.x[2]), "v"(Ca.el.y[0]), "v"(Ca.el.y[1]), "v"(Ca.el.y[2]));
   if constexpr (P == 4) asm volatile("" ::"v"(Ca.el.x[3]), "v"(Ca.el.y[3]));
-  if constexpr (RHO) asm volatile("" ::"v"(Ca.rho_e[0]), "v"(Ca.rho_e[1]), "v"(Ca.rho_e[2]), "v"(Ca.rho_e[P - 1]));
+  if constexpr (RHO) asm volatile("" ::"v"(rho_e[0]), "v"(rho_e[1]), "v"(rho_e[2]), "v"(rho_e[P - 1]));
 
   // steady state: two tiles per trip, both always executed (a conditional second half gives the
   // back edge two different in-flight counts and hipcc falls back to vmcnt(0) at the loop top)
@@ -762,15 +786,24 @@ __global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntil
     const V4Tile T3 = v4_walk_tile(j + 3, n, t0, tstride, tile_desc);
     v4_load_visit<P, RHO, REC>(Bb, RX, Rrho, Cb);
     Ba = v4_load_rec<REC>(T2, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1, rho_e, Bb, Rrho);  // densities of j+1 from Bb
     // tile j+1: integrate Cb; gathers of tile j+2 -> Ca; record of j+3 -> Bb
     const V4Tile T4 = v4_walk_tile(j + 4, n, t0, tstride, tile_desc);
     v4_load_visit<P, RHO, REC>(Ba, RX, Rrho, Ca);
     Bb = v4_load_rec<REC>(T3, lane, vis_rec, nptr);
-    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T1, Cb, img, plane, lane, out0, out1);
+    v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T1, Cb, img, plane, lane, out0, out1, rho_e, Ba, Rrho);  // densities of j+2 from Ba
     T0 = T2; T1 = T3; T2 = T4;
   }
-  if (j < n) v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1);  // odd tail
+  if (j < n) v4_tile<P, Phys, RHO, NOUT, COMB, REC>(pr, T0, Ca, img, plane, lane, out0, out1, rho_e, Bb, Rrho);  // odd tail
+}
+
+template <int P, class Phys, bool RHO, int NOUT, int REC>
+__global__ __launch_bounds__(64) void k_assemble_v4(int64_t nnodes, int64_t ntiles, int32_t plane, const double* __restrict__ X,
+                                                    const int32_t* __restrict__ nptr, const int4* __restrict__ tile_desc,
+                                                    const int4* __restrict__ vis_rec, int64_t nvis, int32_t strided,
+                                                    typename Phys::Params pr, double* __restrict__ out0,
+                                                    double* __restrict__ out1) {
+  v4_kernel_body<P, Phys, RHO, NOUT, REC>(nnodes, ntiles, plane, X, nptr, tile_desc, vis_rec, nvis, strided, pr, out0, out1);
 }
 
 // ------------------------------------------------------------------------------------------
