@@ -3,13 +3,14 @@
 # command, then tools/summarize_prof.py writes the files that get copied to profiles/.
 #   gpurun -- 'bash tools/profile_round.sh r01'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --cg-iters 100 --no-cpu-baseline --legs rho,c3,c4"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1 || exit 1
+# the driver's exact command (BENCH_rNN.json: "python3 bench.py --gpus 1 --steps 20 --warmup 5")
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/trace.log 2>&1 || exit 1
 echo "trace done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
 echo "pmc fetch done"
