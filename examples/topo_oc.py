@@ -25,10 +25,14 @@ from pyfem_gpu_testflight_amd import pyfem  # noqa: E402
 
 
 class TopoProblem:
-    """Same evaluation callbacks as the reference's ParOpt problem (topo.py:15-76), numpy in / numpy out."""
+    """Same evaluation callbacks as the reference's ParOpt problem (topo.py:15-76).  The design, the filtered density, the
+    displacements and the gradients stay in HBM between the callbacks (device tensors in, device tensors out): the second
+    filtr.apply(x) of an iteration returns the kept result, the two gradient filters run concurrently
+    (Helmholtz.apply_gradient_pair), compliance() builds its right-hand side on the device."""
 
     def __init__(self, model, filtr, fixed_volume, rho_min=1e-3):
         self.model, self.filtr, self.fixed_volume, self.rho_min = model, filtr, fixed_volume, rho_min
+        self.on_device = hasattr(model, "compute_rhs_device")
         self.u = None
 
     def _density(self, x):
@@ -38,19 +42,31 @@ class TopoProblem:
         iteration 13 on.  The floor is the design variables' own lower bound; its derivative (0 where it is active)
         goes into the gradients."""
         rho = self.filtr.apply(x)
-        return np.maximum(rho, self.rho_min), rho > self.rho_min
+        return rho.clamp(min=self.rho_min), (rho > self.rho_min).to(rho.dtype)
 
     def evalObjCon(self, x):
         rho, _ = self._density(x)
-        obj, self.u = self.model.compliance(rho)
-        con = self.fixed_volume - self.model.volume(rho)
+        if self.on_device:
+            obj, self.u = self.model.compliance(rho)
+            con = self.fixed_volume - float(self.model.volume(rho))
+        else:  # LinearPoisson evaluates its source term with a Python callback on the host: numpy at the model's boundary
+            rho_h = rho.cpu().numpy()
+            obj, self.u = self.model.compliance(rho_h)
+            con = self.fixed_volume - self.model.volume(rho_h)
         return obj, con
 
     def evalObjConGradient(self, x):
         rho, free = self._density(x)
-        g = self.filtr.apply_gradient(self.model.compliance_grad(rho, self.u) * free)
-        a = -self.filtr.apply_gradient(self.model.volume_grad(rho) * free)
-        return g, a
+        if self.on_device:
+            gc, gv = self.model.compliance_grad(rho, self.u), self.model.volume_grad(rho)
+        else:
+            import torch
+
+            rho_h = rho.cpu().numpy()
+            gc = torch.as_tensor(self.model.compliance_grad(rho_h, self.u), dtype=rho.dtype, device=rho.device)
+            gv = torch.as_tensor(self.model.volume_grad(rho_h), dtype=rho.dtype, device=rho.device)
+        g, a = self.filtr.apply_gradient_pair(gc * free, gv * free)
+        return g, -a
 
 
 def oc_update(x, g, a, con_now, move=0.2, lb=1e-3, ub=1.0):
@@ -75,7 +91,7 @@ def oc_update(x, g, a, con_now, move=0.2, lb=1e-3, ub=1.0):
             hi = lam
         if hi / lo < 1.0 + 1e-9:
             break
-    return xn.cpu().numpy()
+    return xn  # a NEW device tensor every iteration: the filter's kept forward result can never be stale
 
 
 def build(args):
@@ -116,8 +132,10 @@ def main(argv=None):
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args(argv)
 
+    import torch
+
     prob = build(args)
-    x = np.full(prob.model.nnodes, args.volume)
+    x = torch.full((prob.model.nnodes,), args.volume, dtype=torch.float64, device=prob.model.hctx.device)
     history = []
     for it in range(args.iters):
         t0 = time.perf_counter()

@@ -77,7 +77,7 @@ def main(argv=None):
         g = filtr.gather_nodal(filtr.apply_gradient(model.compliance_grad(rho, u) * free)).cpu().numpy()
         a = -filtr.gather_nodal(filtr.apply_gradient(ones * free)).cpu().numpy()
         t2 = time.perf_counter()
-        x = oc_update(x, g, a, con)
+        x = oc_update(x, g, a, con).cpu().numpy()  # the replicated design vector stays a host array here
         t3 = time.perf_counter()
         history.append((obj, con, t3 - t0))
         if rank == 0:

@@ -1458,3 +1458,34 @@ def test_filter_forward_reuse_and_concurrent_gradient_pair(pf):
         assert torch.equal(a1, b1) and torch.equal(a2, b2)
     n1, n2 = filtr.apply_gradient_pair(g1.cpu().numpy(), g2.cpu().numpy())
     assert np.array_equal(n1, a1.cpu().numpy()) and np.array_equal(n2, a2.cpu().numpy())
+
+
+def test_device_side_topology_callbacks_match_the_host_path(pf):
+    """compute_rhs_device() is the vector a fresh model's compute_rhs() returns; compliance() with a DEVICE density returns
+    the host path's compliance and a device u, without the host right-hand side being touched; volume_grad follows its
+    argument's residence; pf_dist_spmv-free single-context path only (the partitioned callbacks: test_gpu_dist.py)."""
+    import torch
+
+    c = pf.ProblemCreator(41, 29)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q = pf.QuadratureBilinear2D()
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, pf.BasisBilinear2D(q), p=3.0)
+    rhs_host = model.compute_rhs().copy()
+    rhs_dev = model.compute_rhs_device()
+    assert rhs_dev.is_cuda and np.array_equal(rhs_dev.cpu().numpy(), rhs_host)
+    rhs_dev.zero_()  # a fresh tensor each time: the caller may overwrite it (apply_dirichlet_bcs does)
+    assert np.array_equal(model.compute_rhs_device().cpu().numpy(), rhs_host)
+    rho = 0.2 + 0.8 * np.random.RandomState(4).rand(X.shape[0])
+    c_host, u_host = model.compliance(rho)
+    rho_d = model.hctx.to_device(rho, torch.float64)
+    model.rhs[:] = 123.0  # the device path must not read the host vector
+    c_dev, u_dev = model.compliance(rho_d)
+    assert isinstance(u_dev, torch.Tensor) and u_dev.is_cuda
+    assert abs(c_dev / c_host - 1) < 1e-10 and np.abs(u_dev.cpu().numpy() - u_host).max() < 1e-9 * np.abs(u_host).max()
+    assert np.all(model.rhs == 123.0)
+    g_host = model.compliance_grad(rho, u_host)
+    g_dev = model.compliance_grad(rho_d, u_dev)
+    assert np.abs(g_dev.cpu().numpy() - g_host).max() < 1e-8 * np.abs(g_host).max()
+    vg = model.volume_grad(rho_d)
+    assert vg.is_cuda and np.array_equal(vg.cpu().numpy(), model.volume_grad(rho))
+    assert abs(float(model.volume(rho_d)) - model.volume(rho)) < 1e-15
