@@ -694,7 +694,7 @@ def main():
             t, _, src_asm = pmc_traffic("k_assemble_v3<4, Elasticity<4, false>")
             if t is not None:
                 traffic_asm = t + 0.5 * 16.0 * 4 * h.nelems
-        t, fetch_kb, src_spmv = pmc_traffic("k_spmv<2")
+        t, fetch_kb, src_spmv = pmc_traffic("k_spmv<2, 1, 3, 640, true, double")
         if t is not None:
             traffic_spmv = t + 1024.0 * fetch_kb  # FETCH counted twice
 

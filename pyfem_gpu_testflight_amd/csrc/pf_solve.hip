@@ -84,6 +84,24 @@ __device__ __forceinline__ double block_sum_partials(const double* __restrict__ 
   return t;
 }
 
+// three partial arrays at once: the loads of all three are in flight together and the block meets twice, not six times
+// (block 0 of k_dcg_update: every other block of the launch waits for what it sends).  Same per-array order as
+// block_sum_partials, so the same bits.
+__device__ __forceinline__ void block_sum_partials3(const double* __restrict__ p0, int n0, const double* __restrict__ p1, int n1,
+                                                    const double* __restrict__ p2, int n2, double* sh12, double out[3]) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n0; i += blockDim.x) s0 += p0[i];
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) s1 += p1[i];
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) s2 += p2[i];
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { sh12[w] = s0; sh12[4 + w] = s1; sh12[8 + w] = s2; }
+  __syncthreads();
+  out[0] = out[1] = out[2] = 0.0;
+  for (int k = 0; k < nw; ++k) { out[0] += sh12[k]; out[1] += sh12[4 + k]; out[2] += sh12[8 + k]; }
+  __syncthreads();
+}
+
 // block-level sum of per-thread values -> out[blockIdx.x]
 __device__ __forceinline__ void block_store_partial(double s, double* __restrict__ out, double* sh) {
   s = wave_sum(s);
@@ -118,7 +136,12 @@ __device__ __forceinline__ T spmv_ld(const T* p) {
   if constexpr (NT) return __builtin_nontemporal_load(p);
   else return *p;
 }
-#define PF_SPMV_LD(p) spmv_ld<D == 1>(p)
+// NTV (template parameter of k_spmv): the value stream is read non-temporally.  Right for matrices that do not fit the
+// 256 MB Infinity Cache (the 4M-quad matrix: 0.242 -> 0.218 ms), WRONG for those that do: one rank's share of the metric
+// mesh at N = 8 (161 MB of values) runs at 28.6 us with plain loads against 31.3 us with non-temporal ones -- the stream
+// of the previous product is still in the memory-side cache and the hint throws that away; at the N = 4 share (322 MB) the
+// hint wins again (58.0 against 62.6 us; r03, tools/strip_cg_ab.py).  pf_launch_spmv decides by the size of the stream.
+static constexpr int64_t SPMV_NT_MIN_BYTES = (int64_t)224 << 20;
 #ifndef PF_AB_SPMV_XCD
 #define PF_AB_SPMV_XCD 1  // the XCD-aware block renumbering on banded numberings too: 0.2153 -> 0.2081 ms at d = 2 (0: only with tperm)
 #endif
@@ -138,7 +161,7 @@ __device__ __forceinline__ T spmv_ld(const T* p) {
 // tile raises this rank's row flag at every neighbour.  The interior tiles follow while the rows travel.  The kernel that
 // consumes y (k_dcg_update, k_halo_recv_apply) sums the interface rows in ascending rank order.
 struct pf_spmv_nosend {};
-template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double, bool SEND = false>
+template <int D, int R, int U, int CH, bool IDX16 = false, typename VT = double, bool SEND = false, bool NTV = true>
 __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __restrict__ nptr,
                                              const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
                                              const double* __restrict__ x, double* __restrict__ y,
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
 #pragma unroll
           for (int u = 0; u < UH; ++u) {
             const f64x2* vp = reinterpret_cast<const f64x2*>(vals) + hb[u];
-            kv[u] = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : *vp;
+            kv[u] = (NTV && PF_AB_SPMV_NT2) ? __builtin_nontemporal_load(vp) : *vp;
           }
 #pragma unroll
           for (int u = 0; u < UH; ++u) xv[u] = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m[u]);
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
         if constexpr (D == 1) {
           double kv[U], xv[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) kv[u] = (double)PF_SPMV_LD(vals + g[u]);
+          for (int u = 0; u < U; ++u) kv[u] = (double)spmv_ld<NTV>(vals + g[u]);
 #pragma unroll
           for (int u = 0; u < U; ++u) xv[u] = x[m[u]];
 #pragma unroll
@@ -236,14 +259,14 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
             if constexpr (sizeof(VT) == 8) {
               typedef double f64x2 __attribute__((ext_vector_type(2)));
               const f64x2* vp = reinterpret_cast<const f64x2*>(vals + 4 * (int64_t)g[u]);
-              const f64x2 a0 = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp) : vp[0];
-              const f64x2 a1 = PF_AB_SPMV_NT2 ? __builtin_nontemporal_load(vp + 1) : vp[1];
+              const f64x2 a0 = (NTV && PF_AB_SPMV_NT2) ? __builtin_nontemporal_load(vp) : vp[0];
+              const f64x2 a1 = (NTV && PF_AB_SPMV_NT2) ? __builtin_nontemporal_load(vp + 1) : vp[1];
               k0[u] = make_double2(a0.x, a0.y);
               k1[u] = make_double2(a1.x, a1.y);
             } else {  // fp32 copy of the operator (the AMG cycle's smoother): one 16-byte load per block
               typedef float f32x4 __attribute__((ext_vector_type(4)));
               const f32x4* vp = reinterpret_cast<const f32x4*>(vals + 4 * (int64_t)g[u]);
-              const f32x4 f = PF_AB_SPMV_NT32 ? __builtin_nontemporal_load(vp) : vp[0];
+              const f32x4 f = (NTV && PF_AB_SPMV_NT32) ? __builtin_nontemporal_load(vp) : vp[0];
               k0[u] = make_double2((double)f.x, (double)f.y);
               k1[u] = make_double2((double)f.z, (double)f.w);
             }
@@ -804,12 +827,10 @@ __global__ __launch_bounds__(256) void k_dcg_update(int64_t n, pf_halo_recv rc, 
                                                     double* __restrict__ z, double* __restrict__ p, double* __restrict__ s,
                                                     double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ gamma_part, double* __restrict__ rr_part) {
-  __shared__ double sh[4];
+  __shared__ double sh[12];
   __shared__ int bad;
   __shared__ double gsum[3];
-  // redg[3] != 0: an earlier update kernel of this solve found ||r|| <= tol (every rank forms the same sum of the same
-  // scalars in the same order, so every rank stops at the same iteration): nothing is sent, waited for or updated
-  if (redg[3] != 0.0) return;
+  const double stopped = redg[3];
   if (threadIdx.x == 0) bad = *rc.err;
   const int spar = (int)(rc.sseq & 1);
   // The loads of this thread's FIRST pair do not depend on the scalars: they are issued before the wait, so that the
@@ -827,11 +848,15 @@ __global__ __launch_bounds__(256) void k_dcg_update(int64_t n, pf_halo_recv rc, 
       if (dinv) d0 = ld2s(dinv, i0);
     }
   }
+  // stopped != 0: an earlier update kernel of this solve found ||r|| <= tol (every rank forms the same sum of the same
+  // scalars in the same order, so every rank stops at the same iteration): nothing is sent, waited for or updated.  (Read
+  // above, tested here: the prefetch loads are harmless and need not wait for it.)
+  if (stopped != 0.0) return;
   if (blockIdx.x == 0) {  // 1. this rank's scalars to every rank (the partial arrays are overwritten at the END of this
                           //    kernel by blocks that cannot get there before block 0 has read them: they wait for its flag)
-    const double g = block_sum_partials(gpart, ngpart, sh);
-    const double dl = block_sum_partials(dpart, ndpart, sh);
-    const double rr = block_sum_partials(rrpart, nrrpart, sh);
+    double loc[3];
+    block_sum_partials3(gpart, ngpart, dpart, ndpart, rrpart, nrrpart, sh, loc);
+    const double g = loc[0], dl = loc[1], rr = loc[2];
     if ((int)threadIdx.x < rc.world) {
       double* pw = rc.peer_win[threadIdx.x];
       double* dst = pw + halo_scal2_off(rc.world) + ((size_t)spar * rc.world + rc.rank) * PF_HALO_NSCAL;
@@ -1002,46 +1027,38 @@ static int ensure_idx16(pf_ctx* ctx) {
 }
 
 // vals32 != nullptr: the product uses that fp32 copy of the values instead of vals (AMG smoother sweeps)
+// one launch of k_spmv<SHAPE..., VT> for the runtime choices (16-bit columns, fused send, non-temporal value stream)
+template <int D, int R, int U, int CH, typename VT>
+static void spmv_dispatch(pf_ctx* ctx, unsigned grid, bool i16, bool ntv, const int32_t* cols, const VT* v, const double* x, double* y,
+                          double* dot_part, const double* sm_dinv, const double* sm_b, const pf_spmv_send* snd,
+                          const int32_t* tperm) {
+#define PF_GO(I16_, SEND_, NTV_, SND_)                                                                                \
+  k_spmv<D, R, U, CH, I16_, VT, SEND_, NTV_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, v, x, y, dot_part, sm_dinv, \
+                                                                           sm_b, tperm, SND_)
+  if (snd) {
+    if (i16) { if (ntv) PF_GO(true, true, true, *snd); else PF_GO(true, true, false, *snd); }
+    else { if (ntv) PF_GO(false, true, true, *snd); else PF_GO(false, true, false, *snd); }
+  } else {
+    if (i16) { if (ntv) PF_GO(true, false, true, pf_spmv_nosend{}); else PF_GO(true, false, false, pf_spmv_nosend{}); }
+    else { if (ntv) PF_GO(false, false, true, pf_spmv_nosend{}); else PF_GO(false, false, false, pf_spmv_nosend{}); }
+  }
+#undef PF_GO
+}
+
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
                    const double* sm_dinv, const double* sm_b, const float* vals32, const pf_spmv_send* snd,
                    const int32_t* snd_tperm) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
-  if (snd) {  // the product over a partition: interface rows leave from the epilogue (k_spmv<..., SEND>)
-    if (ctx->d != 1 && ctx->d != 2) return pf_fail(ctx, PF_E_UNSUPPORTED, "fused exchange: 1 or 2 dofs per node");
-    if (int rc16 = ensure_idx16(ctx)) return rc16;
-    const bool i16 = ctx->nidx16_state == 1;
-    const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
-#define PF_SND(SHAPE, I16_, VT_, V_) \
-    k_spmv<SHAPE, I16_, VT_, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, V_, x, y, dot_part, sm_dinv, sm_b, snd_tperm, *snd)
-    if (vals32) {
-      if (ctx->d == 1) { if (i16) PF_SND(PF_SPMV1F, true, float, vals32); else PF_SND(PF_SPMV1F, false, float, vals32); }
-      else { if (i16) PF_SND(PF_SPMV2F, true, float, vals32); else PF_SND(PF_SPMV2F, false, float, vals32); }
-    } else {
-      if (ctx->d == 1) { if (i16) PF_SND(PF_SPMV1, true, double, vals); else PF_SND(PF_SPMV1, false, double, vals); }
-      else { if (i16) PF_SND(PF_SPMV2, true, double, vals); else PF_SND(PF_SPMV2, false, double, vals); }
-    }
-#undef PF_SND
-    PF_LAUNCH_CHECK();
-    return PF_OK;
-  }
-  if (vals32) {
-    if (ctx->d == 3) {
-      k_spmv3<float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals32, x, y, dot_part, sm_dinv, sm_b);
-    } else {
-      if (int rc16 = ensure_idx16(ctx)) return rc16;
-      const bool i16 = ctx->nidx16_state == 1;
-      const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
-      if (ctx->d == 1 && i16) k_spmv<PF_SPMV1F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-      else if (ctx->d == 1) k_spmv<PF_SPMV1F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-      else if (i16) k_spmv<PF_SPMV2F, true, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-      else k_spmv<PF_SPMV2F, false, float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, vals32, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-    }
+  if (ctx->d == 3) {
+    if (snd) return pf_fail(ctx, PF_E_UNSUPPORTED, "fused exchange: 1 or 2 dofs per node");
+    if (vals32) k_spmv3<float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals32, x, y, dot_part, sm_dinv, sm_b);
+    else k_spmv3<double><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
     PF_LAUNCH_CHECK();
     return PF_OK;
   }
 #ifdef PF_SPMV_SWEEP
   const char* sh = pf_exp_env("PF_SPMV_SHAPE");
-  const int shape = sh ? atoi(sh) : 0;
+  const int shape = (sh && !vals32 && !snd) ? atoi(sh) : 0;
 #define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
   if (shape == ID && ctx->d == D_) {                                                                        \
     grid = (unsigned)std::min<int64_t>(cdiv(ctx->nnodes, 64 * R_), SPMV_MAXGRID);                            \
@@ -1054,23 +1071,19 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
   PF_TRY(1, 2, 2, 3, 1280) PF_TRY(2, 2, 1, 5, 640) PF_TRY(3, 2, 2, 5, 1280) PF_TRY(4, 2, 1, 2, 640) PF_TRY(5, 2, 1, 3, 1024)
 #undef PF_TRY
 #endif
-  if (ctx->d == 3)
-    k_spmv3<double><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b);
-  else if (ctx->d == 1) {
-    if (int rc16 = ensure_idx16(ctx)) return rc16;
-    if (ctx->nidx16_state == 1)
-      k_spmv<PF_SPMV1, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
-                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-    else
-      k_spmv<PF_SPMV1><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-  }
-  else {
-    if (int rc16 = ensure_idx16(ctx)) return rc16;
-    if (ctx->nidx16_state == 1)
-      k_spmv<PF_SPMV2, true><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, reinterpret_cast<const int32_t*>(ctx->nidx16),
-                                                          vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
-    else
-      k_spmv<PF_SPMV2><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm, pf_spmv_nosend{});
+  if (int rc16 = ensure_idx16(ctx)) return rc16;
+  const bool i16 = ctx->nidx16_state == 1;
+  const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
+  const int32_t* tperm = snd ? snd_tperm : ctx->spmv_perm;
+  // the value stream (+ its column ids): non-temporal only when it cannot stay in the 256 MB memory-side cache anyway
+  const int64_t stream = ctx->nblocks * ((int64_t)ctx->d * ctx->d * (vals32 ? 4 : 8) + (i16 ? 2 : 4));
+  const bool ntv = stream >= SPMV_NT_MIN_BYTES;
+  if (vals32) {
+    if (ctx->d == 1) spmv_dispatch<PF_SPMV1F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
+    else spmv_dispatch<PF_SPMV2F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
+  } else {
+    if (ctx->d == 1) spmv_dispatch<PF_SPMV1, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
+    else spmv_dispatch<PF_SPMV2, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
   }
   PF_LAUNCH_CHECK();
   return PF_OK;

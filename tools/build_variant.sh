@@ -14,5 +14,5 @@ done
 wait
 B=$P/build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libpyfem_hip_$name.so /tmp/pfvar_$name/pf_pattern.o /tmp/pfvar_$name/pf_assemble.o /tmp/pfvar_$name/pf_solve.o /tmp/pfvar_$name/pf_halo.o \
-  $B/pf_assemble3d.o $B/pf_tabular.o $B/pf_amg.o $B/pf_dist.o
+  $B/pf_assemble3d.o $B/pf_tabular.o $B/pf_amg.o $B/pf_dist.o $B/pf_bench.o
 echo $P/libpyfem_hip_$name.so
