@@ -81,6 +81,9 @@ struct pf_ctx {
   double* scal = nullptr;      // PF_NPART_ARRAYS x PF_NPART per-block partial sums
   double* cgw = nullptr;       // CG work vectors (4*nrows), grown on demand
   int64_t cgw_cap = 0;
+  bool multi_stream = false;   // set for the duration of an AMG-preconditioned solve: several operators (fp64 K, its fp32 copy, the
+                               // transfer operators) are streamed per iteration, nothing stays in the memory-side cache, and the
+                               // products read their values non-temporally whatever their size (pf_launch_spmv)
   double* cg_ap = nullptr;     // the product's output vector of pf_cg, placed by measurement (pf_solve.hip cg_place_ap)
   int64_t cg_ap_n = 0;
   void* scan_tmp = nullptr;

@@ -66,6 +66,12 @@ extern "C" int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x,
   PF_REQUIRE(a->global->stream == ctx->stream, "pf_dist_pcg_amg: bind both contexts to one stream (pf_ctx_set_stream)");
   PF_REQUIRE(pf_halo_fuse_of(a->halo, a->plan_dof), "pf_dist_pcg_amg: the dof plan was not prepared (pf_halo_plan_fuse)");
   PF_HIP(hipSetDevice(ctx->device));
+  struct MultiStream {  // an AMG iteration streams several operators: products read their values non-temporally (pf_launch_spmv)
+    pf_ctx *l, *g;
+    bool wl, wg;
+    MultiStream(pf_ctx* l_, pf_ctx* g_) : l(l_), g(g_), wl(l_->multi_stream), wg(g_->multi_stream) { l->multi_stream = g->multi_stream = true; }
+    ~MultiStream() { l->multi_stream = wl; g->multi_stream = wg; }
+  } multi_stream_guard(a->local, a->global);
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
   if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
   if (check_every <= 0) check_every = 1;

@@ -140,7 +140,9 @@ __device__ __forceinline__ T spmv_ld(const T* p) {
 // 256 MB Infinity Cache (the 4M-quad matrix: 0.242 -> 0.218 ms), WRONG for those that do: one rank's share of the metric
 // mesh at N = 8 (161 MB of values) runs at 28.6 us with plain loads against 31.3 us with non-temporal ones -- the stream
 // of the previous product is still in the memory-side cache and the hint throws that away; at the N = 4 share (322 MB) the
-// hint wins again (58.0 against 62.6 us; r03, tools/strip_cg_ab.py).  pf_launch_spmv decides by the size of the stream.
+// hint wins again (58.0 against 62.6 us; r03, tools/strip_cg_ab.py).  pf_launch_spmv decides by the size of the stream --
+// except inside an AMG-preconditioned solve (ctx->multi_stream), where an iteration streams K, its fp32 copy and the
+// transfer operators in turn and nothing survives in that cache: the filter's 113 MB fp32 stream ran 3 % slower plain.
 static constexpr int64_t SPMV_NT_MIN_BYTES = (int64_t)224 << 20;
 #ifndef PF_AB_SPMV_XCD
 #define PF_AB_SPMV_XCD 1  // the XCD-aware block renumbering on banded numberings too: 0.2153 -> 0.2081 ms at d = 2 (0: only with tperm)
@@ -1077,7 +1079,7 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
   const int32_t* tperm = snd ? snd_tperm : ctx->spmv_perm;
   // the value stream (+ its column ids): non-temporal only when it cannot stay in the 256 MB memory-side cache anyway
   const int64_t stream = ctx->nblocks * ((int64_t)ctx->d * ctx->d * (vals32 ? 4 : 8) + (i16 ? 2 : 4));
-  const bool ntv = stream >= SPMV_NT_MIN_BYTES;
+  const bool ntv = ctx->multi_stream || stream >= SPMV_NT_MIN_BYTES;
   if (vals32) {
     if (ctx->d == 1) spmv_dispatch<PF_SPMV1F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
     else spmv_dispatch<PF_SPMV2F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
@@ -1255,6 +1257,12 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
     } else if (arc) return arc;
   }
   const bool amg = precond == PF_PRECOND_AMG;
+  struct MultiStream {  // restored on every return path
+    pf_ctx* c;
+    bool was;
+    MultiStream(pf_ctx* c_, bool on) : c(c_), was(c_->multi_stream) { c->multi_stream = on; }
+    ~MultiStream() { c->multi_stream = was; }
+  } multi_stream_guard(ctx, amg);
   if (precond == PF_PRECOND_JACOBI) {
     const unsigned g = (unsigned)cdiv(ctx->nnodes, 256);
     if (ctx->d == 1) k_extract_diag<1><<<g, 256, 0, st>>>(ctx->nnodes, ctx->nptr, ctx->diagpos, vals, dinv, 1);
