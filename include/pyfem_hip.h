@@ -220,6 +220,15 @@ int pf_extract_diag(pf_ctx* ctx, const double* vals, double* diag);
  * that many iterations (<=0: default, 50 for Jacobi / 1 for AMG); iteration count is exact to that granularity. */
 int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x, double rtol, double atol,
           int maxiter, int precond, int check_every, int32_t* iters_host, double* relres_host);
+/* AMG-PCG for TWO right-hand sides of one SCALAR matrix at once: b2 and x2 are (nnodes, 2) row-major device arrays (x2 =
+ * the initial guesses on entry).  The reference solves the two gradient filters of a topology iteration one after the other
+ * with one fixed K (examples/topology_optimization/topo.py:73-74, pyfem.py:2102-2115); here they share every matrix stream
+ * and every launch.  The two recurrences are independent: each vector has pf_cg's stopping rule and gets the iterates
+ * pf_cg(PF_PRECOND_AMG) would give it alone.  reuse != 0: keep the hierarchy's numeric setup if it was made for `vals`
+ * (PF_PRECOND_AMG_REUSE).  iters_host, relres_host: HOST arrays of two.  PF_E_UNSUPPORTED: more than one dof per node, a
+ * matrix that is not positive definite, or a hierarchy level the two-vector cycle does not cover (solve one by one). */
+int pf_cg2(pf_ctx* ctx, const double* vals, const double* b2, double* x2, double rtol, double atol, int maxiter, int reuse,
+           int32_t* iters_host, double* relres_host);
 /* BiCGStab for the nonsymmetric systems of the reference: K with Dirichlet conditions on the rows only
  * (enforce_symmetric_K=False) and the Newton tangent of NonlinearPoisson2D, which it solves with scipy gmres or spsolve
  * (pyfem.py:2340-2349, 2414-2420).  Same stopping rule and outputs as pf_cg.  precond: PF_PRECOND_NONE, _JACOBI (diagonal

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pf_extract_diag": (C.c_int, [_vp, _vp, _vp]),
     "pf_cg": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.c_int, C.POINTER(_i32),
                         C.POINTER(_f64)]),
+    "pf_cg2": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
     "pf_amg_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_f64), C.c_int]),
     "pf_amg_prepare": (C.c_int, [_vp, _vp, C.c_int]),
     "pf_bicgstab": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),

@@ -102,6 +102,9 @@ struct pf_amg {
   double cheb = 4.4;            // PF_AMG_CHEB: the two sweeps target [lambda_max / cheb, lambda_max]; <= 1: equal factors
   double over_sa = 1.0;         // the same for levels with a smoothed prolongator: no over-correction needed
   double omega_scale = 1.0;
+  double psmooth = 1.0;         // scale of the prolongator-smoothing weight 4 / (3 * 1.1 lambda_max); PF_AMG_PSMOOTH (experiments)
+  int pow_iters = 10;           // power-iteration steps of the lambda_max(D^-1 A) estimates; PF_AMG_POW (experiments)
+  int nv_cap = 1;               // right-hand sides the level vectors are allocated for (amg_cycle grows them once)
   bool two_step = true;         // Galerkin products as P^T (A P) (k_sa_ap, k_sa_ptap); PF_AMG_TWOSTEP=0 (experiments): one sweep
 };
 
@@ -373,14 +376,16 @@ enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
 // ~25 x 64 entries took two to four dependent chunks and the kernel 8 - 9 us of pure latency against ~5.5 us with a
 // single chunk per wave and four times as many waves (r03).
 static constexpr int64_t AMG_SMALL_LEVEL = 65536;
-template <int D, int MODE, typename VT, int TR = 64>
+// NV > 1: NV vectors at once, interleaved per dof (entry (dof q, vector v) at q * NV + v); dinv is per dof.  The matrix
+// stream and the launch are shared by the NV products (the two gradient filters of a topology iteration, pf_cg2).
+template <int D, int MODE, typename VT, int TR = 64, int NV = 1>
 __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __restrict__ ptr,
                                                  const int32_t* __restrict__ idx, const VT* __restrict__ vals,
                                                  const double* __restrict__ x, double* __restrict__ y,
                                                  const double* __restrict__ dinv, const double* __restrict__ dinv2,
                                                  const double* __restrict__ b) {
   constexpr int CH = 448;
-  __shared__ double prod[CH * D];
+  __shared__ double prod[CH * D * NV];
   const int lane = threadIdx.x;
   const int64_t ntiles = (n + TR - 1) / TR;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -389,9 +394,9 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
     const int32_t rb = valid ? ptr[i] : 0, re = valid ? ptr[i + 1] : 0;
     const int32_t base = __shfl(rb, 0);
     const int32_t end = ptr[min(n, (tile + 1) * TR)];
-    double acc[D];
+    double acc[D * NV];
 #pragma unroll
-    for (int k = 0; k < D; ++k) acc[k] = 0.0;
+    for (int k = 0; k < D * NV; ++k) acc[k] = 0.0;
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
       // U blocks per lane in flight (column ids first, then blocks and gathers together): these levels wait for memory
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
           mm[u] = idx[gg[u]];
         }
         VT av[U][D * D];
-        double xv[U][D];
+        double xv[U][D * NV];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const VT* a = vals + (int64_t)gg[u] * D * D;  // VT = float: the fp32 copy of the coarse operator (cycle only)
@@ -413,44 +418,51 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
           for (int q = 0; q < D * D; ++q) av[u][q] = a[q];
 #pragma unroll
           for (int l = 0; l < D; ++l)
-            xv[u][l] = (MODE == AMG_SMOOTH0) ? dinv[D * mm[u] + l] * b[D * mm[u] + l] : x[D * mm[u] + l];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+              xv[u][l * NV + v] = (MODE == AMG_SMOOTH0) ? dinv[D * mm[u] + l] * b[(D * mm[u] + l) * NV + v] : x[(D * mm[u] + l) * NV + v];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (g0 + 64 * u >= c1) continue;
 #pragma unroll
-          for (int k = 0; k < D; ++k) {
-            double s = 0.0;
+          for (int k = 0; k < D; ++k)
 #pragma unroll
-            for (int l = 0; l < D; ++l) s += (double)av[u][k * D + l] * xv[u][l];
-            prod[(gg[u] - c0) * D + k] = s;
-          }
+            for (int v = 0; v < NV; ++v) {
+              double s = 0.0;
+#pragma unroll
+              for (int l = 0; l < D; ++l) s += (double)av[u][k * D + l] * xv[u][l * NV + v];
+              prod[(gg[u] - c0) * D * NV + k * NV + v] = s;
+            }
         }
       }
       __syncthreads();
       for (int32_t g = max(rb, c0); g < min(re, c1); ++g)
 #pragma unroll
-        for (int k = 0; k < D; ++k) acc[k] += prod[(g - c0) * D + k];
+        for (int k = 0; k < D * NV; ++k) acc[k] += prod[(g - c0) * D * NV + k];
       __syncthreads();
     }
     if (valid)
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const int64_t q = D * i + k;
-        double out = acc[k];
-        if constexpr (MODE == AMG_RESID) out = b[q] - out;
-        if constexpr (MODE == AMG_SMOOTH) out = x[q] + dinv[q] * (b[q] - out);
-        if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * b[q] + dinv2[q] * (b[q] - out);  // x1 + D2 (b - A x1)
-        y[q] = out;
-      }
+      for (int k = 0; k < D; ++k)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int64_t q = D * i + k, qv = q * NV + v;
+          double out = acc[k * NV + v];
+          if constexpr (MODE == AMG_RESID) out = b[qv] - out;
+          if constexpr (MODE == AMG_SMOOTH) out = x[qv] + dinv[q] * (b[qv] - out);
+          if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * b[qv] + dinv2[q] * (b[qv] - out);  // x1 + D2 (b - A x1)
+          y[qv] = out;
+        }
   }
 }
 
 // x = dinv .* b   (one damped-Jacobi sweep from a zero guess; dinv already holds omega/diag)
+template <int NV = 1>
 __global__ void k_amg_jacobi0(int64_t n, const double* __restrict__ dinv, const double* __restrict__ b,
                               double* __restrict__ x) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] = dinv[i] * b[i];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n * NV; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = dinv[i / NV] * b[i];
 }
 // coarse rhs: bc_I = sum_{n in I} P_n^T res_n
 template <int DIM, int DR, int DC>
@@ -506,10 +518,10 @@ __global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const 
                               const uint8_t* __restrict__ iso, const double* __restrict__ xy,
                               const double* __restrict__ cxy, const double* __restrict__ diag,
                               const double* __restrict__ lam2, const int32_t* __restrict__ pptr,
-                              const int32_t* __restrict__ pidx, double* __restrict__ pvals) {
+                              const int32_t* __restrict__ pidx, double* __restrict__ pvals, double wscale) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double w = 4.0 / (3.3 * sqrt(lam2[0]));
+  const double w = wscale * 4.0 / (3.3 * sqrt(lam2[0]));
   const int32_t pb = pptr[i], pe = pptr[i + 1];
   double wr[DR];
 #pragma unroll
@@ -813,13 +825,13 @@ __global__ void k_sa_transpose_vals(int64_t np, int bs, const int32_t* __restric
 
 // restriction as a streamed block product with P^T (same scheme as k_amg_spmv: 64 coarse rows per wave tile,
 // lanes stream the tile's contiguous entries, products parked in LDS, lane-per-row sums)
-template <int DR, int DC, typename PT = double, int TR = 64>
+template <int DR, int DC, typename PT = double, int TR = 64, int NV = 1>
 __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int32_t* __restrict__ tptr,
                                                            const int32_t* __restrict__ tnode,
                                                            const PT* __restrict__ ptvals,
                                                            const double* __restrict__ resid, double* __restrict__ bc) {
   constexpr int CH = 512;
-  __shared__ double prod[CH * DC];
+  __shared__ double prod[CH * DC * NV];
   const int lane = threadIdx.x;
   const int64_t ntiles = (nc + TR - 1) / TR;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -828,9 +840,9 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
     const int32_t rb = valid ? tptr[I] : 0, re = valid ? tptr[I + 1] : 0;
     const int32_t base = __shfl(rb, 0);
     const int32_t end = tptr[min(nc, (tile + 1) * TR)];
-    double acc[DC];
+    double acc[DC * NV];
 #pragma unroll
-    for (int c = 0; c < DC; ++c) acc[c] = 0.0;
+    for (int c = 0; c < DC * NV; ++c) acc[c] = 0.0;
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
       // U entries per lane in flight (the node ids first, then blocks and residual gathers together): the kernel waits
@@ -844,43 +856,45 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
           ee[u] = min(e0 + 64 * u, c1 - 1);  // clamped: loads stay in range, the result is discarded
           nn[u] = tnode[ee[u]];
         }
-        double Pv[U][DR * DC], rv[U][DR];
+        double Pv[U][DR * DC], rv[U][DR * NV];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const PT* Pn = ptvals + (int64_t)ee[u] * DR * DC;
 #pragma unroll
           for (int q = 0; q < DR * DC; ++q) Pv[u][q] = (double)Pn[q];
 #pragma unroll
-          for (int r = 0; r < DR; ++r) rv[u][r] = resid[DR * nn[u] + r];
+          for (int r = 0; r < DR * NV; ++r) rv[u][r] = resid[DR * NV * nn[u] + r];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (e0 + 64 * u >= c1) continue;
 #pragma unroll
-          for (int c = 0; c < DC; ++c) {
-            double s = 0.0;
+          for (int c = 0; c < DC; ++c)
 #pragma unroll
-            for (int r = 0; r < DR; ++r) s += Pv[u][r * DC + c] * rv[u][r];
-            prod[c * CH + (ee[u] - c0)] = s;
-          }
+            for (int v = 0; v < NV; ++v) {
+              double s = 0.0;
+#pragma unroll
+              for (int r = 0; r < DR; ++r) s += Pv[u][r * DC + c] * rv[u][r * NV + v];
+              prod[(c * NV + v) * CH + (ee[u] - c0)] = s;
+            }
         }
       }
       __syncthreads();
       for (int32_t e = max(rb, c0); e < min(re, c1); ++e)
 #pragma unroll
-        for (int c = 0; c < DC; ++c) acc[c] += prod[c * CH + (e - c0)];
+        for (int c = 0; c < DC * NV; ++c) acc[c] += prod[c * CH + (e - c0)];
       __syncthreads();
     }
     if (valid)
 #pragma unroll
-      for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
+      for (int c = 0; c < DC * NV; ++c) bc[DC * NV * I + c] = acc[c];
   }
 }
 
 // The same restriction with one wave per coarse row, for levels whose columns of P are long and few (3-D: ~200
 // entries per coarse node, 1331 coarse nodes on the second level of 96^3 blocks -- 21 tiles of 64 rows left the
 // stream kernel on 21 waves, 300 us per call).  Lanes stride over the column, fixed-order wave sum: deterministic.
-template <int DR, int DC, typename PT = double>
+template <int DR, int DC, typename PT = double, int NV = 1>
 __global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int32_t* __restrict__ tptr,
                                                           const int32_t* __restrict__ tnode,
                                                           const PT* __restrict__ ptvals,
@@ -888,39 +902,41 @@ __global__ __launch_bounds__(256) void k_sa_restrict_wave(int64_t nc, const int3
   const int lane = threadIdx.x & 63;
   const int64_t I = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (I >= nc) return;  // wave-uniform
-  double acc[DC];
+  double acc[DC * NV];
 #pragma unroll
-  for (int c = 0; c < DC; ++c) acc[c] = 0.0;
+  for (int c = 0; c < DC * NV; ++c) acc[c] = 0.0;
   for (int32_t e = tptr[I] + lane; e < tptr[I + 1]; e += 64) {
     const int64_t n = tnode[e];
     const PT* Pn = ptvals + (int64_t)e * DR * DC;
-    double rv[DR];
+    double rv[DR * NV];
 #pragma unroll
-    for (int r = 0; r < DR; ++r) rv[r] = resid[DR * n + r];
+    for (int r = 0; r < DR * NV; ++r) rv[r] = resid[DR * NV * n + r];
 #pragma unroll
     for (int r = 0; r < DR; ++r)
 #pragma unroll
-      for (int c = 0; c < DC; ++c) acc[c] += (double)Pn[r * DC + c] * rv[r];
+      for (int c = 0; c < DC; ++c)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[c * NV + v] += (double)Pn[r * DC + c] * rv[r * NV + v];
   }
 #pragma unroll
-  for (int c = 0; c < DC; ++c)
+  for (int c = 0; c < DC * NV; ++c)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
   if (lane == 0)
 #pragma unroll
-    for (int c = 0; c < DC; ++c) bc[DC * I + c] = acc[c];
+    for (int c = 0; c < DC * NV; ++c) bc[DC * NV * I + c] = acc[c];
 }
 
 // x_n += over * sum_J P[n,J] e_J
-template <int DR, int DC, typename PT = double>
+template <int DR, int DC, typename PT = double, int NV = 1>
 __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
                              const PT* __restrict__ pvals, const double* __restrict__ ec, double* __restrict__ x,
                              double over) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double s[DR];
+  double s[DR * NV];
 #pragma unroll
-  for (int r = 0; r < DR; ++r) s[r] = 0.0;
+  for (int r = 0; r < DR * NV; ++r) s[r] = 0.0;
   const int32_t qb = pptr[i], qe = pptr[i + 1];
   if constexpr (DR * DC <= 9) {
     // four entries at a time: their aggregate ids first, then the blocks and the coarse values together (independent
@@ -933,14 +949,14 @@ __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const 
         qq[u] = min(q0 + u, qe - 1);
         JJ[u] = pidx[qq[u]];
       }
-      double Pv[4][DR * DC], ev[4][DC];
+      double Pv[4][DR * DC], ev[4][DC * NV];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const PT* Pn = pvals + (int64_t)qq[u] * DR * DC;
 #pragma unroll
         for (int k = 0; k < DR * DC; ++k) Pv[u][k] = (double)Pn[k];
 #pragma unroll
-        for (int c = 0; c < DC; ++c) ev[u][c] = ec[DC * JJ[u] + c];
+        for (int c = 0; c < DC * NV; ++c) ev[u][c] = ec[DC * NV * JJ[u] + c];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -948,21 +964,25 @@ __global__ void k_sa_prolong(int64_t n, const int32_t* __restrict__ pptr, const 
 #pragma unroll
         for (int r = 0; r < DR; ++r)
 #pragma unroll
-          for (int c = 0; c < DC; ++c) s[r] += Pv[u][r * DC + c] * ev[u][c];
+          for (int c = 0; c < DC; ++c)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) s[r * NV + v] += Pv[u][r * DC + c] * ev[u][c * NV + v];
       }
     }
   } else {
     for (int32_t q = qb; q < qe; ++q) {
       const PT* Pn = pvals + (int64_t)q * DR * DC;
-      const double* e = ec + DC * (int64_t)pidx[q];
+      const double* e = ec + DC * NV * (int64_t)pidx[q];
 #pragma unroll
       for (int r = 0; r < DR; ++r)
 #pragma unroll
-        for (int c = 0; c < DC; ++c) s[r] += (double)Pn[r * DC + c] * e[c];
+        for (int c = 0; c < DC; ++c)
+#pragma unroll
+          for (int v = 0; v < NV; ++v) s[r * NV + v] += (double)Pn[r * DC + c] * e[c * NV + v];
     }
   }
 #pragma unroll
-  for (int r = 0; r < DR; ++r) x[DR * i + r] += over * s[r];
+  for (int r = 0; r < DR * NV; ++r) x[DR * NV * i + r] += over * s[r];
 }
 
 // coarsest level: scatter the block matrix into a dense m x m array, invert it in place (Gauss-Jordan,
@@ -1034,16 +1054,24 @@ __global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ 
 }
 
 // x = Ainv b; Ainv is symmetric, so lane i walks column i (= row i) with coalesced reads
+template <int NV = 1>
 __global__ void k_amg_dense_apply(int m, const double* __restrict__ Ainv, const double* __restrict__ b,
                                   double* __restrict__ x) {
-  __shared__ double sb[AMG_COARSEST_DOFS];
-  for (int j = threadIdx.x; j < m; j += blockDim.x) sb[j] = b[j];
+  __shared__ double sb[AMG_COARSEST_DOFS * NV];
+  for (int j = threadIdx.x; j < m * NV; j += blockDim.x) sb[j] = b[j];
   __syncthreads();
   const int i = threadIdx.x;
   if (i >= m) return;
-  double s = 0.0;
-  for (int j = 0; j < m; ++j) s += Ainv[j * m + i] * sb[j];
-  x[i] = s;
+  double s[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) s[v] = 0.0;
+  for (int j = 0; j < m; ++j) {
+    const double a = Ainv[j * m + i];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] += a * sb[j * NV + v];
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) x[i * NV + v] = s[v];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1574,15 +1602,31 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
 
 // which: 0 -> first factor (dinv), 1 -> second (dinv2); AMG_SMOOTH0 uses dinv for its first sweep and dinv2 for the second
 static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, double* y, int mode = AMG_AX,
-                    const double* b = nullptr, int which = 0, double* dot_part = nullptr) {
+                    const double* b = nullptr, int which = 0, double* dot_part = nullptr, int nv = 1) {
   const double* dv = which ? Lv.dinv2 : Lv.dinv;
   if (level == 0) {
     if (mode == AMG_SMOOTH0) return pf_fail(ctx, PF_E_INVALID, "amg_spmv: AMG_SMOOTH0 is a coarse-level mode");
     return pf_launch_spmv(ctx, Lv.vals, x, y, dot_part, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
-                          Lv.vals32);
+                          Lv.vals32, nullptr, nullptr, nv);
   }
   const bool small = Lv.n <= AMG_SMALL_LEVEL;
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, small ? 16 : 64), 4096);
+  if (nv == 2) {  // two vectors at once: scalar levels only (amg_cycle checks)
+#define PF_AS2(M_)                                                                                                  \
+  do {                                                                                                              \
+    if (Lv.vals32 && small) k_amg_spmv<1, M_, float, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    else if (Lv.vals32) k_amg_spmv<1, M_, float, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
+    else if (small) k_amg_spmv<1, M_, double, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
+    else k_amg_spmv<1, M_, double, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
+  } while (0)
+    if (mode == AMG_AX) PF_AS2(AMG_AX);
+    else if (mode == AMG_SMOOTH) PF_AS2(AMG_SMOOTH);
+    else if (mode == AMG_RESID) PF_AS2(AMG_RESID);
+    else PF_AS2(AMG_SMOOTH0);
+#undef PF_AS2
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
 #define PF_AS(D_, M_)                                                                                               \
   do {                                                                                                              \
     if (Lv.vals32 && small) k_amg_spmv<D_, M_, float, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
@@ -1636,13 +1680,13 @@ __global__ void k_amg_pow_ratio(double* __restrict__ num, const double* __restri
 // The iterate is NOT normalised between steps: D^-1 A has a spectral radius of a few units, ten steps grow the start
 // vector by at most that to the tenth, and only the last two norms are needed -- two launches per step (product, divide
 // by the diagonal) instead of five (+ dot, its finalize, rescale): 30 launches less per level and numeric setup.
-static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2, double* den) {
+static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2, double* den, int steps) {
   const int64_t ndof = Lv.n * Lv.dr;
   const unsigned g = (unsigned)cdiv(ndof, 256);
   k_amg_pow_init<<<g, 256, 0, ctx->stream>>>(ndof, v);
-  for (int it = 0; it < 10; ++it) {
+  for (int it = 0; it < steps; ++it) {
     int rc;
-    if (it == 9 && (rc = pf_dot(ctx, ndof, v, v, nullptr, den))) return rc;  // |v_9|^2
+    if (it == steps - 1 && (rc = pf_dot(ctx, ndof, v, v, nullptr, den))) return rc;  // |v_9|^2
     rc = amg_spmv(ctx, Lv, level, v, Lv.t);
     if (rc) return rc;
     k_amg_pow_div<<<g, 256, 0, ctx->stream>>>(ndof, Lv.dinv, Lv.t, v);
@@ -1672,10 +1716,12 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   H->L[0].vals = const_cast<double*>(vals);
   if (const char* e = pf_exp_env("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));
   if (const char* e = pf_exp_env("PF_AMG_TWOSTEP")) H->two_step = atoi(e) != 0;
+  if (const char* e = pf_exp_env("PF_AMG_POW")) H->pow_iters = std::max(2, atoi(e));
   if (const char* e = pf_exp_env("PF_AMG_OVER")) H->over = atof(e);
   if (const char* e = pf_exp_env("PF_AMG_OVER_SA")) H->over_sa = atof(e);
   if (const char* e = pf_exp_env("PF_AMG_CHEB")) H->cheb = atof(e);
   if (const char* e = pf_exp_env("PF_AMG_OMEGA_SCALE")) H->omega_scale = atof(e);
+  if (const char* e = pf_exp_env("PF_AMG_PSMOOTH")) H->psmooth = atof(e);
   // The cycle's finest-level operator in fp32 (PF_AMG_FP32=0 keeps fp64): the preconditioner only has to be a fixed
   // symmetric positive definite operator, which the V-cycle of the rounded matrix is as well -- all arithmetic and all
   // vectors stay fp64, PCG's own product uses the fp64 matrix.  Five of the six fine SpMVs per iteration then read
@@ -1706,7 +1752,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
     // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
     const int64_t ndof = Lv.n * Lv.dr;
-    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l, H->lam + AMG_MAX_LEVELS + 3);
+    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l, H->lam + AMG_MAX_LEVELS + 3, H->pow_iters);
     if (rc) return rc;
     if (l + 1 < H->nlevels) {
       AmgLevel& Nx = H->L[l + 1];
@@ -1715,7 +1761,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
         const unsigned gn = (unsigned)cdiv(Lv.n, 128);
 #define PF_SAP(DIM_, DR_, DC_)                                                                                   \
         k_sa_smooth_P<DIM_, DR_, DC_><<<gn, 128, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.agg, Lv.iso, Lv.xy, \
-                                                                   Nx.xy, Lv.dinv, H->lam + l, Lv.pptr, Lv.pidx, Lv.pvals)
+                                                                   Nx.xy, Lv.dinv, H->lam + l, Lv.pptr, Lv.pidx, Lv.pvals, H->psmooth)
 #define PF_SAG(DR_, DC_)                                                                                         \
         do {                                                                                                     \
           const int gw_ = std::max(4, std::min(32, Lv.max_row));                                                 \
@@ -1821,17 +1867,34 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
 // Jacobi sweeps are fused into the products (x_out = x_in + dinv (b - A x_in)), so the iterate ping-pongs
 // between the level's x and t buffers: it changes buffer 2 nsmooth - 1 times per level (always odd), so
 // it starts in t and the level's result lands in x (= z on the fine level).
-static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out);
-static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c);
+static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out, int nv = 1);
+static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c, int nv = 1);
 
 // l0 = 0: the whole cycle on (r, z).  l0 = 1: levels >= 1 only, from L[1].b to L[1].x (r, z unused): the part of the
 // cycle every rank runs redundantly when the finest level is distributed (dist.py).
-static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz_part = nullptr, bool* rz_done = nullptr) {
+// nv = 2: two right-hand sides at once (r, z and the level vectors hold the pair of every dof next to each other); scalar
+// hierarchies with smoothed prolongators only.  Every matrix and transfer stream and every launch is shared by the two.
+static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz_part = nullptr, bool* rz_done = nullptr, int nv = 1) {
   if (rz_done) *rz_done = false;
   pf_amg* H = ctx->amg;
   if (!H) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: no hierarchy");
   hipStream_t st = ctx->stream;
   const int Lc = H->nlevels - 1;
+  if (nv != 1) {
+    if (nv != 2) return pf_fail(ctx, PF_E_INVALID, "pf_amg_apply: one or two right-hand sides");
+    for (int l = 0; l <= Lc; ++l)
+      if (H->L[l].dr != 1 || (l < Lc && !H->L[l].sa)) return PF_E_UNSUPPORTED;  // the caller solves one by one
+    if (!(H->dense_inv && Lc > 0)) return PF_E_UNSUPPORTED;
+    if (H->nv_cap < nv) {  // the level vectors, once, at twice their length
+      for (int l = 0; l <= Lc; ++l) {
+        AmgLevel& Lv = H->L[l];
+        const size_t bytes = sizeof(double) * (size_t)(Lv.n * Lv.dr) * nv;
+        pf_free(Lv.t); PF_HIP(hipMalloc(&Lv.t, bytes));
+        if (l > 0) { pf_free(Lv.x); pf_free(Lv.b); PF_HIP(hipMalloc(&Lv.x, bytes)); PF_HIP(hipMalloc(&Lv.b, bytes)); }
+      }
+      H->nv_cap = nv;
+    }
+  }
   auto vg = [](int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); };
   double* cur[AMG_MAX_LEVELS];
   double* oth[AMG_MAX_LEVELS];
@@ -1852,19 +1915,20 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
     const int64_t ndof = Lv.n * Lv.dr;
     int done;
     if (l > 0 && H->nsmooth >= 2) {  // first two sweeps in one launch; counts as one buffer change
-      if ((rc = amg_spmv(ctx, Lv, l, nullptr, o, AMG_SMOOTH0, b))) return rc;
+      if ((rc = amg_spmv(ctx, Lv, l, nullptr, o, AMG_SMOOTH0, b, 0, nullptr, nv))) return rc;
       std::swap(c, o);
       done = 2;
     } else {
-      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, c);
+      if (nv == 2) k_amg_jacobi0<2><<<vg(2 * ndof), 256, 0, st>>>(ndof, Lv.dinv, b, c);
+      else k_amg_jacobi0<1><<<vg(ndof), 256, 0, st>>>(ndof, Lv.dinv, b, c);
       done = 1;
     }
     for (; done < H->nsmooth; ++done) {  // sweep s uses factor s & 1 on the way down ...
-      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, done & 1))) return rc;
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, done & 1, nullptr, nv))) return rc;
       std::swap(c, o);
     }
-    if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b))) return rc;
-    if ((rc = amg_restrict_level(ctx, H, l, o, Nx.b))) return rc;
+    if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_RESID, b, 0, nullptr, nv))) return rc;
+    if ((rc = amg_restrict_level(ctx, H, l, o, Nx.b, nv))) return rc;
     PF_LAUNCH_CHECK();
     cur[l] = c;
     oth[l] = o;
@@ -1876,11 +1940,12 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
     double* x = (Lc == 0) ? z : C.x;
     const int64_t ndof = C.n * C.dr;
     if (H->dense_inv && Lc > 0) {
-      k_amg_dense_apply<<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
+      if (nv == 2) k_amg_dense_apply<2><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
+      else k_amg_dense_apply<1><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
     } else {  // could not coarsen down to the dense size (or a one-level hierarchy): Jacobi sweeps
       double* c = x;
       double* o = C.t;
-      k_amg_jacobi0<<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, c);
+      k_amg_jacobi0<1><<<vg(ndof), 256, 0, st>>>(ndof, C.dinv, b, c);
       for (int s = 0; s < 4 && Lc > 0; ++s) {  // even count: the result is back in x
         if ((rc = amg_spmv(ctx, C, Lc, c, o, AMG_SMOOTH, b))) return rc;
         std::swap(c, o);
@@ -1895,11 +1960,11 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
     const double* b = (l == 0) ? r : Lv.b;
     double* c = cur[l];
     double* o = oth[l];
-    if ((rc = amg_prolong_level(ctx, H, l, Nx.x, c))) return rc;
+    if ((rc = amg_prolong_level(ctx, H, l, Nx.x, c, nv))) return rc;
     for (int s = H->nsmooth - 1; s >= 0; --s) {  // ... and the reverse order on the way up: the cycle stays symmetric
       // the finest level's LAST sweep writes z: the caller's r.z partials come out of its epilogue (b = r)
       double* dp = (l == 0 && s == 0 && rz_part) ? rz_part : nullptr;
-      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1, dp))) return rc;
+      if ((rc = amg_spmv(ctx, Lv, l, c, o, AMG_SMOOTH, b, s & 1, dp, nv))) return rc;
       if (dp && rz_done) *rz_done = true;
       std::swap(c, o);
     }
@@ -1909,11 +1974,26 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
   return PF_OK;
 }
 
-static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out) {
+static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, double* out, int nv) {
   AmgLevel& Lv = H->L[l];
   AmgLevel& Nx = H->L[l + 1];
   (void)Nx;
     const unsigned g = (unsigned)cdiv(Lv.nc, 128);
+    if (nv == 2) {  // scalar smoothed-aggregation levels only (amg_cycle checks)
+      const unsigned gs = (unsigned)std::min<int64_t>(cdiv(Lv.nc, 64), 4096), g16 = (unsigned)std::min<int64_t>(cdiv(Lv.nc, 16), 4096);
+      if (Lv.np >= 48 * Lv.nc) {
+        if (Lv.ptvals32) k_sa_restrict_wave<1, 1, float, 2><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out);
+        else k_sa_restrict_wave<1, 1, double, 2><<<(unsigned)cdiv(Lv.nc, 4), 256, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out);
+      } else if (Lv.nc <= AMG_SMALL_LEVEL) {
+        if (Lv.ptvals32) k_sa_restrict_stream<1, 1, float, 16, 2><<<g16, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out);
+        else k_sa_restrict_stream<1, 1, double, 16, 2><<<g16, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out);
+      } else {
+        if (Lv.ptvals32) k_sa_restrict_stream<1, 1, float, 64, 2><<<gs, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals32, o, out);
+        else k_sa_restrict_stream<1, 1, double, 64, 2><<<gs, 64, 0, ctx->stream>>>(Lv.nc, Lv.tptr, Lv.tnode, Lv.ptvals, o, out);
+      }
+      PF_LAUNCH_CHECK();
+      return PF_OK;
+    }
     if (Lv.sa) {
 #define PF_SAR(DR_, DC_)                                                                                    \
   do {                                                                                                      \
@@ -1946,12 +2026,18 @@ static int amg_restrict_level(pf_ctx* ctx, pf_amg* H, int l, const double* o, do
   return PF_OK;
 }
 
-static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c) {
+static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, double* c, int nv) {
   AmgLevel& Lv = H->L[l];
   AmgLevel& Nx = H->L[l + 1];
   (void)Nx;
     const unsigned g = (unsigned)cdiv(Lv.n, 256);
     const double over = Lv.sa ? H->over_sa : H->over;
+    if (nv == 2) {  // scalar smoothed-aggregation levels only (amg_cycle checks)
+      if (Lv.pvals32) k_sa_prolong<1, 1, float, 2><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals32, xc, c, over);
+      else k_sa_prolong<1, 1, double, 2><<<g, 256, 0, ctx->stream>>>(Lv.n, Lv.pptr, Lv.pidx, Lv.pvals, xc, c, over);
+      PF_LAUNCH_CHECK();
+      return PF_OK;
+    }
     if (Lv.sa) {
 #define PF_SAO(DR_, DC_)                                                                                              \
   do {                                                                                                                \
@@ -1974,7 +2060,7 @@ static int amg_prolong_level(pf_ctx* ctx, pf_amg* H, int l, const double* xc, do
   return PF_OK;
 }
 
-int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part, bool* rz_done) { return amg_cycle(ctx, r, z, 0, rz_part, rz_done); }
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part, bool* rz_done, int nv) { return amg_cycle(ctx, r, z, 0, rz_part, rz_done, nv); }
 
 int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap) {
   pf_amg* H = ctx->amg;

@@ -84,6 +84,9 @@ struct pf_ctx {
   bool multi_stream = false;   // set for the duration of an AMG-preconditioned solve: several operators (fp64 K, its fp32 copy, the
                                // transfer operators) are streamed per iteration, nothing stays in the memory-side cache, and the
                                // products read their values non-temporally whatever their size (pf_launch_spmv)
+  double* pin = nullptr;       // pinned host buffer (2 * PF_NPART doubles) and event for the PCG loops' residual read-back: the
+  hipEvent_t pin_ev = nullptr; //   copy is queued right after the update that produces |r|^2 and awaited after the rest of the
+                               //   iteration has been queued, so the device never waits for the host (pf_solve.hip)
   double* cg_ap = nullptr;     // the product's output vector of pf_cg, placed by measurement (pf_solve.hip cg_place_ap)
   int64_t cg_ap_n = 0;
   void* scan_tmp = nullptr;
@@ -288,7 +291,8 @@ int pf_launch_assemble_helmholtz(pf_ctx* ctx, double r0, double* Kvals, double* 
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
                    const double* sm_dinv = nullptr, const double* sm_b = nullptr,  // smoother epilogues: pf_solve.hip
                    const float* vals32 = nullptr,                                  // fp32 copy of vals to use instead
-                   const pf_spmv_send* snd = nullptr, const int32_t* snd_tperm = nullptr);  // fused exchange (pf_halo.hip)
+                   const pf_spmv_send* snd = nullptr, const int32_t* snd_tperm = nullptr,   // fused exchange (pf_halo.hip)
+                   int nv = 1);  // 2: x, y, sm_b hold TWO vectors interleaved per node (scalar matrices; dot_part: 2 per wave)
 int pf_halo_recv_apply(pf_halo* h, int plan, const double* x, const double* d, const double* b, double* y);
 // the two launches of a distributed CG iteration and their helpers (pf_solve.hip; used by pf_dist.hip as well)
 int pf_dist_product(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const float* vals32, const double* x, double* y,
@@ -301,6 +305,6 @@ int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, co
                           const double* own_w, double* x, double* r, double* z);
 void pf_amg_free(pf_ctx* ctx);
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse);   // PF_E_UNSUPPORTED: matrix not positive definite
-int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part = nullptr, bool* rz_done = nullptr);  // rz_part: partials of
+int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part = nullptr, bool* rz_done = nullptr, int nv = 1);  // rz_part: partials of
                                                                     // r.z from the last sweep (one per product wave) when *rz_done
 int pf_amg_describe(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);

@@ -416,6 +416,8 @@ extern "C" int pf_ctx_destroy(pf_ctx* ctx) {
   pf_free(ctx->cgw);
   pf_free(ctx->cg_ap);
   ctx->cg_ap_n = 0;
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->pin_ev) (void)hipEventDestroy(ctx->pin_ev);
   if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
   delete ctx;
   return PF_OK;

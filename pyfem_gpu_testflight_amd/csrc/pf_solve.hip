@@ -44,6 +44,8 @@ struct SpmvShape { static constexpr int d = D, tile = 64 * R; };
 static_assert(SpmvShape<PF_SPMV1>::tile == SPMV_TILE1 && SpmvShape<PF_SPMV1F>::tile == SPMV_TILE1, "d = 1 SpMV shapes must keep 128-node tiles");
 static_assert(SpmvShape<PF_SPMV2>::tile == SPMV_TILE2 && SpmvShape<PF_SPMV2F>::tile == SPMV_TILE2, "d = 2 SpMV shapes must keep 64-node tiles");
 static constexpr int SPMV_MAXGRID = 4096;
+static constexpr int SPMV2_MAXGRID = 2048;  // k_spmv_nv2 leaves two partials per wave
+static_assert(2 * SPMV2_MAXGRID <= PF_NPART && 2 * 64 == PF_SPMV_TILE1, "k_spmv_nv2: partial capacity / tile of the 16-bit offsets");
 static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
 static constexpr int NPART = PF_NPART;   // capacity of one partial array
 
@@ -358,6 +360,101 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
   if (dot_part) {
     dacc = wave_sum(dacc);
     if (lane == 0) dot_part[blockIdx.x] = dacc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Scalar matrix times TWO vectors (x, y, sm_b interleaved per node: double2 per node), for the pair of gradient filters of
+// a topology iteration (pf_cg2): the value and index streams -- two thirds of a scalar product's bytes -- are read once
+// for both.  Same tiling as k_spmv<PF_SPMV1>, same epilogues (sm_dinv is per node), dot_part[2 * wave + v].  The value
+// stream is always read non-temporally (this only runs inside AMG-preconditioned solves, see SPMV_NT_MIN_BYTES).
+// ------------------------------------------------------------------------------------------
+template <int R, int U, int CH, bool IDX16, typename VT>
+__global__ __launch_bounds__(64) void k_spmv_nv2(int64_t nnodes, const int32_t* __restrict__ nptr,
+                                                 const int32_t* __restrict__ nidx, const VT* __restrict__ vals,
+                                                 const double* __restrict__ x, double* __restrict__ y,
+                                                 double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
+                                                 const double* __restrict__ sm_b, const int32_t* __restrict__ tperm) {
+  constexpr int TILE = 64 * R;
+  __shared__ double2 prod[CH];
+  const int lane = threadIdx.x;
+  double dacc0 = 0.0, dacc1 = 0.0;
+  const int64_t ntiles = (nnodes + TILE - 1) / TILE;
+  const int64_t vblk = ((tperm || PF_AB_SPMV_XCD) && (gridDim.x & 7) == 0) ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  for (int64_t tslot = vblk; tslot < ntiles; tslot += gridDim.x) {
+    const int64_t tile = tperm ? tperm[tslot] : tslot;
+    int32_t rb[R], re[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t n = tile * TILE + r * 64 + lane;
+      const bool valid = n < nnodes;
+      rb[r] = valid ? nptr[n] : 0;
+      re[r] = valid ? nptr[n + 1] : 0;
+    }
+    const int32_t base = __shfl(rb[0], 0);
+    const int64_t nlast = min(nnodes, (tile + 1) * TILE);
+    const int32_t end = nptr[nlast];  // uniform
+    double2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_double2(0.0, 0.0);
+    for (int32_t c0 = base; c0 < end; c0 += CH) {
+      const int32_t c1 = min(end, c0 + CH);
+      for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
+        int32_t g[U], m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          g[u] = min(g0 + 64 * u, c1 - 1);  // clamped: loads stay in range, result discarded
+          if constexpr (IDX16) m[u] = (int32_t)(tile * TILE) + reinterpret_cast<const int16_t*>(nidx)[g[u]];
+          else m[u] = nidx[g[u]];
+        }
+        double kv[U];
+        double2 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) kv[u] = (double)__builtin_nontemporal_load(vals + g[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2*>(x + 2 * (int64_t)m[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (g0 + 64 * u < c1) prod[g[u] - c0] = make_double2(kv[u] * xv[u].x, kv[u] * xv[u].y);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int32_t lo = max(rb[r], c0), hi = min(re[r], c1);
+        for (int32_t gq = lo; gq < hi; ++gq) {
+          const double2 pv = prod[gq - c0];
+          acc[r].x += pv.x; acc[r].y += pv.y;
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t n = tile * TILE + r * 64 + lane;
+      if (n < nnodes) {
+        if (sm_b) {
+          const double2 bv = *reinterpret_cast<const double2*>(sm_b + 2 * n);
+          double2 res = make_double2(bv.x - acc[r].x, bv.y - acc[r].y);
+          if (sm_dinv) {
+            const double2 xv = *reinterpret_cast<const double2*>(x + 2 * n);
+            const double dv = sm_dinv[n];
+            res = make_double2(xv.x + dv * res.x, xv.y + dv * res.y);
+          }
+          acc[r] = res;
+        }
+        *reinterpret_cast<double2*>(y + 2 * n) = acc[r];
+        if (dot_part) {  // x.y per vector (b.y with a smoother epilogue), as in k_spmv
+          const double2 xv = *reinterpret_cast<const double2*>((sm_b ? sm_b : x) + 2 * n);
+          dacc0 += xv.x * acc[r].x;
+          dacc1 += xv.y * acc[r].y;
+        }
+      }
+    }
+  }
+  if (dot_part) {
+    dacc0 = wave_sum(dacc0);
+    dacc1 = wave_sum(dacc1);
+    if (lane == 0) { dot_part[2 * blockIdx.x] = dacc0; dot_part[2 * blockIdx.x + 1] = dacc1; }
   }
 }
 
@@ -1049,8 +1146,28 @@ static void spmv_dispatch(pf_ctx* ctx, unsigned grid, bool i16, bool ntv, const 
 
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
                    const double* sm_dinv, const double* sm_b, const float* vals32, const pf_spmv_send* snd,
-                   const int32_t* snd_tperm) {
+                   const int32_t* snd_tperm, int nv) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
+  if (nv == 2) {  // scalar matrix, two vectors
+    if (ctx->d != 1 || snd) return pf_fail(ctx, PF_E_UNSUPPORTED, "two-vector product: scalar matrices, no fused exchange");
+    if (int rc16 = ensure_idx16(ctx)) return rc16;
+    const bool i16 = ctx->nidx16_state == 1;
+    const int32_t* cols = i16 ? reinterpret_cast<const int32_t*>(ctx->nidx16) : ctx->nidx;
+    grid = std::min(grid, (unsigned)SPMV2_MAXGRID);  // two partials per wave in one partial array
+#ifndef PF_AB_NV2_CH
+#define PF_AB_NV2_CH 1280
+#endif
+#ifndef PF_AB_NV2_U
+#define PF_AB_NV2_U 9
+#endif
+#define PF_GO2(I16_, VT_, V_) k_spmv_nv2<2, PF_AB_NV2_U, PF_AB_NV2_CH, I16_, VT_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, V_, x, y, dot_part, sm_dinv, sm_b, ctx->spmv_perm)
+    if (vals32) { if (i16) PF_GO2(true, float, vals32); else PF_GO2(false, float, vals32); }
+    else { if (i16) PF_GO2(true, double, vals); else PF_GO2(false, double, vals); }
+#undef PF_GO2
+    PF_LAUNCH_CHECK();
+    return PF_OK;
+  }
+  if (nv != 1) return pf_fail(ctx, PF_E_INVALID, "pf_launch_spmv: one or two vectors");
   if (ctx->d == 3) {
     if (snd) return pf_fail(ctx, PF_E_UNSUPPORTED, "fused exchange: 1 or 2 dofs per node");
     if (vals32) k_spmv3<float><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals32, x, y, dot_part, sm_dinv, sm_b);
@@ -1206,6 +1323,26 @@ static double host_sum(const double* v, int n) {
   return s;
 }
 
+// Residual read-back of the PCG loops without a device stall.  |r|^2 is known right after the x / r update, long before
+// the iteration ends (the V-cycle and the direction update follow): the copy to PINNED host memory and an event are queued
+// at that point, the rest of the iteration is queued behind them, and only then does the host wait for the event -- the
+// device is still busy, and the next iteration's first launch is in its queue before it runs dry.  (r02 / early r03: copy
+// to pageable memory and a stream synchronise at the end of every iteration -- a 42 us hole per AMG-PCG iteration in the
+// kernel trace, 2 ms of a 40 ms topology iteration.)
+static int readback_queue(pf_ctx* ctx, const double* dev, size_t count) {
+  if (!ctx->pin) {
+    PF_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), sizeof(double) * 2 * NPART, hipHostMallocDefault));
+    PF_HIP(hipEventCreateWithFlags(&ctx->pin_ev, hipEventDisableTiming));
+  }
+  PF_HIP(hipMemcpyAsync(ctx->pin, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipEventRecord(ctx->pin_ev, ctx->stream));
+  return PF_OK;
+}
+static int readback_wait(pf_ctx* ctx) {
+  PF_HIP(hipEventSynchronize(ctx->pin_ev));
+  return PF_OK;
+}
+
 // The product's output vector of the PCG loops, owned by the context.  Round 2 "placed it by measurement" (three candidate
 // allocations, the fastest of a few launches each kept), on the belief that the product runs at two speeds depending on
 // where its OUTPUT lies.  Round 3 took that apart (profiles/r03_spmv_placement.md): in a warm process every output
@@ -1276,6 +1413,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   if (rc) return rc;
   k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
   PF_LAUNCH_CHECK();
+  if ((rc = readback_queue(ctx, part(ctx, PA_RR), 2 * NPART))) return rc;  // RR | BB, awaited behind the first cycle
   // AMG-PCG: the r.z partials come out of the cycle's last sweep (one per product wave: ns of them); k_dot only when the
   // hierarchy has a single level and the cycle ends without a product
   int nrz = (int)vg;
@@ -1291,16 +1429,19 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
     PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     PF_LAUNCH_CHECK();
   }
-  static thread_local double h[2 * NPART];
-  PF_HIP(hipMemcpyAsync(h, part(ctx, PA_RR), sizeof(double) * 2 * NPART, hipMemcpyDeviceToHost, st));  // RR | BB
-  PF_HIP(hipStreamSynchronize(st));
-  const double bnorm = sqrt(host_sum(h + NPART, (int)vg));
+  if ((rc = readback_wait(ctx))) return rc;
+  const double bnorm = sqrt(host_sum(ctx->pin + NPART, (int)vg));
   const double tol = std::max(rtol * bnorm, atol);
-  double rnorm = sqrt(host_sum(h, (int)vg));
+  double rnorm = sqrt(host_sum(ctx->pin, (int)vg)), rnorm_prev = rnorm;
   int it = 0;
   int cur = 0;  // which rz partial array is live
   while (rnorm > tol && it < maxiter) {
     const int burst = std::min(check_every, maxiter - it);
+    // Checked every iteration (AMG): when the residual's recent rate says THIS step probably ends the solve, the host
+    // looks at |r|^2 before it queues the V-cycle and the direction update, and leaves them out if it does (they were a
+    // whole wasted cycle per solve); otherwise it queues them first and looks afterwards (no stall, see readback_queue).
+    const bool early = burst == 1 && rnorm * std::min(1.0, rnorm / rnorm_prev) <= 4.0 * tol;
+    bool finished = false;
     for (int k = 0; k < burst; ++k) {
       double* rz_old = part(ctx, cur ? PA_RZ1 : PA_RZ0);
       double* rz_new = part(ctx, cur ? PA_RZ0 : PA_RZ1);
@@ -1309,20 +1450,245 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
       const int nrz_old = nrz;
       k_cg_update_xr<<<vg, 256, 0, st>>>(n, rz_old, nrz_old, part(ctx, PA_PAP), ns, p, Ap, dinv, x, r, z, rz_new,
                                          part(ctx, PA_RR), amg ? 0 : 1);
+      if (k == burst - 1 && (rc = readback_queue(ctx, part(ctx, PA_RR), vg))) return rc;  // |r|^2 of the burst's last step
+      if (early) {
+        if ((rc = readback_wait(ctx))) return rc;
+        rnorm_prev = rnorm;
+        rnorm = sqrt(host_sum(ctx->pin, (int)vg));
+        if (!(rnorm > tol) || it + 1 >= maxiter) { finished = true; break; }  // (NaN ends here too)
+      }
       if (amg && (rc = cycle(rz_new))) return rc;
       k_cg_update_p<<<vg, 256, 0, st>>>(n, rz_new, nrz, rz_old, nrz_old, z, p);
       cur ^= 1;
     }
     PF_LAUNCH_CHECK();
     it += burst;
-    PF_HIP(hipMemcpyAsync(h, part(ctx, PA_RR), sizeof(double) * vg, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    rnorm = sqrt(host_sum(h, (int)vg));
+    if (finished) break;
+    if (!early) {
+      if ((rc = readback_wait(ctx))) return rc;
+      rnorm_prev = rnorm;
+      rnorm = sqrt(host_sum(ctx->pin, (int)vg));
+    }
     if (!(rnorm == rnorm)) break;  // NaN: breakdown
   }
   if (iters_host) *iters_host = it;
   if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;
   if (!(rnorm <= tol))
+    return pf_fail(ctx, PF_E_NOCONV, "cg failed with code " + std::to_string(it));  // pyfem.py:2421-2422
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// AMG-PCG for TWO right-hand sides of one scalar matrix at once (the two gradient filters that topo.py:73-74 issues
+// together; /root/reference/pyfem.py:2102-2115 solves them one after the other).  Vectors hold the pair of every node next
+// to each other (an (n, 2) row-major array); every product, smoother sweep and transfer reads its operator ONCE for both
+// (k_spmv_nv2, the NV = 2 forms of the cycle kernels) and the launch-bound coarse levels are walked once.  The two
+// recurrences are independent -- each vector keeps its own alpha, beta and stopping test, so each gets the iterates pf_cg
+// would give it alone -- and a vector that has converged (or is zero) is frozen: alpha = 0, x and r keep their values
+// (the host, which reads |r|^2 after every iteration anyway, says which).
+// Partial arrays hold the pair of every block next to each other.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 block_sum_partials2(const double* __restrict__ part, int nblk, double* sh8) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x) { s0 += part[2 * i]; s1 += part[2 * i + 1]; }
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { sh8[w] = s0; sh8[4 + w] = s1; }
+  __syncthreads();
+  double2 t = make_double2(0.0, 0.0);
+  for (int k = 0; k < nw; ++k) { t.x += sh8[k]; t.y += sh8[4 + k]; }
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ void block_store_partial2(double s0, double s1, double* __restrict__ out, double* sh8) {
+  s0 = wave_sum(s0); s1 = wave_sum(s1);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { sh8[w] = s0; sh8[4 + w] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < nw; ++k) { t0 += sh8[k]; t1 += sh8[4 + k]; }
+    out[2 * blockIdx.x] = t0;
+    out[2 * blockIdx.x + 1] = t1;
+  }
+  __syncthreads();
+}
+
+// r = b - Ap; partials of b.b and r.r per vector (n = nodes; the vectors are pairs)
+__global__ __launch_bounds__(256) void k_cg2_init(int64_t n, const double* __restrict__ b, const double* __restrict__ Ap,
+                                                  double* __restrict__ r, double* __restrict__ bb_part, double* __restrict__ rr_part) {
+  __shared__ double sh[8];
+  double b0 = 0.0, b1 = 0.0, r0 = 0.0, r1 = 0.0;
+  PF_VEC_LOOP(i, n) {
+    const double2 bv = ld2(b, i), av = ld2(Ap, i);
+    const double2 rv = make_double2(bv.x - av.x, bv.y - av.y);
+    st2(r, i, rv);
+    b0 += bv.x * bv.x; b1 += bv.y * bv.y;
+    r0 += rv.x * rv.x; r1 += rv.y * rv.y;
+  }
+  block_store_partial2(b0, b1, bb_part, sh);
+  block_store_partial2(r0, r1, rr_part, sh);
+}
+
+// alpha_v = rz_v / pAp_v (0 for a frozen vector: the host found it converged); x += alpha p; r -= alpha Ap; |r|^2
+__global__ __launch_bounds__(256) void k_cg2_update_xr(int64_t n, const double* __restrict__ rz_part, int n_rz,
+                                                       const double* __restrict__ pAp_part, int n_pAp, int frozen0, int frozen1,
+                                                       const double* __restrict__ p, const double* __restrict__ Ap,
+                                                       double* __restrict__ x, double* __restrict__ r,
+                                                       double* __restrict__ rr_part) {
+  __shared__ double sh[8];
+  const double2 rz = block_sum_partials2(rz_part, n_rz, sh);
+  const double2 pAp = block_sum_partials2(pAp_part, n_pAp, sh);
+  const bool f0 = frozen0 || pAp.x == 0.0, f1 = frozen1 || pAp.y == 0.0;
+  const double a0 = f0 ? 0.0 : rz.x / pAp.x, a1 = f1 ? 0.0 : rz.y / pAp.y;
+  double s0 = 0.0, s1 = 0.0;
+  PF_VEC_LOOP(i, n) {
+    const double2 pv = ld2(p, i), av = ld2s(Ap, i);
+    double2 xv = ld2s(x, i), rv = ld2s(r, i);
+    if (!f0) { xv.x += a0 * pv.x; rv.x -= a0 * av.x; }
+    if (!f1) { xv.y += a1 * pv.y; rv.y -= a1 * av.y; }
+    st2s(x, i, xv);
+    st2(r, i, rv);  // the cycle reads r next
+    s0 += rv.x * rv.x; s1 += rv.y * rv.y;
+  }
+  block_store_partial2(s0, s1, rr_part, sh);
+}
+
+// beta_v = rz_new_v / rz_old_v; p = z + beta p
+__global__ __launch_bounds__(256) void k_cg2_update_p(int64_t n, const double* __restrict__ rz_new_part, int n_new,
+                                                      const double* __restrict__ rz_old_part, int n_old,
+                                                      const double* __restrict__ z, double* __restrict__ p) {
+  __shared__ double sh[8];
+  const double2 rzn = block_sum_partials2(rz_new_part, n_new, sh);
+  const double2 rzo = block_sum_partials2(rz_old_part, n_old, sh);
+  const double b0 = rzo.x != 0.0 ? rzn.x / rzo.x : 0.0, b1 = rzo.y != 0.0 ? rzn.y / rzo.y : 0.0;
+  PF_VEC_LOOP(i, n) {
+    const double2 zv = ld2(z, i);
+    double2 pv = ld2(p, i);
+    pv.x = zv.x + b0 * pv.x; pv.y = zv.y + b1 * pv.y;
+    st2(p, i, pv);
+  }
+}
+
+// partials of r.z per vector (only when the cycle ends without a product: never for the hierarchies pf_cg2 accepts)
+__global__ __launch_bounds__(256) void k_dot2(int64_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out_part) {
+  __shared__ double sh[8];
+  double s0 = 0.0, s1 = 0.0;
+  PF_VEC_LOOP(i, n) { const double2 av = ld2(a, i), bv = ld2(b, i); s0 += av.x * bv.x; s1 += av.y * bv.y; }
+  block_store_partial2(s0, s1, out_part, sh);
+}
+
+static void host_sum2(const double* v, int nblk, double out[2]) {
+  out[0] = out[1] = 0.0;
+  for (int i = 0; i < nblk; ++i) { out[0] += v[2 * i]; out[1] += v[2 * i + 1]; }
+}
+
+extern "C" int pf_cg2(pf_ctx* ctx, const double* vals, const double* b2, double* x2, double rtol, double atol, int maxiter,
+                      int reuse, int32_t* iters_host, double* relres_host) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && vals && b2 && x2 && iters_host && relres_host, "pf_cg2: no pattern / NULL argument");
+  if (ctx->d != 1) return pf_fail(ctx, PF_E_UNSUPPORTED, "pf_cg2: scalar matrices (one dof per node)");
+  PF_HIP(hipSetDevice(ctx->device));
+  const int64_t n = ctx->nnodes, n2 = 2 * n;
+  if (maxiter <= 0) maxiter = (int)std::min<int64_t>(10 * n, INT32_MAX);
+  if (ctx->cgw_cap < 4 * n2) {  // r, z, p, Ap of the pair
+    pf_free(ctx->cgw);
+    ctx->cgw_cap = 0;
+    PF_HIP(hipMalloc(&ctx->cgw, sizeof(double) * 4 * n2));
+    ctx->cgw_cap = 4 * n2;
+  }
+  double *r = ctx->cgw, *z = r + n2, *p = z + n2, *Ap = p + n2;
+  hipStream_t st = ctx->stream;
+  const unsigned vg = vec_grid(n2);
+  const int ns = (int)std::min<unsigned>(spmv_grid_d(n, 1), (unsigned)SPMV2_MAXGRID);
+  {
+    const int arc = pf_amg_setup(ctx, vals, reuse);
+    if (arc == PF_E_UNSUPPORTED) return pf_fail(ctx, arc, "pf_cg2: the matrix is not positive definite");
+    if (arc) return arc;
+  }
+  struct MultiStream {
+    pf_ctx* c;
+    bool was;
+    explicit MultiStream(pf_ctx* c_) : c(c_), was(c_->multi_stream) { c->multi_stream = true; }
+    ~MultiStream() { c->multi_stream = was; }
+  } multi_stream_guard(ctx);
+  int rc = pf_launch_spmv(ctx, vals, x2, Ap, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2);  // Ap = A x0
+  if (rc) return rc;
+  // partial arrays (pairs): PA_BB b.b, PA_RR |r|^2, PA_RZ0 / PA_RZ1 r.z ping-pong, PA_PAP p.Ap
+  k_cg2_init<<<vg, 256, 0, st>>>(n, b2, Ap, r, part(ctx, PA_BB), part(ctx, PA_RR));
+  PF_LAUNCH_CHECK();
+  if ((rc = readback_queue(ctx, part(ctx, PA_RR), 2 * NPART))) return rc;  // RR | BB, awaited behind the first cycle
+  int nrz = ns;
+  auto cycle = [&](double* rz_part) -> int {
+    bool dotted = false;
+    const int e = pf_amg_apply(ctx, r, z, rz_part, &dotted, 2);
+    if (e == PF_E_UNSUPPORTED) return pf_fail(ctx, e, "pf_cg2: the hierarchy has a level the two-vector cycle does not cover");
+    if (e) return e;
+    if (dotted) nrz = ns;
+    else { k_dot2<<<vg, 256, 0, st>>>(n, r, z, rz_part); nrz = (int)vg; }
+    return PF_OK;
+  };
+  if ((rc = cycle(part(ctx, PA_RZ0)))) return rc;
+  PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n2, hipMemcpyDeviceToDevice, st));
+  if ((rc = readback_wait(ctx))) return rc;
+  double bb[2], rr[2], rr_prev[2], tol[2], bnorm[2];
+  host_sum2(ctx->pin + NPART, (int)vg, bb);
+  host_sum2(ctx->pin, (int)vg, rr);
+  rr_prev[0] = rr[0]; rr_prev[1] = rr[1];
+  for (int v = 0; v < 2; ++v) {
+    bnorm[v] = sqrt(bb[v]);
+    tol[v] = std::max(rtol * bnorm[v], atol);
+    iters_host[v] = 0;
+  }
+  bool done[2] = {!(sqrt(rr[0]) > tol[0]), !(sqrt(rr[1]) > tol[1])};
+  int it = 0, cur = 0;
+  bool broke = false;
+  auto look = [&]() {  // the residuals of step `it`, just read back
+    double now[2];
+    host_sum2(ctx->pin, (int)vg, now);
+    for (int v = 0; v < 2; ++v) {
+      rr_prev[v] = rr[v];
+      rr[v] = now[v];
+      if (!(rr[v] == rr[v])) broke = true;  // NaN: breakdown
+      if (!done[v]) {
+        iters_host[v] = it;
+        done[v] = !(sqrt(rr[v]) > tol[v]);
+      }
+    }
+  };
+  while (!(done[0] && done[1]) && it < maxiter && !broke) {
+    double* rz_old = part(ctx, cur ? PA_RZ1 : PA_RZ0);
+    double* rz_new = part(ctx, cur ? PA_RZ0 : PA_RZ1);
+    // as in pf_cg: look before queuing the cycle when this step probably ends the solve, afterwards otherwise
+    bool early = true;
+    for (int v = 0; v < 2; ++v)
+      if (!done[v]) {
+        const double rn = sqrt(rr[v]), rp = sqrt(rr_prev[v]);
+        early = early && rn * std::min(1.0, rn / rp) <= 4.0 * tol[v];
+      }
+    rc = pf_launch_spmv(ctx, vals, p, Ap, part(ctx, PA_PAP), nullptr, nullptr, nullptr, nullptr, nullptr, 2);  // Ap = A p, p.Ap
+    if (rc) return rc;
+    const int nrz_old = nrz;
+    k_cg2_update_xr<<<vg, 256, 0, st>>>(n, rz_old, nrz_old, part(ctx, PA_PAP), ns, done[0] ? 1 : 0, done[1] ? 1 : 0, p, Ap, x2, r,
+                                        part(ctx, PA_RR));
+    if ((rc = readback_queue(ctx, part(ctx, PA_RR), 2 * (size_t)vg))) return rc;
+    ++it;
+    if (early) {
+      if ((rc = readback_wait(ctx))) return rc;
+      look();
+      if ((done[0] && done[1]) || broke || it >= maxiter) break;
+    }
+    if ((rc = cycle(rz_new))) return rc;
+    k_cg2_update_p<<<vg, 256, 0, st>>>(n, rz_new, nrz, rz_old, nrz_old, z, p);
+    PF_LAUNCH_CHECK();
+    cur ^= 1;
+    if (!early) {
+      if ((rc = readback_wait(ctx))) return rc;
+      look();
+    }
+  }
+  for (int v = 0; v < 2; ++v) relres_host[v] = bnorm[v] > 0 ? sqrt(rr[v]) / bnorm[v] : sqrt(rr[v]);
+  if (broke || !(done[0] && done[1]))
     return pf_fail(ctx, PF_E_NOCONV, "cg failed with code " + std::to_string(it));  // pyfem.py:2421-2422
   return PF_OK;
 }

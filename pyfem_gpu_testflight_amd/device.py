@@ -337,6 +337,19 @@ class HipContext:
         self._warn()
         return x, iters.value, relres.value
 
+    def cg2(self, vals, b2, x0=None, rtol=1e-8, atol=0.0, maxiter=0, reuse=True):
+        """AMG-PCG for two right-hand sides of a scalar matrix at once (pf_cg2): b2 is an (nnodes, 2) device array.
+        Returns (x2, (iters0, iters1), (relres0, relres1)); raises like cg() when either fails to converge and
+        ValueError (PF_E_UNSUPPORTED) when the pair has to be solved one by one."""
+        if b2.dim() != 2 or b2.shape[1] != 2 or b2.shape[0] != self.nnodes or not b2.is_contiguous():
+            raise ValueError("cg2: b2 must be a contiguous (nnodes, 2) array")
+        x = self.torch.zeros_like(b2) if x0 is None else x0.clone()
+        iters, relres = (_lib._i32 * 2)(), (_lib._f64 * 2)()
+        self._sync_stream()
+        rc = self.lib.pf_cg2(self._ctx, _ptr(vals), _ptr(b2), _ptr(x), rtol, atol, int(maxiter), 1 if reuse else 0, iters, relres)
+        _lib.check(self._ctx, rc, "pf_cg2")
+        return x, (iters[0], iters[1]), (relres[0], relres[1])
+
     def _warn(self):
         """Surface the library's non-fatal conditions (a refused preconditioner means a 100x slower solve)."""
         msg = self.lib.pf_last_warning(self._ctx)

@@ -759,47 +759,22 @@ class Helmholtz(ModelBase):
 
     def apply_gradient_pair(self, g1, g2):
         """(apply_gradient(g1), apply_gradient(g2)) -- the two gradient filters evalObjConGradient issues back to back
-        (topo.py:73-74) -- solved CONCURRENTLY: the second runs on a twin context (same mesh, same K, its own hierarchy
-        and work vectors, built on first use) from a second host thread on its own HIP stream.  An AMG-PCG iteration of
-        the filter is two fifths bandwidth (the finest level's products) and three fifths dependent-launch latency of
-        the small coarse levels; two independent solves fill each other's gaps (measured: the pair in ~1.4x the time of
-        one, bench.py c5).  Device tensors in, device tensors out; numpy inputs are solved one after the other."""
+        (topo.py:73-74; the reference solves them one after the other, pyfem.py:2110-2115) -- as ONE AMG-PCG over the
+        pair (pf_cg2): the two vectors sit next to each other per node, every product, smoother sweep and transfer
+        streams its operator once for both and the launch-bound coarse levels are walked once.  Each vector keeps its own
+        recurrence and stopping test, so each result is what apply_gradient gives alone (to rounding).  Device tensors
+        in, device tensors out; numpy inputs, and preconditioners other than AMG, are solved one after the other."""
         torch = self.hctx.torch
-        if not (isinstance(g1, torch.Tensor) and isinstance(g2, torch.Tensor)):
+        if not (isinstance(g1, torch.Tensor) and isinstance(g2, torch.Tensor)) or _PRECOND[self.precond] != _lib.PF_PRECOND_AMG:
             return self.apply_gradient(g1), self.apply_gradient(g2)
-        import threading
-
-        if getattr(self, "_twin", None) is None:
-            self._twin = Helmholtz(self.r0, self.X, self.conn, self.quadrature, self.basis, device=self.hctx.device.index)
-            self._pair_streams = (torch.cuda.Stream(device=self.hctx.device), torch.cuda.Stream(device=self.hctx.device))
-        twin = self._twin
-        twin.rtol, twin.precond = self.rtol, self.precond
-        main = torch.cuda.current_stream(self.hctx.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        out, err = [None, None], [None, None]
-
-        def work(i, filt, g, stream):
-            try:
-                with torch.cuda.stream(stream):
-                    stream.wait_event(ready)
-                    out[i] = filt.apply_gradient(g)
-            except BaseException as e:  # noqa: BLE001 -- re-raised in the calling thread
-                err[i] = e
-
-        t = threading.Thread(target=work, args=(1, twin, g2, self._pair_streams[1]))
-        t.start()
-        work(0, self, g1, self._pair_streams[0])
-        t.join()
-        for e in err:
-            if e is not None:
-                raise e
-        for i in (0, 1):
-            main.wait_stream(self._pair_streams[i])
-            out[i].record_stream(main)
-            (g1, g2)[i].record_stream(self._pair_streams[i])
-        self.last_iters = max(self.last_iters, twin.last_iters)
-        return out[0], out[1]
+        try:
+            sol, its, _ = self.hctx.cg2(self.K.vals, torch.stack((g1, g2), dim=1), rtol=self.rtol)
+        except ValueError:  # PF_E_UNSUPPORTED: a hierarchy the two-vector cycle does not cover
+            return self.apply_gradient(g1), self.apply_gradient(g2)
+        self.last_iters = max(its)
+        self.last_pair_iters = its
+        sol = sol.t().contiguous()  # (2, n): one vector after the other for R^T
+        return self.hctx.spmv(self.RT.vals, sol[0]), self.hctx.spmv(self.RT.vals, sol[1])
 
     @time_this
     def compute_rhs(self, x):

@@ -1424,11 +1424,12 @@ def test_user_defined_basis_runs_on_the_table_driven_kernels(pf, orc):
     assert relmax(u, spsolve(Kbc.tocsc(), rbc)) < U_TOL
 
 
-def test_filter_forward_reuse_and_concurrent_gradient_pair(pf):
+def test_filter_forward_reuse_and_two_vector_gradient_pair(pf):
     """The two device-side shortcuts of the optimisation callbacks (topo.py:50-75): apply(x) of an unchanged device tensor
     returns the kept result (and solves again after ANY in-place write to x or for another tensor), and
-    apply_gradient_pair solves the two gradient filters concurrently on a twin context -- same bits as one after the
-    other, because each solve is the same deterministic kernel sequence on its own context."""
+    apply_gradient_pair solves the two gradient filters as one AMG-PCG over the pair (pf_cg2): independent recurrences,
+    so the same iteration counts and the same results as one after the other up to the rounding of the reductions (the
+    partial sums are grouped differently), and bitwise reproducible from call to call."""
     import torch
 
     c = pf.ProblemCreator(97, 61)
@@ -1452,11 +1453,25 @@ def test_filter_forward_reuse_and_concurrent_gradient_pair(pf):
     assert np.allclose(filtr.apply(x0 + 0.25), r3.cpu().numpy(), rtol=0, atol=1e-12)  # numpy: always solved
     g1 = torch.cos(7 * h.to_device(X[:, 0].copy(), torch.float64)) + 0.3
     g2 = torch.full_like(g1, 1.0 / X.shape[0])
-    a1, a2 = filtr.apply_gradient(g1), filtr.apply_gradient(g2)
-    for _ in range(3):
-        b1, b2 = filtr.apply_gradient_pair(g1, g2)
-        assert torch.equal(a1, b1) and torch.equal(a2, b2)
-    n1, n2 = filtr.apply_gradient_pair(g1.cpu().numpy(), g2.cpu().numpy())
+    a1 = filtr.apply_gradient(g1); it1 = filtr.last_iters
+    a2 = filtr.apply_gradient(g2); it2 = filtr.last_iters
+    b1, b2 = filtr.apply_gradient_pair(g1, g2)
+    assert filtr.last_pair_iters == (it1, it2)
+    for a, b in ((a1, b1), (a2, b2)):
+        assert float((a - b).abs().max()) <= 1e-9 * float(a.abs().max())  # both solved to rtol 1e-11 of the same system
+    for _ in range(2):
+        c1, c2 = filtr.apply_gradient_pair(g1, g2)
+        assert torch.equal(c1, b1) and torch.equal(c2, b2)
+    # a zero vector next to a real one: frozen from the start, the other is not disturbed
+    z1, z2 = filtr.apply_gradient_pair(torch.zeros_like(g1), g2)
+    assert float(z1.abs().max()) == 0.0 and filtr.last_pair_iters == (0, it2)
+    assert float((z2 - a2).abs().max()) <= 1e-9 * float(a2.abs().max())
+    # against a dense solve of K y = g, then R^T y (pyfem.py:2110-2115)
+    Kd, Rd = filtr.K.to_scipy().toarray(), filtr.R.to_scipy().toarray()
+    for g, b in ((g1, b1), (g2, b2)):
+        ref = Rd.T @ np.linalg.solve(Kd, g.cpu().numpy())
+        assert relmax(b.cpu().numpy(), ref) < U_TOL
+    n1, n2 = filtr.apply_gradient_pair(g1.cpu().numpy(), g2.cpu().numpy())  # numpy: one after the other
     assert np.array_equal(n1, a1.cpu().numpy()) and np.array_equal(n2, a2.cpu().numpy())
 
 
