@@ -87,6 +87,12 @@ struct pf_amg {
                                 // read coordinates, so they run the dim = 2 code on any mesh)
   AmgLevel L[AMG_MAX_LEVELS];
   double* dense_inv = nullptr;  // coarsest level, (m x m) row-major
+  // The inversion (one workgroup, ~0.47 ms for 114 dofs) runs on a SIDE stream: the numeric setup does not wait for it,
+  // and the first cycle's work on the finer levels overlaps it; the stream that runs the cycle waits for ev_inv once,
+  // right before the first dense apply.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_coarse = nullptr, ev_inv = nullptr;
+  bool inv_pending = false;
   int64_t dense_m = 0;
   double* gersh = nullptr;      // scratch vector for the power iteration
   double* lam = nullptr;        // device: per-level |D^-1 A v|^2, the not-SPD flag, the finest diagonal scale
@@ -1476,6 +1482,12 @@ void pf_amg_free(pf_ctx* ctx) {
     pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32); pf_free(Lv.apptr); pf_free(Lv.apidx); pf_free(Lv.aprow); pf_free(Lv.apvals); pf_free(Lv.gptr); pf_free(Lv.gpair);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
   }
+  if (H->side) {
+    (void)hipStreamSynchronize(H->side);
+    (void)hipStreamDestroy(H->side);
+    (void)hipEventDestroy(H->ev_coarse);
+    (void)hipEventDestroy(H->ev_inv);
+  }
   pf_free(H->dense_inv);
   pf_free(H->gersh);
   pf_free(H->lam);
@@ -1835,14 +1847,26 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   }
   if (H->dense_inv) {
     AmgLevel& C = H->L[H->nlevels - 1];
-    PF_HIP(hipMemsetAsync(H->dense_inv, 0, sizeof(double) * H->dense_m * H->dense_m, ctx->stream));
+    if (!H->side) {
+      PF_HIP(hipStreamCreateWithFlags(&H->side, hipStreamNonBlocking));
+      PF_HIP(hipEventCreateWithFlags(&H->ev_coarse, hipEventDisableTiming));
+      PF_HIP(hipEventCreateWithFlags(&H->ev_inv, hipEventDisableTiming));
+    }
+    const char* side_env = pf_exp_env("PF_AMG_SIDE");
+    const bool use_side = !(side_env && atoi(side_env) == 0);
+    hipStream_t inv_stream = use_side ? H->side : ctx->stream;
+    PF_HIP(hipEventRecord(H->ev_coarse, ctx->stream));  // the coarsest operator is complete, the old inverse no longer in use
+    PF_HIP(hipStreamWaitEvent(inv_stream, H->ev_coarse, 0));
+    PF_HIP(hipMemsetAsync(H->dense_inv, 0, sizeof(double) * H->dense_m * H->dense_m, inv_stream));
     const unsigned g = (unsigned)cdiv(C.n, 128);
-    if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
-    else if (C.dr == 6) k_amg_to_dense<6><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
-    else k_amg_to_dense<3><<<g, 128, 0, ctx->stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
-    if (H->dense_m <= 128) k_amg_dense_invert<4><<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
-    else k_amg_dense_invert<5><<<1, 1024, 0, ctx->stream>>>(H->dense_inv, (int)H->dense_m);
+    if (C.dr == 1) k_amg_to_dense<1><<<g, 128, 0, inv_stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    else if (C.dr == 6) k_amg_to_dense<6><<<g, 128, 0, inv_stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    else k_amg_to_dense<3><<<g, 128, 0, inv_stream>>>(C.n, C.ptr, C.idx, C.vals, H->dense_inv, H->dense_m);
+    if (H->dense_m <= 128) k_amg_dense_invert<4><<<1, 1024, 0, inv_stream>>>(H->dense_inv, (int)H->dense_m);
+    else k_amg_dense_invert<5><<<1, 1024, 0, inv_stream>>>(H->dense_inv, (int)H->dense_m);
     PF_LAUNCH_CHECK();
+    PF_HIP(hipEventRecord(H->ev_inv, inv_stream));
+    H->inv_pending = true;
   }
   double h[AMG_MAX_LEVELS + 3];
   PF_HIP(hipMemcpyAsync(h, H->lam, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1940,6 +1964,10 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
     double* x = (Lc == 0) ? z : C.x;
     const int64_t ndof = C.n * C.dr;
     if (H->dense_inv && Lc > 0) {
+      if (H->inv_pending) {  // the inverse of this numeric setup, made on the side stream
+        PF_HIP(hipStreamWaitEvent(st, H->ev_inv, 0));
+        H->inv_pending = false;
+      }
       if (nv == 2) k_amg_dense_apply<2><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
       else k_amg_dense_apply<1><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
     } else {  // could not coarsen down to the dense size (or a one-level hierarchy): Jacobi sweeps

@@ -6,7 +6,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
 inits = [i for i, r in enumerate(rows) if name(r).startswith("k_cg_init")]
 # the last solve whose setup contains a Galerkin product of the finest level
-cands = [i for i in inits if any("k_sa_galerkin_wave<2, 3" in name(rows[j]) for j in range(max(0, i - 400), i))]
+cands = [i for i in inits if any(name(rows[j]).startswith(("k_sa_galerkin_wave<2, 3", "k_sa_ap<2, 3")) for j in range(max(0, i - 400), i))]
 i1 = cands[-1]
 i0 = max(j for j in range(i1) if name(rows[j]).startswith(("k_cg_update_p", "k_apply_dirichlet")))  # end of the previous solve
 t0 = int(rows[i0]["End_Timestamp"]); prev = t0; busy = 0
