@@ -31,6 +31,7 @@
 #include "pf_common.h"
 
 static constexpr int AMG_MAX_LEVELS = 12;
+static constexpr int AMG_POW_PARTS = 4096;     // waves of one product launch at most (k_amg_spmv grids, SPMV_MAXGRID)
 static constexpr int AMG_COARSEST_DOFS = 160;  // dense inverse: cost ~ m^3 on one workgroup per numeric setup
 
 struct AmgLevel {
@@ -95,6 +96,7 @@ struct pf_amg {
   bool inv_pending = false;
   int64_t dense_m = 0;
   double* gersh = nullptr;      // scratch vector for the power iteration
+  double* powpart = nullptr;    // 2 x AMG_POW_PARTS per-wave partials of the last two iterates' norms
   double* lam = nullptr;        // device: per-level |D^-1 A v|^2, the not-SPD flag, the finest diagonal scale
   bool numeric_ok = false;      // the numeric setup below matches L[0].vals
   int sa_mode = 1;              // PF_AMG_SA: 0 tentative P on the fly everywhere (plain aggregation), 2 smoothed
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_wave(int64_t nc, const int3
 //   AMG_AX   y = A x                         AMG_RESID  y = b - A x
 //   AMG_SMOOTH y = x + dinv .* (b - A x)     (one damped-Jacobi sweep, y != x)
 //   AMG_SMOOTH0 two sweeps from a zero guess: x1 = dinv .* b (formed on the fly), y = x1 + dinv2 .* (b - A x1)
-enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3 };
+//   AMG_POW  y = (A x) ./ dinv  (one power-iteration step of D^-1 A during the numeric setup, when dinv still holds the RAW
+//            diagonal) and, if dinv2 != NULL, dinv2[wave] = this wave's share of |y|^2 (fixed order: reproducible)
+enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3, AMG_POW = 4 };
 // TR = rows per wave tile.  64 on the large levels (bandwidth); 16 on the small ones (n <= AMG_SMALL_LEVEL), where a tile's
 // ~25 x 64 entries took two to four dependent chunks and the kernel 8 - 9 us of pure latency against ~5.5 us with a
 // single chunk per wave and four times as many waves (r03).
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
   constexpr int CH = 448;
   __shared__ double prod[CH * D * NV];
   const int lane = threadIdx.x;
+  double yy = 0.0;  // AMG_POW
   const int64_t ntiles = (n + TR - 1) / TR;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t i = tile * TR + lane;
@@ -458,8 +463,16 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
           if constexpr (MODE == AMG_RESID) out = b[qv] - out;
           if constexpr (MODE == AMG_SMOOTH) out = x[qv] + dinv[q] * (b[qv] - out);
           if constexpr (MODE == AMG_SMOOTH0) out = dinv[q] * b[qv] + dinv2[q] * (b[qv] - out);  // x1 + D2 (b - A x1)
+          if constexpr (MODE == AMG_POW) { out = out / dinv[q]; yy += out * out; }
           y[qv] = out;
         }
+  }
+  if constexpr (MODE == AMG_POW) {
+    if (dinv2) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) yy += __shfl_xor(yy, o);
+      if (lane == 0) const_cast<double*>(dinv2)[blockIdx.x] = yy;
+    }
   }
 }
 
@@ -1490,6 +1503,7 @@ void pf_amg_free(pf_ctx* ctx) {
   }
   pf_free(H->dense_inv);
   pf_free(H->gersh);
+  pf_free(H->powpart);
   pf_free(H->lam);
   delete H;
   ctx->amg = nullptr;
@@ -1608,6 +1622,7 @@ static int amg_build_hierarchy(pf_ctx* ctx) {
   int64_t maxdof = 1;
   for (int k = 0; k < H->nlevels; ++k) maxdof = std::max(maxdof, H->L[k].n * H->L[k].dr);
   PF_HIP(hipMalloc(&H->gersh, sizeof(double) * maxdof));
+  PF_HIP(hipMalloc(&H->powpart, sizeof(double) * 2 * AMG_POW_PARTS));
   PF_HIP(hipMalloc(&H->lam, sizeof(double) * (AMG_MAX_LEVELS + 4)));  // + non-positive flag + diagonal scale + positive flag + power-iteration scratch
   return PF_OK;
 }
@@ -1618,6 +1633,8 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
   const double* dv = which ? Lv.dinv2 : Lv.dinv;
   if (level == 0) {
     if (mode == AMG_SMOOTH0) return pf_fail(ctx, PF_E_INVALID, "amg_spmv: AMG_SMOOTH0 is a coarse-level mode");
+    if (mode == AMG_POW)  // y = (A x) ./ diag, dot_part <- partials of |y|^2 (Lv.dinv holds the raw diagonal during the setup)
+      return pf_launch_spmv(ctx, Lv.vals, x, y, dot_part, nullptr, nullptr, Lv.vals32, nullptr, nullptr, 1, Lv.dinv);
     return pf_launch_spmv(ctx, Lv.vals, x, y, dot_part, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
                           Lv.vals32, nullptr, nullptr, nv);
   }
@@ -1647,6 +1664,12 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
     else k_amg_spmv<D_, M_, double><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
   } while (0)
 #define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
+  if (mode == AMG_POW) {  // dv = the raw diagonal, the partial array travels in the dinv2 slot
+    const double* dinv2_keep = Lv.dinv2;
+    Lv.dinv2 = dot_part;
+    PF_ASD(AMG_POW);
+    Lv.dinv2 = const_cast<double*>(dinv2_keep);
+  } else
   if (mode == AMG_AX) PF_ASD(AMG_AX);
   else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
   else if (mode == AMG_RESID) PF_ASD(AMG_RESID);
@@ -1687,25 +1710,55 @@ __global__ void k_amg_pow_div(int64_t n, const double* __restrict__ diag, const 
 // holding |D^-1 A v|^2 with |v| = 1.  Lv.dinv still holds the raw diagonal; v is scratch of at least ndof
 // doubles.  Unlike a Gershgorin row sum this is invariant under the scaling of individual dofs, which
 // matters on the coarse levels where translations and the rotation have different units.
+// lam2[0] = (sum of partB) / (sum of partA): one block, fixed order
+__global__ __launch_bounds__(256) void k_amg_pow_ratio_parts(double* __restrict__ lam2, const double* __restrict__ partA, int nA,
+                                                            const double* __restrict__ partB, int nB) {
+  __shared__ double sh[8];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nA; i += 256) a += partA[i];
+  for (int i = threadIdx.x; i < nB; i += 256) b += partB[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double den = sh[0] + sh[1] + sh[2] + sh[3], num = sh[4] + sh[5] + sh[6] + sh[7];
+    lam2[0] = den > 0.0 ? num / den : 0.0;
+  }
+}
 __global__ void k_amg_pow_ratio(double* __restrict__ num, const double* __restrict__ den) { num[0] = den[0] > 0.0 ? num[0] / den[0] : 0.0; }
 
 // The iterate is NOT normalised between steps: D^-1 A has a spectral radius of a few units, ten steps grow the start
-// vector by at most that to the tenth, and only the last two norms are needed -- two launches per step (product, divide
-// by the diagonal) instead of five (+ dot, its finalize, rescale): 30 launches less per level and numeric setup.
-static int amg_power_lambda(pf_ctx* ctx, AmgLevel& Lv, int level, double* v, double* lam2, double* den, int steps) {
+// vector by at most that to the tenth, and only the last two norms are needed.  One launch per step: the product divides
+// by the diagonal in its epilogue and leaves per-wave partials of |y|^2 (AMG_POW; round 2 and early round 3: product,
+// divide, and for the last two steps dot + finalize -- 26 launches per level, most of them on levels where a launch is
+// all latency).  The iterate ping-pongs between v and Lv.t.  3x3-block finest levels (k_spmv3) keep the separate kernels.
+static int amg_power_lambda(pf_ctx* ctx, pf_amg* H, AmgLevel& Lv, int level, double* v, double* lam2, double* den, int steps) {
   const int64_t ndof = Lv.n * Lv.dr;
   const unsigned g = (unsigned)cdiv(ndof, 256);
   k_amg_pow_init<<<g, 256, 0, ctx->stream>>>(ndof, v);
-  for (int it = 0; it < steps; ++it) {
-    int rc;
-    if (it == steps - 1 && (rc = pf_dot(ctx, ndof, v, v, nullptr, den))) return rc;  // |v_9|^2
-    rc = amg_spmv(ctx, Lv, level, v, Lv.t);
+  if (level == 0 && ctx->d == 3) {
+    for (int it = 0; it < steps; ++it) {
+      int rc;
+      if (it == steps - 1 && (rc = pf_dot(ctx, ndof, v, v, nullptr, den))) return rc;  // |v_9|^2
+      rc = amg_spmv(ctx, Lv, level, v, Lv.t);
+      if (rc) return rc;
+      k_amg_pow_div<<<g, 256, 0, ctx->stream>>>(ndof, Lv.dinv, Lv.t, v);
+    }
+    int rc = pf_dot(ctx, ndof, v, v, nullptr, lam2);  // |v_10|^2
     if (rc) return rc;
-    k_amg_pow_div<<<g, 256, 0, ctx->stream>>>(ndof, Lv.dinv, Lv.t, v);
+    k_amg_pow_ratio<<<1, 1, 0, ctx->stream>>>(lam2, den);  // |D^-1 A v_9|^2 / |v_9|^2
+    PF_LAUNCH_CHECK();
+    return PF_OK;
   }
-  int rc = pf_dot(ctx, ndof, v, v, nullptr, lam2);  // |v_10|^2
-  if (rc) return rc;
-  k_amg_pow_ratio<<<1, 1, 0, ctx->stream>>>(lam2, den);  // |D^-1 A v_9|^2 / |v_9|^2
+  double *a = v, *b = Lv.t;
+  const int nparts = level == 0 ? pf_spmv_waves(ctx) : (int)std::min<int64_t>(cdiv(Lv.n, Lv.n <= AMG_SMALL_LEVEL ? 16 : 64), 4096);
+  for (int it = 0; it < steps; ++it) {
+    double* parts = it == steps - 2 ? H->powpart : it == steps - 1 ? H->powpart + AMG_POW_PARTS : nullptr;  // |v_9|^2, |v_10|^2
+    if (int rc = amg_spmv(ctx, Lv, level, a, b, AMG_POW, nullptr, 0, parts)) return rc;
+    std::swap(a, b);
+  }
+  k_amg_pow_ratio_parts<<<1, 256, 0, ctx->stream>>>(lam2, H->powpart, nparts, H->powpart + AMG_POW_PARTS, nparts);
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -1764,7 +1817,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
     // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
     const int64_t ndof = Lv.n * Lv.dr;
-    int rc = amg_power_lambda(ctx, Lv, l, H->gersh, H->lam + l, H->lam + AMG_MAX_LEVELS + 3, H->pow_iters);
+    int rc = amg_power_lambda(ctx, H, Lv, l, H->gersh, H->lam + l, H->lam + AMG_MAX_LEVELS + 3, H->pow_iters);
     if (rc) return rc;
     if (l + 1 < H->nlevels) {
       AmgLevel& Nx = H->L[l + 1];

@@ -292,7 +292,9 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
                    const double* sm_dinv = nullptr, const double* sm_b = nullptr,  // smoother epilogues: pf_solve.hip
                    const float* vals32 = nullptr,                                  // fp32 copy of vals to use instead
                    const pf_spmv_send* snd = nullptr, const int32_t* snd_tperm = nullptr,   // fused exchange (pf_halo.hip)
-                   int nv = 1);  // 2: x, y, sm_b hold TWO vectors interleaved per node (scalar matrices; dot_part: 2 per wave)
+                   int nv = 1,   // 2: x, y, sm_b hold TWO vectors interleaved per node (scalar matrices; dot_part: 2 per wave)
+                   const double* pw_diag = nullptr);  // y = (A x) ./ pw_diag, dot_part <- partials of |y|^2 (power-iteration step)
+int pf_spmv_waves(pf_ctx* ctx);  // waves (= dot partials) of one pf_launch_spmv launch on this pattern
 int pf_halo_recv_apply(pf_halo* h, int plan, const double* x, const double* d, const double* b, double* y);
 // the two launches of a distributed CG iteration and their helpers (pf_solve.hip; used by pf_dist.hip as well)
 int pf_dist_product(pf_ctx* ctx, pf_halo* halo, int plan, const double* vals, const float* vals32, const double* x, double* y,

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
                                              const double* __restrict__ x, double* __restrict__ y,
                                              double* __restrict__ dot_part, const double* __restrict__ sm_dinv,
                                              const double* __restrict__ sm_b, const int32_t* __restrict__ tperm,
+                                             const double* __restrict__ pw_diag,
                                              const std::conditional_t<SEND, pf_spmv_send, pf_spmv_nosend> snd) {
   using V = typename Vec<D>::T;
   constexpr int TILE = 64 * R;
@@ -329,14 +330,20 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
           }
         }
         // partials: x.y for a plain product (p.Ap of CG); with a smoother epilogue b.y -- the r.z of AMG-PCG when this is
-        // the cycle's last sweep (b = r, y = z): no separate dot kernel, no extra pass over r and z
+        // the cycle's last sweep (b = r, y = z): no separate dot kernel, no extra pass over r and z.  pw_diag (a step of
+        // the power iteration on D^-1 A, AMG numeric setup): y = (A x) ./ diag and the partials are those of |y|^2.
         if constexpr (D == 1) {
+          if (pw_diag) acc[r] = acc[r] / pw_diag[n];
           y[n] = acc[r];
-          if (dot_part) dacc += (sm_b ? sm_b[n] : x[n]) * acc[r];
+          if (dot_part) dacc += (pw_diag ? acc[r] : sm_b ? sm_b[n] : x[n]) * acc[r];
         } else {
+          if (pw_diag) {
+            const double2 dg = *reinterpret_cast<const double2*>(pw_diag + 2 * n);
+            acc[r] = make_double2(acc[r].x / dg.x, acc[r].y / dg.y);
+          }
           *reinterpret_cast<double2*>(y + 2 * n) = acc[r];
           if (dot_part) {
-            const double2 xv = *reinterpret_cast<const double2*>((sm_b ? sm_b : x) + 2 * n);
+            const double2 xv = pw_diag ? acc[r] : *reinterpret_cast<const double2*>((sm_b ? sm_b : x) + 2 * n);
             dacc += xv.x * acc[r].x + xv.y * acc[r].y;
           }
         }
@@ -1089,6 +1096,7 @@ static inline unsigned spmv_grid_d(int64_t nnodes, int d) {
   return (unsigned)std::min<int64_t>(cdiv(nnodes, d == 1 ? SPMV_TILE1 : SPMV_TILE2), SPMV_MAXGRID);
 }
 static inline double* part(pf_ctx* ctx, int which) { return ctx->scal + (size_t)which * NPART; }
+int pf_spmv_waves(pf_ctx* ctx) { return (int)spmv_grid_d(ctx->nnodes, ctx->d); }
 
 // 16-bit column offsets for the d = 1 and d = 2 products (12 -> 10 bytes per scalar nonzero, 36 -> 34 per 2x2 block):
 // neighbour id minus the first node of the
@@ -1130,10 +1138,10 @@ static int ensure_idx16(pf_ctx* ctx) {
 template <int D, int R, int U, int CH, typename VT>
 static void spmv_dispatch(pf_ctx* ctx, unsigned grid, bool i16, bool ntv, const int32_t* cols, const VT* v, const double* x, double* y,
                           double* dot_part, const double* sm_dinv, const double* sm_b, const pf_spmv_send* snd,
-                          const int32_t* tperm) {
+                          const int32_t* tperm, const double* pw_diag) {
 #define PF_GO(I16_, SEND_, NTV_, SND_)                                                                                \
   k_spmv<D, R, U, CH, I16_, VT, SEND_, NTV_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, cols, v, x, y, dot_part, sm_dinv, \
-                                                                           sm_b, tperm, SND_)
+                                                                           sm_b, tperm, pw_diag, SND_)
   if (snd) {
     if (i16) { if (ntv) PF_GO(true, true, true, *snd); else PF_GO(true, true, false, *snd); }
     else { if (ntv) PF_GO(false, true, true, *snd); else PF_GO(false, true, false, *snd); }
@@ -1146,8 +1154,10 @@ static void spmv_dispatch(pf_ctx* ctx, unsigned grid, bool i16, bool ntv, const 
 
 int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, double* dot_part,
                    const double* sm_dinv, const double* sm_b, const float* vals32, const pf_spmv_send* snd,
-                   const int32_t* snd_tperm, int nv) {
+                   const int32_t* snd_tperm, int nv, const double* pw_diag) {
   unsigned grid = spmv_grid_d(ctx->nnodes, ctx->d);
+  if (pw_diag && (ctx->d == 3 || nv != 1 || snd || sm_b || sm_dinv))
+    return pf_fail(ctx, PF_E_UNSUPPORTED, "power-iteration product: plain one-vector product of 1 or 2 dofs per node");
   if (nv == 2) {  // scalar matrix, two vectors
     if (ctx->d != 1 || snd) return pf_fail(ctx, PF_E_UNSUPPORTED, "two-vector product: scalar matrices, no fused exchange");
     if (int rc16 = ensure_idx16(ctx)) return rc16;
@@ -1177,12 +1187,12 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
   }
 #ifdef PF_SPMV_SWEEP
   const char* sh = pf_exp_env("PF_SPMV_SHAPE");
-  const int shape = (sh && !vals32 && !snd) ? atoi(sh) : 0;
+  const int shape = (sh && !vals32 && !snd && !pw_diag) ? atoi(sh) : 0;
 #define PF_TRY(ID, D_, R_, U_, CH_)                                                                         \
   if (shape == ID && ctx->d == D_) {                                                                        \
     grid = (unsigned)std::min<int64_t>(cdiv(ctx->nnodes, 64 * R_), SPMV_MAXGRID);                            \
     k_spmv<D_, R_, U_, CH_><<<grid, 64, 0, ctx->stream>>>(ctx->nnodes, ctx->nptr, ctx->nidx, vals, x, y, dot_part, sm_dinv, sm_b, \
-                                                          64 * R_ == (D_ == 1 ? SPMV_TILE1 : SPMV_TILE2) ? ctx->spmv_perm : nullptr, pf_spmv_nosend{}); \
+                                                          64 * R_ == (D_ == 1 ? SPMV_TILE1 : SPMV_TILE2) ? ctx->spmv_perm : nullptr, pw_diag, pf_spmv_nosend{}); \
     PF_LAUNCH_CHECK();                                                                                      \
     return PF_OK;                                                                                           \
   }
@@ -1198,11 +1208,11 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
   const int64_t stream = ctx->nblocks * ((int64_t)ctx->d * ctx->d * (vals32 ? 4 : 8) + (i16 ? 2 : 4));
   const bool ntv = ctx->multi_stream || stream >= SPMV_NT_MIN_BYTES;
   if (vals32) {
-    if (ctx->d == 1) spmv_dispatch<PF_SPMV1F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
-    else spmv_dispatch<PF_SPMV2F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
+    if (ctx->d == 1) spmv_dispatch<PF_SPMV1F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm, pw_diag);
+    else spmv_dispatch<PF_SPMV2F, float>(ctx, grid, i16, ntv, cols, vals32, x, y, dot_part, sm_dinv, sm_b, snd, tperm, pw_diag);
   } else {
-    if (ctx->d == 1) spmv_dispatch<PF_SPMV1, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
-    else spmv_dispatch<PF_SPMV2, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm);
+    if (ctx->d == 1) spmv_dispatch<PF_SPMV1, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm, pw_diag);
+    else spmv_dispatch<PF_SPMV2, double>(ctx, grid, i16, ntv, cols, vals, x, y, dot_part, sm_dinv, sm_b, snd, tperm, pw_diag);
   }
   PF_LAUNCH_CHECK();
   return PF_OK;
