@@ -133,7 +133,9 @@ template <int D>
 __global__ __launch_bounds__(256) void k_amg_rows(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                                                   const double* __restrict__ vals, uint8_t* __restrict__ iso,
                                                   double* __restrict__ diag, double* __restrict__ bad,
-                                                  double* __restrict__ scale, int finest) {
+                                                  double* __restrict__ scale, int finest, float* __restrict__ v32) {
+  // v32 != NULL: the fp32 copy of the operator the cycle reads is written in the same pass (it was a pass of its own over
+  // the 600 MB of the fine matrix, and one more launch on every coarse level)
   const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / AMG_ROW_LANES;
   const int sub = threadIdx.x & (AMG_ROW_LANES - 1);
   const bool valid = i < n;  // the lanes of a group agree, and a group never straddles a wave
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(256) void k_amg_rows(int64_t n, const int32_t* __re
   for (int32_t g = gb + sub; g < ge; g += AMG_ROW_LANES) {
     const int64_t m = idx[g];
     const double* a = vals + (int64_t)g * D * D;
+    if (v32) {
+#pragma unroll
+      for (int q = 0; q < D * D; ++q) v32[(int64_t)g * D * D + q] = (float)a[q];
+    }
 #pragma unroll
     for (int k = 0; k < D; ++k)
 #pragma unroll
@@ -1799,9 +1805,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
     if (!fp32) {
       pf_free(L0.vals32);
     } else {
-      if (!L0.vals32) PF_HIP(hipMalloc(&L0.vals32, sizeof(float) * (size_t)nv));
-      k_amg_to_f32<<<(unsigned)std::min<int64_t>(cdiv(nv, 256), 8192), 256, 0, ctx->stream>>>(nv, vals, L0.vals32);
-      PF_LAUNCH_CHECK();
+      if (!L0.vals32) PF_HIP(hipMalloc(&L0.vals32, sizeof(float) * (size_t)nv));  // written by k_amg_rows below
     }
   }
   double* bad = H->lam + AMG_MAX_LEVELS;
@@ -1809,10 +1813,10 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   for (int l = 0; l < H->nlevels; ++l) {
     AmgLevel& Lv = H->L[l];
     const unsigned gr = (unsigned)cdiv(Lv.n * AMG_ROW_LANES, 256);
-    if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
-    else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
-    else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
-    else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0);
+    if (Lv.dr == 1) k_amg_rows<1><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0, Lv.vals32);
+    else if (Lv.dr == 2) k_amg_rows<2><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0, Lv.vals32);
+    else if (Lv.dr == 6) k_amg_rows<6><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0, Lv.vals32);
+    else k_amg_rows<3><<<gr, 256, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, Lv.iso, Lv.dinv, bad, H->lam + AMG_MAX_LEVELS + 1, l == 0, Lv.vals32);
     PF_LAUNCH_CHECK();
     // lambda_max(D^-1 A) of this level (power iteration under-estimates slightly, hence the 1.1 in the consumers):
     // damping of the smoother and of the prolongator smoothing.  Lv.dinv still holds the raw diagonal.
@@ -1888,8 +1892,7 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
       PF_LAUNCH_CHECK();
       const int64_t nvc = Nx.nblk * Nx.dr * Nx.dr;
       if (fp32) {
-        if (!Nx.vals32) PF_HIP(hipMalloc(&Nx.vals32, sizeof(float) * (size_t)std::max<int64_t>(nvc, 1)));
-        k_amg_to_f32<<<(unsigned)std::min<int64_t>(cdiv(nvc, 256), 8192), 256, 0, ctx->stream>>>(nvc, Nx.vals, Nx.vals32);
+        if (!Nx.vals32) PF_HIP(hipMalloc(&Nx.vals32, sizeof(float) * (size_t)std::max<int64_t>(nvc, 1)));  // written by the next level's k_amg_rows
       } else {
         pf_free(Nx.vals32);
       }
