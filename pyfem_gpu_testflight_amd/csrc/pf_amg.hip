@@ -72,6 +72,8 @@ struct AmgLevel {
   int32_t* aprow = nullptr;  // (nap) the row of every entry
   double* apvals = nullptr;  // (nap) blocks of dr x dc(next level)
   int64_t nap = 0;
+  int32_t* aplptr = nullptr; // (nap + 1) plan of A P: for every entry (n, J) the (block of A, block of P) pairs it sums --
+  int2* aplpair = nullptr;   //   which neighbour's row of P holds J, found once per pattern instead of once per matrix
   int32_t* gptr = nullptr;   // (next level's nblk + 1) gather plan of P^T (A P): the (P block, A P block) pairs of every coarse
   int2* gpair = nullptr;     //   entry (I, J >= I), in ascending fine-node order; entries below the diagonal have none
   int64_t ngpair = 0;
@@ -1271,6 +1273,82 @@ __global__ __launch_bounds__(256) void k_sa_ap(int64_t nap, const int32_t* __res
     for (int c = 0; c < DC; ++c) dst[r * DC + c] = acc[r][c];
 }
 
+// Plan of the first step, once per pattern: entry q = (n, J) of A P sums A[n, m] P[m, J] over the neighbours m of n whose
+// row of P holds J.  Finding them is four dependent loads per neighbour (column id, row bounds of P, its aggregate ids,
+// then the blocks) -- k_sa_ap spent its 0.94 ms on configuration 5's finest level waiting for those chains.  The plan
+// stores the (block of A, block of P) index pairs, so the numeric kernel issues independent loads.
+// count != NULL: count pass; else fill pass.
+__global__ __launch_bounds__(256) void k_sa_applan(int64_t nap, const int32_t* __restrict__ aprow, const int32_t* __restrict__ apidx,
+                                                  const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                  const int32_t* __restrict__ pptr, const int32_t* __restrict__ pidx,
+                                                  int32_t* __restrict__ count, const int32_t* __restrict__ aplptr,
+                                                  int2* __restrict__ aplpair) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nap) return;
+  const int64_t i = aprow[q];
+  const int32_t J = apidx[q];
+  int32_t cnt = 0;
+  const int32_t base = count ? 0 : aplptr[q];
+  for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
+    const int32_t m = idx[g];
+    int32_t s2 = pptr[m];
+    const int32_t se = pptr[m + 1];
+    while (s2 < se && pidx[s2] < J) ++s2;
+    if (s2 == se || pidx[s2] != J) continue;
+    if (!count) aplpair[base + cnt] = make_int2(g, s2);
+    ++cnt;
+  }
+  if (count) count[q] = cnt;
+}
+
+template <int DR, int DC>
+__global__ __launch_bounds__(256) void k_sa_ap_planned(int64_t nap, const int32_t* __restrict__ aplptr, const int2* __restrict__ aplpair,
+                                                      const double* __restrict__ vals, const double* __restrict__ pvals,
+                                                      double* __restrict__ apvals) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nap) return;
+  const int32_t kb = aplptr[q], ke = aplptr[q + 1];
+  double acc[DR][DC];
+#pragma unroll
+  for (int r = 0; r < DR; ++r)
+#pragma unroll
+    for (int c = 0; c < DC; ++c) acc[r][c] = 0.0;
+  constexpr int U = (DR * DC <= 9) ? 3 : 1;  // pairs in flight
+  for (int32_t k0 = kb; k0 < ke; k0 += U) {
+    int2 pr[U];
+    double a[U][DR * DR], Pm[U][DR * DC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pr[u] = aplpair[min(k0 + u, ke - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double* p1 = vals + (int64_t)pr[u].x * DR * DR;
+      const double* p2 = pvals + (int64_t)pr[u].y * DR * DC;
+#pragma unroll
+      for (int k = 0; k < DR * DR; ++k) a[u][k] = p1[k];
+#pragma unroll
+      for (int k = 0; k < DR * DC; ++k) Pm[u][k] = p2[k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + u >= ke) continue;
+#pragma unroll
+      for (int r = 0; r < DR; ++r)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int tt = 0; tt < DR; ++tt) sacc += a[u][r * DR + tt] * Pm[u][tt * DC + c];
+          acc[r][c] += sacc;  // neighbours in ascending order, as in k_sa_ap: the same bits
+        }
+    }
+  }
+  double* dst = apvals + q * DR * DC;
+#pragma unroll
+  for (int r = 0; r < DR; ++r)
+#pragma unroll
+    for (int c = 0; c < DC; ++c) dst[r * DC + c] = acc[r][c];
+}
+
 __global__ void k_sa_aprow_of(int64_t n, const int32_t* __restrict__ apptr, int32_t* __restrict__ aprow) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1309,6 +1387,9 @@ __global__ __launch_bounds__(64) void k_sa_gplan(int64_t nc, const int32_t* __re
   }
 }
 
+#ifndef PF_AB_PTAP_U
+#define PF_AB_PTAP_U 2
+#endif
 template <int DR, int DC>
 __global__ __launch_bounds__(256) void k_sa_ptap(int64_t nq, const int32_t* __restrict__ gptr, const int2* __restrict__ gpair,
                                                 const double* __restrict__ pvals, const double* __restrict__ apvals,
@@ -1322,20 +1403,21 @@ __global__ __launch_bounds__(256) void k_sa_ptap(int64_t nq, const int32_t* __re
   for (int c = 0; c < DC; ++c)
 #pragma unroll
     for (int c2 = 0; c2 < DC; ++c2) acc[c][c2] = 0.0;
-  for (int32_t g0 = gb; g0 < ge; g0 += 2) {  // two pairs in flight
-    int2 pr[2];
-    double Pn[2][DR * DC], AP[2][DR * DC];
+  constexpr int UP = PF_AB_PTAP_U;  // pairs in flight
+  for (int32_t g0 = gb; g0 < ge; g0 += UP) {
+    int2 pr[UP];
+    double Pn[UP][DR * DC], AP[UP][DR * DC];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) pr[u] = gpair[min(g0 + u, ge - 1)];
+    for (int u = 0; u < UP; ++u) pr[u] = gpair[min(g0 + u, ge - 1)];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < UP; ++u) {
       const double* p1 = pvals + (int64_t)pr[u].x * DR * DC;
       const double* p2 = apvals + (int64_t)pr[u].y * DR * DC;
 #pragma unroll
       for (int k = 0; k < DR * DC; ++k) { Pn[u][k] = p1[k]; AP[u][k] = p2[k]; }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < UP; ++u) {
       if (g0 + u >= ge) continue;
 #pragma unroll
       for (int c = 0; c < DC; ++c)
@@ -1450,6 +1532,30 @@ static int sa_pattern_device(pf_ctx* ctx, AmgLevel& Lv, int64_t n, const int32_t
       Lv.apptr = apptr; Lv.apidx = apidx; Lv.nap = tot2;
       PF_HIP(hipMalloc(&Lv.aprow, sizeof(int32_t) * (size_t)tot2));
       k_sa_aprow_of<<<gn, 128, 0, st>>>(n, apptr, Lv.aprow);
+      {  // plan of A P (count, scan, fill); without it k_sa_ap searches the rows of P itself
+        int32_t *acnt = nullptr, *aplptr = nullptr;
+        const unsigned ga = (unsigned)cdiv(tot2, 256);
+        PF_HIP(hipMalloc(&acnt, sizeof(int32_t) * (size_t)(tot2 + 1)));
+        PF_HIP(hipMalloc(&aplptr, sizeof(int32_t) * (size_t)(tot2 + 1)));
+        PF_HIP(hipMemsetAsync(acnt, 0, sizeof(int32_t) * (size_t)(tot2 + 1), st));
+        k_sa_applan<<<ga, 256, 0, st>>>(tot2, Lv.aprow, apidx, d_ptr, d_idx, pptr, pidx, acnt, nullptr, nullptr);
+        int rc4 = sa_scan(ctx, acnt, aplptr, (int64_t)tot2 + 1);
+        int32_t tot4 = 0;
+        if (rc4 == PF_OK) {
+          PF_HIP(hipMemcpyAsync(&tot4, aplptr + tot2, sizeof(tot4), hipMemcpyDeviceToHost, st));
+          PF_HIP(hipStreamSynchronize(st));
+        }
+        (void)hipFree(acnt);
+        int2* aplpair = nullptr;
+        if (rc4 == PF_OK && tot4 > 0 && hipMalloc(&aplpair, sizeof(int2) * (size_t)tot4) == hipSuccess) {
+          k_sa_applan<<<ga, 256, 0, st>>>(tot2, Lv.aprow, apidx, d_ptr, d_idx, pptr, pidx, nullptr, aplptr, aplpair);
+          PF_HIP(hipGetLastError());
+          Lv.aplptr = aplptr; Lv.aplpair = aplpair;
+        } else {
+          (void)hipGetLastError();
+          (void)hipFree(aplptr);
+        }
+      }
       // gather plan of P^T (A P) over the coarse graph just built (count, scan, fill)
       int32_t *gcnt = nullptr, *gptr = nullptr;
       int2* gpair = nullptr;
@@ -1498,7 +1604,7 @@ void pf_amg_free(pf_ctx* ctx) {
     if (Lv.owns_xy) pf_free(Lv.xy);
     pf_free(Lv.dinv); pf_free(Lv.dinv2); pf_free(Lv.iso); pf_free(Lv.agg); pf_free(Lv.aptr); pf_free(Lv.amem);
     pf_free(Lv.pptr); pf_free(Lv.pidx); pf_free(Lv.pvals); pf_free(Lv.tptr); pf_free(Lv.tnode); pf_free(Lv.tslot);
-    pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32); pf_free(Lv.apptr); pf_free(Lv.apidx); pf_free(Lv.aprow); pf_free(Lv.apvals); pf_free(Lv.gptr); pf_free(Lv.gpair);
+    pf_free(Lv.ptvals); pf_free(Lv.pvals32); pf_free(Lv.ptvals32); pf_free(Lv.apptr); pf_free(Lv.apidx); pf_free(Lv.aprow); pf_free(Lv.apvals); pf_free(Lv.gptr); pf_free(Lv.gpair); pf_free(Lv.aplptr); pf_free(Lv.aplpair);
     pf_free(Lv.x); pf_free(Lv.b); pf_free(Lv.t);
   }
   if (H->side) {
@@ -1835,6 +1941,10 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
         do {                                                                                                     \
           const int gw_ = std::max(4, std::min(32, Lv.max_row));                                                 \
           if (Lv.gpair && Lv.apvals && H->two_step) { /* A P first, then P^T (A P) through the gather plan: no atomics */ \
+            if (Lv.aplpair)                                                                                       \
+              k_sa_ap_planned<DR_, DC_><<<(unsigned)cdiv(Lv.nap, 256), 256, 0, ctx->stream>>>(Lv.nap, Lv.aplptr, Lv.aplpair, Lv.vals, \
+                                                                                              Lv.pvals, Lv.apvals); \
+            else                                                                                                  \
             k_sa_ap<DR_, DC_><<<(unsigned)cdiv(Lv.nap, 256), 256, 0, ctx->stream>>>(Lv.nap, Lv.aprow, Lv.apidx, Lv.ptr, Lv.idx, \
                                                                                     Lv.vals, Lv.pptr, Lv.pidx, Lv.pvals, Lv.apvals); \
             k_sa_ptap<DR_, DC_><<<(unsigned)cdiv(Nx.nblk, 256), 256, 0, ctx->stream>>>(Nx.nblk, Lv.gptr, Lv.gpair, Lv.pvals, \
