@@ -539,6 +539,9 @@ __global__ void k_amg_prolong(int64_t n, const int32_t* __restrict__ agg, const 
 // ---- smoothed aggregation: stored prolongator ------------------------------------------------------------
 // P = (I - w D^-1 A) P_tent, w = 4 / (3 * 1.1 * lambda_max(D^-1 A)); one lane per fine node owns its row of P.
 // diag holds the raw diagonal, lam2 the squared estimate of lambda_max from the power iteration.
+#ifndef PF_AB_SMOOTHP_UNROLL
+#define PF_AB_SMOOTHP_UNROLL 3
+#endif
 template <int DIM, int DR, int DC>
 __global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
                               const double* __restrict__ vals, const int32_t* __restrict__ agg,
@@ -578,28 +581,45 @@ __global__ void k_sa_smooth_P(int64_t n, const int32_t* __restrict__ ptr, const 
             for (int c = 0; c < DC; ++c) acc[k][r * DC + c] = Pn[r][c];
         }
     }
-    for (int32_t g = ptr[i]; g < ptr[i + 1]; ++g) {
-      const int64_t m = idx[g];
-      const int32_t J = agg[m];
-      double Pm[DR][DC];
-      amg_P<DIM, DR, DC>(xy + DIM * m, cxy + DIM * (int64_t)J, iso + DR * m, Pm);
-      const double* a = vals + (int64_t)g * DR * DR;
-      double d[DR * DC];
+    // the neighbours three at a time -- ids first, then their aggregates, then blocks and coordinates together: a row's
+    // nine neighbours are nine chains of four dependent loads otherwise, and the kernel waits for them
+    constexpr int UN = PF_AB_SMOOTHP_UNROLL;
+    const int32_t ge = ptr[i + 1];
+    for (int32_t g0 = ptr[i]; g0 < ge; g0 += UN) {
+      int32_t gg[UN], JJ[UN];
+      int64_t mm[UN];
 #pragma unroll
-      for (int r = 0; r < DR; ++r)
+      for (int u = 0; u < UN; ++u) { gg[u] = min(g0 + u, ge - 1); mm[u] = idx[gg[u]]; }
 #pragma unroll
-        for (int c = 0; c < DC; ++c) {
-          double t2 = 0.0;
+      for (int u = 0; u < UN; ++u) JJ[u] = agg[mm[u]];
+      double Pm[UN][DR][DC], a[UN][DR * DR];
 #pragma unroll
-          for (int t = 0; t < DR; ++t) t2 += a[r * DR + t] * Pm[t][c];
-          d[r * DC + c] = wr[r] * t2;
-        }
+      for (int u = 0; u < UN; ++u) {
+        amg_P<DIM, DR, DC>(xy + DIM * mm[u], cxy + DIM * (int64_t)JJ[u], iso + DR * mm[u], Pm[u]);
+        const double* ap = vals + (int64_t)gg[u] * DR * DR;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (col[k] == J) {
+        for (int q = 0; q < DR * DR; ++q) a[u][q] = ap[q];
+      }
 #pragma unroll
-          for (int q = 0; q < DR * DC; ++q) acc[k][q] -= d[q];
-        }
+      for (int u = 0; u < UN; ++u) {
+        if (g0 + u >= ge) continue;
+        double d[DR * DC];
+#pragma unroll
+        for (int r = 0; r < DR; ++r)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) {
+            double t2 = 0.0;
+#pragma unroll
+            for (int t = 0; t < DR; ++t) t2 += a[u][r * DR + t] * Pm[u][t][c];
+            d[r * DC + c] = wr[r] * t2;
+          }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (col[k] == JJ[u]) {
+#pragma unroll
+            for (int q = 0; q < DR * DC; ++q) acc[k][q] -= d[q];
+          }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -1301,6 +1321,9 @@ __global__ __launch_bounds__(256) void k_sa_applan(int64_t nap, const int32_t* _
   if (count) count[q] = cnt;
 }
 
+#ifndef PF_AB_AP_U
+#define PF_AB_AP_U 5
+#endif
 template <int DR, int DC>
 __global__ __launch_bounds__(256) void k_sa_ap_planned(int64_t nap, const int32_t* __restrict__ aplptr, const int2* __restrict__ aplpair,
                                                       const double* __restrict__ vals, const double* __restrict__ pvals,
@@ -1313,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_sa_ap_planned(int64_t nap, const int32_
   for (int r = 0; r < DR; ++r)
 #pragma unroll
     for (int c = 0; c < DC; ++c) acc[r][c] = 0.0;
-  constexpr int U = (DR * DC <= 9) ? 3 : 1;  // pairs in flight
+  constexpr int U = (DR * DC <= 9) ? PF_AB_AP_U : 1;  // pairs in flight
   for (int32_t k0 = kb; k0 < ke; k0 += U) {
     int2 pr[U];
     double a[U][DR * DR], Pm[U][DR * DC];
@@ -1388,7 +1411,7 @@ __global__ __launch_bounds__(64) void k_sa_gplan(int64_t nc, const int32_t* __re
 }
 
 #ifndef PF_AB_PTAP_U
-#define PF_AB_PTAP_U 2
+#define PF_AB_PTAP_U 4
 #endif
 template <int DR, int DC>
 __global__ __launch_bounds__(256) void k_sa_ptap(int64_t nq, const int32_t* __restrict__ gptr, const int2* __restrict__ gpair,
