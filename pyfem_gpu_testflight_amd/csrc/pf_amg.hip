@@ -1101,24 +1101,35 @@ __global__ __launch_bounds__(1024) void k_amg_dense_invert(double* __restrict__ 
 }
 
 // x = Ainv b; Ainv is symmetric, so lane i walks column i (= row i) with coalesced reads
+// 4 x 192 threads: thread (part, i) sums the rows j = part (mod 4) of column i, the four partial sums meet in LDS -- a
+// single thread per entry walked all m rows in one dependent chain (13.8 us for 114 dofs, three launch floors)
 template <int NV = 1>
-__global__ void k_amg_dense_apply(int m, const double* __restrict__ Ainv, const double* __restrict__ b,
-                                  double* __restrict__ x) {
+__global__ __launch_bounds__(768) void k_amg_dense_apply(int m, const double* __restrict__ Ainv, const double* __restrict__ b,
+                                                         double* __restrict__ x) {
   __shared__ double sb[AMG_COARSEST_DOFS * NV];
+  __shared__ double ps[4][192 * NV];
+  static_assert(AMG_COARSEST_DOFS <= 192, "k_amg_dense_apply: 192 columns per part");
   for (int j = threadIdx.x; j < m * NV; j += blockDim.x) sb[j] = b[j];
   __syncthreads();
-  const int i = threadIdx.x;
-  if (i >= m) return;
+  const int i = threadIdx.x % 192, part = threadIdx.x / 192;
   double s[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) s[v] = 0.0;
-  for (int j = 0; j < m; ++j) {
-    const double a = Ainv[j * m + i];
+  if (i < m) {
+#pragma unroll 4
+    for (int j = part; j < m; j += 4) {
+      const double a = Ainv[j * m + i];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) s[v] += a * sb[j * NV + v];
+      for (int v = 0; v < NV; ++v) s[v] += a * sb[j * NV + v];
+    }
   }
 #pragma unroll
-  for (int v = 0; v < NV; ++v) x[i * NV + v] = s[v];
+  for (int v = 0; v < NV; ++v) ps[part][i * NV + v] = s[v];
+  __syncthreads();
+  if (part == 0 && i < m) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x[i * NV + v] = (ps[0][i * NV + v] + ps[1][i * NV + v]) + (ps[2][i * NV + v] + ps[3][i * NV + v]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2157,8 +2168,8 @@ static int amg_cycle(pf_ctx* ctx, const double* r, double* z, int l0, double* rz
         PF_HIP(hipStreamWaitEvent(st, H->ev_inv, 0));
         H->inv_pending = false;
       }
-      if (nv == 2) k_amg_dense_apply<2><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
-      else k_amg_dense_apply<1><<<1, 192, 0, st>>>((int)ndof, H->dense_inv, b, x);
+      if (nv == 2) k_amg_dense_apply<2><<<1, 768, 0, st>>>((int)ndof, H->dense_inv, b, x);
+      else k_amg_dense_apply<1><<<1, 768, 0, st>>>((int)ndof, H->dense_inv, b, x);
     } else {  // could not coarsen down to the dense size (or a one-level hierarchy): Jacobi sweeps
       double* c = x;
       double* o = C.t;
