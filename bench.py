@@ -262,6 +262,7 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
         c = pyfem.ProblemCreator(2049, 2049)
         conn, X, x = c.create_helmhotz_problem()
         m = pyfem.Helmholtz(0.05, X, conn, qq, bq)
+        m.reuse_forward = False  # the timed apply() below is a SOLVE, not the kept result of the warm-up call on the same tensor
         h = m.hctx
         Kv, Rv = h.assemble_helmholtz(0.05)
         ms_asm2 = timer(lambda: h._call("pf_assemble_helmholtz2d", 0.05, pyfem_ptr(Kv), pyfem_ptr(Rv)), 100)

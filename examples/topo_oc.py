@@ -27,7 +27,7 @@ from pyfem_gpu_testflight_amd import pyfem  # noqa: E402
 class TopoProblem:
     """Same evaluation callbacks as the reference's ParOpt problem (topo.py:15-76).  The design, the filtered density, the
     displacements and the gradients stay in HBM between the callbacks (device tensors in, device tensors out): the second
-    filtr.apply(x) of an iteration returns the kept result, the two gradient filters run concurrently
+    filtr.apply(x) of an iteration returns the kept result, the two gradient filters are one two-vector solve
     (Helmholtz.apply_gradient_pair), compliance() builds its right-hand side on the device."""
 
     def __init__(self, model, filtr, fixed_volume, rho_min=1e-3):

@@ -5,7 +5,7 @@ from pyfem_gpu_testflight_amd import pyfem, _lib
 qq = pyfem.QuadratureBilinear2D(); bq = pyfem.BasisBilinear2D(qq)
 c = pyfem.ProblemCreator(2049, 1025)
 conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
-filtr = pyfem.Helmholtz(0.05, X, conn, qq, bq); filtr.rtol = 1e-8
+filtr = pyfem.Helmholtz(0.05, X, conn, qq, bq); filtr.rtol = 1e-8; filtr.reuse_forward = False  # every timed apply() is a solve
 model = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, qq, bq, p=5.0)
 h = model.hctx
 xk = h.to_device(np.random.default_rng(0).uniform(1e-3, 1, X.shape[0]), torch.float64)

@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "3d":  # 96^3 blocks, three AMG-PCG solv
 c = pyfem.ProblemCreator(2049, 1025)
 conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
 q = pyfem.QuadratureBilinear2D(); b = pyfem.BasisBilinear2D(q)
-f = pyfem.Helmholtz(0.05, X, conn, q, b); f.rtol = 1e-8
+f = pyfem.Helmholtz(0.05, X, conn, q, b); f.rtol = 1e-8; f.reuse_forward = False  # every timed apply() is a solve
 m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=5.0)
 h = m.hctx
 x = h.to_device(np.random.default_rng(0).uniform(1e-3, 1, X.shape[0]), torch.float64)

@@ -12,7 +12,7 @@ m = pyfem.LinearElasticity(X, conn, df, None, f, qq, bq); K = m.compute_jacobian
 x = torch.rand(h.nrows, dtype=torch.float64, device="cuda"); y = torch.empty_like(x)
 rhs = h.to_device(m.compute_rhs(), torch.float64); Kbc, b = m.apply_dirichlet_bcs(K, rhs, True)
 c3 = pyfem.ProblemCreator(2049, 2049); conn3, X3, x3 = c3.create_helmhotz_problem()
-mh = pyfem.Helmholtz(0.05, X3, conn3, qq, bq); hh = mh.hctx
+mh = pyfem.Helmholtz(0.05, X3, conn3, qq, bq); hh = mh.hctx; mh.reuse_forward = False  # every timed apply() is a solve
 xh = torch.rand(hh.nrows, dtype=torch.float64, device="cuda"); yh = torch.empty_like(xh)
 h.time_kernel(_lib.PF_K_SPMV, 300, in0=K.vals, in1=x, out0=y)  # steady clocks first (~100 launches after idle)
 for rep in range(3):
