@@ -226,6 +226,15 @@ def test_c3_helmholtz_apply_against_sparse_lu_and_full_size_properties(pf, orc):
     assert relmax(rho, rho_lu) < U_TOL
     g = np.cos(7 * X[:, 0]) + X[:, 1]
     assert relmax(filtr.apply_gradient(g), Ro.T @ lu(g)) < U_TOL
+    # the two gradient filters of a topology iteration as ONE two-vector solve (pf_cg2; topo.py:73-74): each column against
+    # the factorisation, iteration counts those of the single solves
+    hq = filtr.hctx
+    g2 = np.full(X.shape[0], 1.0 / X.shape[0])  # the volume gradient: constant
+    filtr.apply_gradient(hq.to_device(g, hq.torch.float64)); it_a = filtr.last_iters
+    filtr.apply_gradient(hq.to_device(g2, hq.torch.float64)); it_b = filtr.last_iters
+    p1, p2 = filtr.apply_gradient_pair(hq.to_device(g, hq.torch.float64), hq.to_device(g2, hq.torch.float64))
+    assert filtr.last_pair_iters == (it_a, it_b)
+    assert relmax(p1.cpu().numpy(), Ro.T @ lu(g)) < U_TOL and relmax(p2.cpu().numpy(), Ro.T @ lu(g2)) < U_TOL
     del filtr, Ko, Ro, rho_lu, lu
 
     n = 2048
@@ -241,6 +250,12 @@ def test_c3_helmholtz_apply_against_sparse_lu_and_full_size_properties(pf, orc):
     assert relmax(out, gR) < U_TOL
     h = filtr.hctx
     torch = h.torch
+    # the same manufactured vector next to a second one (K (1 - rho*) -> R (1 - rho*)) through the two-vector solve
+    ones = np.ones(X.shape[0])
+    gK1 = np.bincount(conn.ravel(), weights=np.einsum("eij,ej->ei", Ke, (ones - rstar)[conn]).ravel(), minlength=X.shape[0])
+    gR1 = np.bincount(conn.ravel(), weights=np.einsum("eij,ej->ei", Re, (ones - rstar)[conn]).ravel(), minlength=X.shape[0])
+    o1, o2 = filtr.apply_gradient_pair(h.to_device(gK, torch.float64), h.to_device(gK1, torch.float64))
+    assert relmax(o1.cpu().numpy(), gR) < U_TOL and relmax(o2.cpu().numpy(), gR1) < U_TOL
     xd = h.to_device(orc.helmholtz_input(n + 1, n + 1), torch.float64)
     rho = filtr.apply(xd)
     Rx = h.spmv(filtr.R.vals, xd)
