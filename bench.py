@@ -352,7 +352,7 @@ def secondary_legs(torch, pyfem, _lib, timer, ceil, model4m, K4m, which):
             t.append(time.perf_counter())
             rho2 = filtr.apply(xk).clamp(1e-3, 1.0)
             reused = filtr.last_reused
-            g, a = filtr.apply_gradient_pair(model.compliance_grad(rho2, u), model.volume_grad(rho2))  # topo.py:73-74, concurrently
+            g, a = filtr.apply_gradient_pair(model.compliance_grad(rho2, u), model.volume_grad(rho2))  # topo.py:73-74, one two-vector AMG-PCG (pf_cg2)
             a = -a
             it_g = filtr.last_iters
             torch.cuda.synchronize()

@@ -1034,6 +1034,11 @@ static inline ElasticityParams make_elasticity(double E, double nu, double p, co
 // copy-out variant for `per_lane` 16-byte pieces per lane: a static store count (3, 5, 10) or the counted loop (0)
 template <int P, class Phys, bool RHO, int REC>
 static auto v4_variant(int per_lane, int& nout) -> decltype(&k_assemble_v4<P, Phys, RHO, 0, REC>) {
+  // quads with a density field: the counted loop.  The static store count costs that kernel six registers (134 against
+  // 128: 12 against 16 resident waves per CU); with the loop it runs 0.302 -> 0.296 ms on 4 M quads (r03, tools/asm_sweep.py).
+  // The sixteen waves are NOT the 0.64 of peak VERDICT r2 hoped for: the kernel's extra 50 us over the plain one are the
+  // density gathers and the fp64 divisions of RAMP at every quadrature point, not occupancy.
+  if (RHO && P == 4) { nout = per_lane; return k_assemble_v4<P, Phys, RHO, 0, REC>; }
   if (per_lane <= 3) { nout = 3; return k_assemble_v4<P, Phys, RHO, 3, REC>; }
   if (per_lane <= 5) { nout = 5; return k_assemble_v4<P, Phys, RHO, 5, REC>; }
   if (per_lane <= 10) { nout = 10; return k_assemble_v4<P, Phys, RHO, 10, REC>; }
