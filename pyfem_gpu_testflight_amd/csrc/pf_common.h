@@ -294,6 +294,10 @@ int pf_launch_spmv(pf_ctx* ctx, const double* vals, const double* x, double* y, 
                    const pf_spmv_send* snd = nullptr, const int32_t* snd_tperm = nullptr,   // fused exchange (pf_halo.hip)
                    int nv = 1,   // 2: x, y, sm_b hold TWO vectors interleaved per node (scalar matrices; dot_part: 2 per wave)
                    const double* pw_diag = nullptr);  // y = (A x) ./ pw_diag, dot_part <- partials of |y|^2 (power-iteration step)
+// read-back without a device stall (pf_solve.hip): pieces into the context's pinned buffer, an event behind them, awaited later
+int pf_pin_copy(pf_ctx* ctx, size_t double_offset, const void* dev, size_t bytes);
+int pf_pin_mark(pf_ctx* ctx);
+int pf_pin_wait(pf_ctx* ctx);
 int pf_spmv_waves(pf_ctx* ctx);  // waves (= dot partials) of one pf_launch_spmv launch on this pattern
 int pf_halo_recv_apply(pf_halo* h, int plan, const double* x, const double* d, const double* b, double* y);
 // the two launches of a distributed CG iteration and their helpers (pf_solve.hip; used by pf_dist.hip as well)

@@ -101,32 +101,62 @@ extern "C" int pf_dist_pcg_amg(const pf_dist_amg* a, const double* b, double* x,
   double *state = stA, *state_next = stB;
   // partials of own r.r for the first reduction (zeroed state: x, r unchanged; the z it writes is overwritten by the cycle)
   if ((rc = pf_dist_init_partials(ctx, state, p, s, nullptr, a->own_w, x, r, z))) return rc;
-  bool stopped = false;
-  while (it < maxiter && !stopped) {
-    const int burst = std::min(check_every - it % check_every, maxiter - it);
-    for (int k = 0; k < burst; ++k, ++it) {
-      if ((rc = dist_vcycle(a, r, z, c, c2, t, b1, x1))) return rc;                              // z = M^-1 r
-      if ((rc = pf_dist_dot_gamma(ctx, r, z, a->own_w))) return rc;                              // partials of own r.z
-      if ((rc = pf_dist_product(ctx, a->halo, a->plan_dof, a->K, nullptr, z, w, true, nullptr, nullptr, redg + 3))) return rc;
-      if ((rc = pf_dist_update(ctx, a->halo, a->plan_dof, w, nullptr, true, true, it == 0, x, r, z, p, s, state, state_next, redg,
-                               it == 0, tol * tol, it)))
-        return rc;
-      std::swap(state, state_next);
-    }
-    PF_HIP(hipMemcpyAsync(h, redg, sizeof(double) * 5, hipMemcpyDeviceToHost, st));
-    int32_t herr1 = 0;
-    PF_HIP(hipMemcpyAsync(&herr, pf_halo_err_ptr(a->halo), sizeof(herr), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(&herr1, pf_halo_err_ptr(a->halo_coarse), sizeof(herr1), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));  // one synchronisation per read-back
-    if (herr) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the fused exchange (timeout)");
-    if (herr1) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the level-1 exchange (timeout)");
-    rnorm = sqrt(h[2]);
-    if (h[3] != 0.0) {  // converged on the device after h[4] updates
-      it = (int)h[4];
+  // Convergence is tested on the device by every update (redg[3]); the host looks at it once per iteration WITHOUT stalling
+  // the device: the copy to pinned memory is queued right behind the update, the next iteration's V-cycle behind that, and
+  // only then does the host wait for the copy.  When the residual's recent rate says that this update probably ends the
+  // solve, the host waits BEFORE queuing the next cycle instead, so that no cycle is wasted (as in pf_cg).  check_every is
+  // accepted for compatibility; the result never depended on it.
+  (void)check_every;
+  bool stopped = false, pending = false, failed = false;
+  double rnorm_prev = INFINITY;
+  int herr_state = 0;
+  auto queue_look = [&]() -> int {
+    if (int e = pf_pin_copy(ctx, 0, redg, sizeof(double) * 5)) return e;
+    if (int e = pf_pin_copy(ctx, 8, pf_halo_err_ptr(a->halo), sizeof(int32_t))) return e;
+    if (int e = pf_pin_copy(ctx, 9, pf_halo_err_ptr(a->halo_coarse), sizeof(int32_t))) return e;
+    return pf_pin_mark(ctx);
+  };
+  auto look = [&]() -> int {
+    if (int e = pf_pin_wait(ctx)) return e;
+    int32_t e0, e1;
+    memcpy(&e0, ctx->pin + 8, sizeof(e0));
+    memcpy(&e1, ctx->pin + 9, sizeof(e1));
+    if (e0) { herr_state = 1; failed = true; return PF_OK; }
+    if (e1) { herr_state = 2; failed = true; return PF_OK; }
+    rnorm_prev = rnorm;
+    rnorm = sqrt(ctx->pin[2]);
+    if (ctx->pin[3] != 0.0) {  // converged on the device after pin[4] updates
+      it = (int)ctx->pin[4];
       stopped = true;
     }
-    if (!(rnorm == rnorm)) break;
+    if (!(rnorm == rnorm)) failed = true;
+    return PF_OK;
+  };
+  while (it < maxiter && !stopped && !failed) {
+    if ((rc = dist_vcycle(a, r, z, c, c2, t, b1, x1))) return rc;                              // z = M^-1 r
+    if (pending) {  // the previous update's verdict, with this iteration's cycle already queued behind it
+      pending = false;
+      if ((rc = look())) return rc;
+      if (stopped || failed) break;  // (the queued cycle is wasted; its update is not queued, x is the converged iterate)
+    }
+    if ((rc = pf_dist_dot_gamma(ctx, r, z, a->own_w))) return rc;                              // partials of own r.z
+    if ((rc = pf_dist_product(ctx, a->halo, a->plan_dof, a->K, nullptr, z, w, true, nullptr, nullptr, redg + 3))) return rc;
+    if ((rc = pf_dist_update(ctx, a->halo, a->plan_dof, w, nullptr, true, true, it == 0, x, r, z, p, s, state, state_next, redg,
+                             it == 0, tol * tol, it)))
+      return rc;
+    std::swap(state, state_next);
+    ++it;
+    if ((rc = queue_look())) return rc;
+    const bool early = rnorm * std::min(1.0, rnorm / rnorm_prev) <= 4.0 * tol || it >= maxiter;
+    if (early) {
+      if ((rc = look())) return rc;
+    } else {
+      pending = true;
+    }
   }
+  if (pending && (rc = look())) return rc;
+  if (herr_state == 1) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the fused exchange (timeout)");
+  if (herr_state == 2) return pf_fail(ctx, PF_E_HIP, "pf_dist_pcg_amg: a peer did not arrive at the level-1 exchange (timeout)");
   if (iters_host) *iters_host = it;
   if (relres_host) *relres_host = bnorm > 0 ? rnorm / bnorm : rnorm;
   if (!(rnorm <= tol)) return pf_fail(ctx, PF_E_NOCONV, "cg failed with code " + std::to_string(it));  // pyfem.py:2421-2422

@@ -1339,19 +1339,27 @@ static double host_sum(const double* v, int n) {
 // device is still busy, and the next iteration's first launch is in its queue before it runs dry.  (r02 / early r03: copy
 // to pageable memory and a stream synchronise at the end of every iteration -- a 42 us hole per AMG-PCG iteration in the
 // kernel trace, 2 ms of a 40 ms topology iteration.)
-static int readback_queue(pf_ctx* ctx, const double* dev, size_t count) {
+int pf_pin_copy(pf_ctx* ctx, size_t double_offset, const void* dev, size_t bytes) {  // one piece into ctx->pin (2 * PF_NPART doubles)
   if (!ctx->pin) {
     PF_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->pin), sizeof(double) * 2 * NPART, hipHostMallocDefault));
     PF_HIP(hipEventCreateWithFlags(&ctx->pin_ev, hipEventDisableTiming));
   }
-  PF_HIP(hipMemcpyAsync(ctx->pin, dev, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+  PF_HIP(hipMemcpyAsync(ctx->pin + double_offset, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return PF_OK;
+}
+int pf_pin_mark(pf_ctx* ctx) {
   PF_HIP(hipEventRecord(ctx->pin_ev, ctx->stream));
   return PF_OK;
 }
-static int readback_wait(pf_ctx* ctx) {
+int pf_pin_wait(pf_ctx* ctx) {
   PF_HIP(hipEventSynchronize(ctx->pin_ev));
   return PF_OK;
 }
+static int readback_queue(pf_ctx* ctx, const double* dev, size_t count) {
+  if (int rc = pf_pin_copy(ctx, 0, dev, sizeof(double) * count)) return rc;
+  return pf_pin_mark(ctx);
+}
+static int readback_wait(pf_ctx* ctx) { return pf_pin_wait(ctx); }
 
 // The product's output vector of the PCG loops, owned by the context.  Round 2 "placed it by measurement" (three candidate
 // allocations, the fastest of a few launches each kept), on the belief that the product runs at two speeds depending on

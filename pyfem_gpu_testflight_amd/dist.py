@@ -1107,7 +1107,7 @@ class PartitionedElasticity:
         "amg" (the same hierarchy pf_cg uses on one GPU, replicated, with a distributed finest level: single-GPU
         iteration counts)."""
         K = self.compute_jacobian(rho)
-        rhs = self.ops.from_numpy(self.model.compute_rhs(), self.ops.torch.float64)
+        rhs = self.model.compute_rhs_device()  # built in HBM (a clone of the kept load vector): no upload per solve
         K, b = self.apply_dirichlet_bcs(K, rhs)
         if precond == "amg":
             hier = self._hierarchy_for(self._global_rho(rho))
