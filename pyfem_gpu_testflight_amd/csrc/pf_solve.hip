@@ -247,6 +247,9 @@ __global__ __launch_bounds__(64) void k_spmv(int64_t nnodes, const int32_t* __re
             m[u] = (int32_t)(tile * TILE) + reinterpret_cast<const int16_t*>(nidx)[g[u]];
           else
             m[u] = nidx[g[u]];
+#ifdef PF_ABLATE_GATHER  // timing experiment (wrong results): every lane gathers its own tile's node `lane` -- coalesced, index stream still read
+          m[u] = (int32_t)min((int64_t)nnodes - 1, tile * TILE + lane + (m[u] & 0));
+#endif
         }
         if constexpr (D == 1) {
           double kv[U], xv[U];
