@@ -20,3 +20,21 @@ for etype, n in (("quad", 2049), ("tri", 1416), ("tri", 0)):
         m.compute_jacobian(out=K)
     torch.cuda.synchronize()
     print(etype, m.hctx.nelems, flush=True)
+# round 3: the two kernels VERDICT r2 asked to re-record -- quads with a nodal density field (RAMP) and Helmholtz K + R
+import ctypes as C
+c = pyfem.ProblemCreator(2049, 2049); conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+q = pyfem.QuadratureBilinear2D(); b = pyfem.BasisBilinear2D(q)
+m = pyfem.LinearElasticity(X, conn, dof_fixed, None, force, q, b, p=5.0)
+rho = torch.rand(m.hctx.nnodes, dtype=torch.float64, device="cuda") * 0.7 + 0.3
+K = m.compute_jacobian(rho)
+for _ in range(10):
+    m.compute_jacobian(rho, out=K)
+torch.cuda.synchronize()
+print("quad rho", m.hctx.nelems, flush=True)
+c = pyfem.ProblemCreator(2049, 2049); conn, X, x0 = c.create_helmhotz_problem()
+mh = pyfem.Helmholtz(0.05, X, conn, q, b)
+Kv, Rv = mh.hctx.assemble_helmholtz(0.05)
+for _ in range(10):
+    mh.hctx._call("pf_assemble_helmholtz2d", 0.05, C.c_void_p(Kv.data_ptr()), C.c_void_p(Rv.data_ptr()))
+torch.cuda.synchronize()
+print("helmholtz K+R", mh.hctx.nelems, flush=True)

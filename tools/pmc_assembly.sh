@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: the assembly kernels (quads 2048^2, 1415^2 split triangles, arm5) under separate counter
 # passes; tools/pmc_assembly_summary.py prints per-kernel averages.   gpurun -- 'bash tools/pmc_assembly.sh r02'
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_asm_$TAG
 mkdir -p $OUT
