@@ -115,7 +115,9 @@ def _worker(rank, world, port, etype, transport):
         u = pm.gather_global(x).cpu().numpy()
         err = np.abs(u - u_ref).max() / np.abs(u_ref).max()
         assert err < 1e-8, err
-        assert pm.last_iters <= 1.3 * it_single + 1, (pm.last_iters, it_single)
+        # same operator as the single-GPU cycle since round 3 (fp32 copies of K and P on both paths): the same count, give
+        # or take the one iteration the two recurrences' rounding may differ by (measured: equal in every case here)
+        assert abs(pm.last_iters - it_single) <= 1, (pm.last_iters, it_single)
         assert pm.last_iters * 3 < it_jacobi
         if transport == "peer":  # that was pf_dist_pcg_amg (all in C); the Python-driven loop must agree with it
             from pyfem_gpu_testflight_amd.dist import dist_pcg_amg
@@ -134,7 +136,7 @@ def _worker(rank, world, port, etype, transport):
         u = pc.gather_global(x).cpu().numpy()
         assert np.abs(u - u_ref).max() / np.abs(u_ref).max() < 1e-8
         assert pc.iface.n <= pm.iface.n or etype == "quad"
-        assert pc.last_iters <= 1.3 * it_single + 1, (pc.last_iters, it_single)
+        assert abs(pc.last_iters - it_single) <= 1, (pc.last_iters, it_single)
     finally:
         dist.destroy_process_group()
 
@@ -263,7 +265,7 @@ def _worker_c5(rank, world, port):
             c_one, u_one = model.compliance(rho)
             assert abs(c_dist / c_one - 1) < 1e-8, (c_dist, c_one)
             assert np.abs(u - u_one).max() < 1e-8 * np.abs(u_one).max()
-            assert it_dist <= 1.3 * model.last_iters + 1, (it_dist, model.last_iters)
+            assert abs(it_dist - model.last_iters) <= 1, (it_dist, model.last_iters)
             g_one = model.compliance_grad(rho, u_one)
             assert np.abs(g - g_one).max() < 1e-7 * np.abs(g_one).max()
         dist.barrier()
@@ -324,7 +326,7 @@ def _worker_c4(rank, world, port):
             asm = pyfem.Assembler(model)
             u_one = asm.solve(method="cg")
             assert np.abs(u - u_one).max() < 1e-8 * np.abs(u_one).max()
-            assert it_dist <= 1.3 * asm.last_iters + 1, (it_dist, asm.last_iters)
+            assert abs(it_dist - asm.last_iters) <= 1, (it_dist, asm.last_iters)
             f = model.compute_rhs()
             assert f @ u < 0  # negative definite K: the reference keeps the sign of detJ
         dist.barrier()
