@@ -1,6 +1,7 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: the assembly kernels (quads 2048^2, 1415^2 split triangles, arm5) under separate counter
-# passes; tools/pmc_assembly_summary.py prints per-kernel averages.   gpurun -- 'bash tools/pmc_assembly.sh r02'
+# Runs ON THE GPU BOX: the assembly kernels (quads 2048^2, 1415^2 split triangles, arm5; round 3: quads with a density field,
+# Helmholtz K + R) under separate counter passes; tools/pmc_assembly_summary.py prints per-kernel averages.
+#   gpurun -- 'bash tools/pmc_assembly.sh r03'
 set -o pipefail
 TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""A/B of the V-cycle tail kernel (k_amg_tail; NOT KEPT: see profiles/r03_vcycle_tail_ab.jsonl and the note in amg_cycle) on configuration 5's two systems: PF_AMG_TAIL=0/1 with the experiments
-library (PF_LIB_PATH=.../libpyfem_hip_exp.so).  Prints ms per Helmholtz filter solve and per elasticity AMG-PCG solve."""
+"""Filter solve and elasticity AMG-PCG solve of configuration 5 (2048 x 1024, random nodal design) for ONE library
+(PF_LIB_PATH selects it; experiment knobs through the environment): ms per Helmholtz apply and per solve incl. the numeric
+setup, iteration counts.  The A/B driver of round 3's solver changes (first use: the V-cycle tail kernel that was NOT kept,
+profiles/r03_vcycle_tail_ab.jsonl -- hence the PF_AMG_TAIL field of the output line)."""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
