@@ -130,11 +130,15 @@ def main(argv=None):
     ap.add_argument("--p", type=float, default=5.0, help="RAMP penalty")
     ap.add_argument("--volume", type=float, default=0.4)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--amg-lag", type=int, default=0,
+                    help="keep the AMG numeric setup of the state solve for up to N further iterations (Assembler.amg_lag): "
+                         "pays once the design moves by well under a percent per step; 0 = a setup per matrix")
     args = ap.parse_args(argv)
 
     import torch
 
     prob = build(args)
+    prob.model.amg_lag = args.amg_lag
     x = torch.full((prob.model.nnodes,), args.volume, dtype=torch.float64, device=prob.model.hctx.device)
     history = []
     for it in range(args.iters):

@@ -49,7 +49,7 @@ enum {
 enum { PF_QUAD4 = 4, PF_TRI3 = 3, PF_BLOCK8 = 8 };  /* nodes per element selects the element */
 enum { PF_TAB_MAX_NODES = 32, PF_TAB_MAX_QUADS = 64 };  /* limits of the table-driven element */
 enum { PF_SCATTER_GATHER = 0, PF_SCATTER_ATOMIC = 1 };
-enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECOND_AMG_REUSE = 3 };
+enum { PF_PRECOND_NONE = 0, PF_PRECOND_JACOBI = 1, PF_PRECOND_AMG = 2, PF_PRECOND_AMG_REUSE = 3, PF_PRECOND_AMG_STALE = 4 };
 
 /* ---- context -------------------------------------------------------------------------- */
 int pf_ctx_create(int device, pf_ctx** out);
@@ -241,7 +241,13 @@ int pf_bicgstab(pf_ctx* ctx, const double* vals, const double* pvals, const doub
  * pyamg.ruge_stuben_solver (pyfem.py:2098).  Aggregates and coarse graphs are built once per pattern,
  * the coarse operators per call.  The matrix may be positive or negative definite (arm.inp: every detJ < 0); if the
  * coupled dofs carry diagonal entries of both signs pf_cg uses Jacobi instead.  pf_amg_info reports the hierarchy of the last AMG solve (HOST outputs,
- * arrays of length cap). */
+ * arrays of length cap).
+ * PF_PRECOND_AMG_REUSE keeps the numeric setup when it was made for exactly this `vals` buffer (the Helmholtz filter: one K,
+ * many solves).  PF_PRECOND_AMG_STALE keeps WHATEVER numeric setup the hierarchy holds, even one made for other values: the
+ * V-cycle of the previous matrix is still a fixed symmetric positive definite operator, so PCG converges to the same
+ * solution, in more iterations the further the matrix has moved -- for loops whose matrix changes slowly (late topology
+ * optimisation steps), where the setup is a quarter of the solve.  The caller decides when that stops paying
+ * (Assembler.amg_lag in the Python mirror); without an earlier setup it is PF_PRECOND_AMG. */
 int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);
 /* The same V-cycle as a stand-alone operator for drivers with their own Krylov loop (dist.py: one local AMG per
  * rank in an additive Schwarz preconditioner).  prepare: numeric setup for vals (reuse as in PF_PRECOND_AMG_REUSE;

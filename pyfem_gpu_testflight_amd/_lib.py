@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpyfem_hip.so
 
 PF_OK, PF_E_INVALID, PF_E_HIP, PF_E_UNSUPPORTED, PF_E_NOCONV = 0, -1, -2, -3, -4
 PF_SCATTER_GATHER, PF_SCATTER_ATOMIC = 0, 1
-PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE = 0, 1, 2, 3
+PF_PRECOND_NONE, PF_PRECOND_JACOBI, PF_PRECOND_AMG, PF_PRECOND_AMG_REUSE, PF_PRECOND_AMG_STALE = 0, 1, 2, 3, 4
 PF_K_ASSEMBLE_ELASTICITY, PF_K_SPMV, PF_K_ASSEMBLE_HELMHOLTZ = 0, 1, 2
 PF_HBM_FILL, PF_HBM_READ, PF_HBM_MIX = 0, 1, 2
 PF_TAB_ELASTICITY, PF_TAB_POISSON = 0, 1

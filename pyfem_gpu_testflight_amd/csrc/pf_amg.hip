@@ -1923,6 +1923,10 @@ int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   }
   pf_amg* H = ctx->amg;
   if (reuse && H->numeric_ok && H->L[0].vals == vals) return PF_OK;
+  // reuse == 2 (PF_PRECOND_AMG_STALE): the setup of an EARLIER matrix stays in use.  The cycle reads only what the hierarchy
+  // owns -- the fp32 copy of that matrix on the finest level, the coarse operators, the transfer operators, the damping
+  // factors -- never the caller's buffer, which may hold other values by now (or be gone).
+  if (reuse == 2 && H->numeric_ok && H->L[0].vals32) return PF_OK;
   H->numeric_ok = false;
   H->L[0].vals = const_cast<double*>(vals);
   if (const char* e = pf_exp_env("PF_AMG_NSMOOTH")) H->nsmooth = std::max(1, atoi(e));

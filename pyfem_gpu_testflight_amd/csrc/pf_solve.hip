@@ -1386,9 +1386,9 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
   PF_REQUIRE(ctx->d && vals && b && x, "pf_cg: no pattern / NULL argument");
   PF_REQUIRE(precond == PF_PRECOND_NONE || precond == PF_PRECOND_JACOBI || precond == PF_PRECOND_AMG ||
-                 precond == PF_PRECOND_AMG_REUSE,
+                 precond == PF_PRECOND_AMG_REUSE || precond == PF_PRECOND_AMG_STALE,
              "pf_cg: unknown preconditioner");
-  const int amg_reuse = precond == PF_PRECOND_AMG_REUSE;
+  const int amg_reuse = precond == PF_PRECOND_AMG_REUSE ? 1 : precond == PF_PRECOND_AMG_STALE ? 2 : 0;  // pf_amg_setup's `reuse`
   if (amg_reuse) precond = PF_PRECOND_AMG;
   PF_HIP(hipSetDevice(ctx->device));
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;

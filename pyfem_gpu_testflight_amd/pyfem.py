@@ -655,8 +655,11 @@ class LinearElasticity(ModelBase):
         if isinstance(rho, torch.Tensor):  # a device density (the optimisation loop keeps its fields in HBM): nothing
             rhs = self.compute_rhs_device()  # crosses PCIe -- (c, u) with u a device tensor
             K, rhs = self.apply_dirichlet_bcs(K, rhs, enforce_symmetric_K=True)
-            asm = getattr(self, "_asm", None) or Assembler(self)
+            asm = getattr(self, "_asm", None)
+            if asm is None:  # kept: the amg_lag bookkeeping lives in it (set model.amg_lag = N to opt in, see Assembler)
+                asm = self._asm = Assembler(self)
             asm.rtol = getattr(self, "rtol", asm.rtol)
+            asm.amg_lag = getattr(self, "amg_lag", asm.amg_lag)
             u = asm._solve_linear_system(K, rhs, solver)
             self.last_iters = asm.last_iters
             return float(rhs.dot(u)), u
@@ -886,6 +889,14 @@ class Assembler:
         self.last_iters = None
         self.last_relres = None  # relative residual of the last solve (method="direct": the TRUE ||b - K x|| / ||b||)
         self.direct_strict = False  # True: method="direct" raises above DIRECT_QUIET instead of warning up to DIRECT_ACCEPT
+        # amg_lag = N > 0 (opt-in; "cg" / "gmres" with the AMG preconditioner): the numeric setup of the hierarchy is kept
+        # for up to N further solves although the matrix has changed (PF_PRECOND_AMG_STALE) -- the V-cycle of an earlier
+        # matrix is still a valid preconditioner, PCG converges to the same solution -- and redone as soon as a solve
+        # needs 30 % more iterations than the one right after the last setup.  For loops whose matrix moves slowly (late
+        # topology-optimisation steps), where the setup is a quarter of the solve; 0 (default): a setup per matrix.
+        self.amg_lag = 0
+        self.amg_setups = 0  # numeric setups requested so far (amg_lag bookkeeping; tests read it)
+        self._lag = {}
 
     @time_this
     def solve(self, method="gmres"):
@@ -925,7 +936,18 @@ class Assembler:
             elif method == "direct":
                 x, it, rr = self._direct_by_refinement(K, b)
             else:
-                x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=_PRECOND[self.precond])
+                pc, lag = _PRECOND[self.precond], None
+                if pc == _lib.PF_PRECOND_AMG:
+                    lag = self._lag.get(id(hctx))
+                    if self.amg_lag > 0 and lag is not None and lag["age"] < self.amg_lag and not lag["refresh"]:
+                        pc = _lib.PF_PRECOND_AMG_STALE
+                x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=pc)
+                if pc == _lib.PF_PRECOND_AMG_STALE:
+                    lag["age"] += 1
+                    lag["refresh"] = it > 1.3 * lag["fresh_iters"] + 1
+                elif pc == _lib.PF_PRECOND_AMG:
+                    self.amg_setups += 1
+                    self._lag[id(hctx)] = {"fresh_iters": it, "age": 0, "refresh": False}
         except (_lib.PyfemHipError, DirectSolveError):
             raise  # a HIP / argument error is not a convergence failure, and method="direct"'s message is final
         except RuntimeError as e:  # PF_E_NOCONV: "<solver> failed with code <iters>" (pyfem.py:2421-2422)

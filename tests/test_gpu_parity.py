@@ -1504,3 +1504,46 @@ def test_device_side_topology_callbacks_match_the_host_path(pf):
     vg = model.volume_grad(rho_d)
     assert vg.is_cuda and np.array_equal(vg.cpu().numpy(), model.volume_grad(rho))
     assert abs(float(model.volume(rho_d)) - model.volume(rho)) < 1e-15
+
+
+def test_amg_lag_keeps_the_setup_while_the_matrix_moves_slowly(pf):
+    """Assembler.amg_lag (opt-in, PF_PRECOND_AMG_STALE): the hierarchy of an earlier matrix preconditions the next ones.
+    Same u as a solve with a fresh setup (both to rtol 1e-11 of the SAME system; the two run on models of their own,
+    because a hierarchy belongs to its context), fewer numeric setups while the density drifts, a fresh setup at least
+    every amg_lag + 1 solves and as soon as a solve needed 30 % more iterations than the one after the last setup."""
+    import torch
+
+    c = pf.ProblemCreator(193, 97)
+    conn, X, dof_fixed, force = c.create_linear_elasticity_problem()
+    q = pf.QuadratureBilinear2D()
+    models = [pf.LinearElasticity(X, conn, dof_fixed, None, force, q, pf.BasisBilinear2D(q), p=3.0) for _ in range(2)]
+    xn = (X - X.min(axis=0)) / (X.max(axis=0) - X.min(axis=0))
+    base = 0.5 + 0.4 * np.sin(5 * xn[:, 0]) * np.cos(3 * xn[:, 1])
+
+    def system(model, rho):
+        K = model.compute_jacobian(model.hctx.to_device(rho, torch.float64))
+        return model.apply_dirichlet_bcs(K, model.compute_rhs_device(), True)
+
+    lag, fresh = pf.Assembler(models[0]), pf.Assembler(models[1])
+    lag.amg_lag = 3
+    its_lag, its_fresh = [], []
+
+    def both(rho):
+        u1 = lag._solve_linear_system(*system(models[0], rho), "cg")
+        u2 = fresh._solve_linear_system(*system(models[1], rho), "cg")
+        its_lag.append(lag.last_iters)
+        its_fresh.append(fresh.last_iters)
+        assert float((u1 - u2).abs().max()) <= 1e-8 * float(u2.abs().max())
+
+    for k in range(7):  # a drifting design: 0.4 % per step
+        both(np.clip(base + 0.004 * k * np.cos(9 * xn[:, 0]), 1e-3, 1.0))
+    assert fresh.amg_setups == 7
+    assert lag.amg_setups == 2, (lag.amg_setups, its_lag, its_fresh)  # solves 0 and 4: every (amg_lag + 1)th
+    assert max(its_lag) <= 1.3 * max(its_fresh) + 1, (its_lag, its_fresh)
+    # a jump (another design altogether): the stale hierarchy still converges, to the same u, and is then replaced
+    rho = np.random.default_rng(3).uniform(1e-3, 1.0, X.shape[0])
+    n0 = lag.amg_setups
+    both(rho)
+    assert lag.amg_setups == n0 and its_lag[-1] > 1.3 * its_fresh[-1] + 1, (its_lag, its_fresh)
+    both(rho)  # flagged by the slow solve: a fresh setup now, and the fresh solve's count
+    assert lag.amg_setups == n0 + 1 and its_lag[-1] == its_fresh[-1], (its_lag, its_fresh)
