@@ -249,6 +249,12 @@ int pf_bicgstab(pf_ctx* ctx, const double* vals, const double* pvals, const doub
  * optimisation steps), where the setup is a quarter of the solve.  The caller decides when that stops paying
  * (Assembler.amg_lag in the Python mirror); without an earlier setup it is PF_PRECOND_AMG. */
 int pf_amg_info(pf_ctx* ctx, int32_t* nlevels, int64_t* nodes, int32_t* dofs_per_node, double* omega, int cap);
+/* Power-iteration steps of the hierarchy's lambda_max(D^-1 A) estimates (default 10, 2..200), from the next numeric setup on;
+ * builds the graph part of the hierarchy if it does not exist yet.  Too few steps under-estimate lambda_max beyond the 1.1
+ * margin and the smoother over-relaxes; pf_cg notices (an AMG-PCG solve still running after 150 iterations), sets the
+ * hierarchy up again with three times the steps -- kept from then on --, restarts from the iterate reached and reports it
+ * through pf_last_warning.  A tuning knob for meshes whose top eigenvector the ten steps do not reach. */
+int pf_amg_set_power_steps(pf_ctx* ctx, int steps);
 /* The same V-cycle as a stand-alone operator for drivers with their own Krylov loop (dist.py: one local AMG per
  * rank in an additive Schwarz preconditioner).  prepare: numeric setup for vals (reuse as in PF_PRECOND_AMG_REUSE;
  * PF_E_UNSUPPORTED if the diagonal signs are mixed).  vcycle: z = M^-1 r (device vectors of length nrows, z != r),

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pf_cg2": (C.c_int, [_vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
     "pf_amg_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_f64), C.c_int]),
     "pf_amg_prepare": (C.c_int, [_vp, _vp, C.c_int]),
+    "pf_amg_set_power_steps": (C.c_int, [_vp, C.c_int]),
     "pf_bicgstab": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f64, _f64, C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_f64)]),
     "pf_nlpoisson_tab": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "pf_amg_vcycle": (C.c_int, [_vp, _vp, _vp]),

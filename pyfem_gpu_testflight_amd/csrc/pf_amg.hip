@@ -1916,6 +1916,28 @@ static int amg_power_lambda(pf_ctx* ctx, pf_amg* H, AmgLevel& Lv, int level, dou
 // is accepted: every step of the cycle is linear in A, and PCG only sees r.z and p.Ap change sign together.
 // With reuse != 0 the numeric setup of the previous call is kept if it was made for the same value array (the caller asserts the values are
 // unchanged, e.g. the constant Helmholtz filter matrix).
+int pf_amg_more_power_steps(pf_ctx* ctx) {
+  if (!ctx->amg) return pf_fail(ctx, PF_E_INVALID, "pf_amg_more_power_steps: no hierarchy");
+  ctx->amg->pow_iters = std::min(3 * ctx->amg->pow_iters, 90);
+  ctx->amg->numeric_ok = false;
+  return PF_OK;
+}
+
+// HOST-settable number of power-iteration steps of the lambda_max(D^-1 A) estimates (default 10; see pf_cg's rescue):
+// takes effect at the next numeric setup of this context's hierarchy, which is built if it does not exist yet.
+extern "C" int pf_amg_set_power_steps(pf_ctx* ctx, int steps) {
+  if (!ctx) return pf_fail(nullptr, PF_E_INVALID, "ctx is NULL");
+  PF_REQUIRE(ctx->d && steps >= 2 && steps <= 200, "pf_amg_set_power_steps: no pattern, or steps outside 2..200");
+  PF_HIP(hipSetDevice(ctx->device));
+  if (!ctx->amg) {
+    const int rc = amg_build_hierarchy(ctx);
+    if (rc) { pf_amg_free(ctx); return rc; }
+  }
+  ctx->amg->pow_iters = steps;
+  ctx->amg->numeric_ok = false;
+  return PF_OK;
+}
+
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse) {
   if (!ctx->amg) {
     int rc = amg_build_hierarchy(ctx);

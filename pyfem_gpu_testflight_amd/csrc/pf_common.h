@@ -310,6 +310,7 @@ int pf_dist_dot_gamma(pf_ctx* ctx, const double* r, const double* z, const doubl
 int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, const double* s, const double* dinv,
                           const double* own_w, double* x, double* r, double* z);
 void pf_amg_free(pf_ctx* ctx);
+int pf_amg_more_power_steps(pf_ctx* ctx);  // three times the power-iteration steps from the next numeric setup on (pf_cg's rescue)
 int pf_amg_setup(pf_ctx* ctx, const double* vals, int reuse);   // PF_E_UNSUPPORTED: matrix not positive definite
 int pf_amg_apply(pf_ctx* ctx, const double* r, double* z, double* rz_part = nullptr, bool* rz_done = nullptr, int nv = 1);  // rz_part: partials of
                                                                     // r.z from the last sweep (one per product wave) when *rz_done

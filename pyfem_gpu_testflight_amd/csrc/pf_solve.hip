@@ -44,6 +44,7 @@ struct SpmvShape { static constexpr int d = D, tile = 64 * R; };
 static_assert(SpmvShape<PF_SPMV1>::tile == SPMV_TILE1 && SpmvShape<PF_SPMV1F>::tile == SPMV_TILE1, "d = 1 SpMV shapes must keep 128-node tiles");
 static_assert(SpmvShape<PF_SPMV2>::tile == SPMV_TILE2 && SpmvShape<PF_SPMV2F>::tile == SPMV_TILE2, "d = 2 SpMV shapes must keep 64-node tiles");
 static constexpr int SPMV_MAXGRID = 4096;
+static constexpr int PF_AMG_RESCUE_AT = 150;  // AMG-PCG iterations after which pf_cg re-estimates lambda_max once (see there)
 static constexpr int SPMV2_MAXGRID = 2048;  // k_spmv_nv2 leaves two partials per wave
 static_assert(2 * SPMV2_MAXGRID <= PF_NPART && 2 * 64 == PF_SPMV_TILE1, "k_spmv_nv2: partial capacity / tile of the 16-bit offsets");
 static constexpr int VEC_BLOCKS = 1024;  // persistent blocks of the vector kernels (256 threads)
@@ -1430,11 +1431,7 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
   } else {
     dinv = nullptr;
   }
-  int rc = pf_launch_spmv(ctx, vals, x, Ap, nullptr);  // Ap = A x0
-  if (rc) return rc;
-  k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
-  PF_LAUNCH_CHECK();
-  if ((rc = readback_queue(ctx, part(ctx, PA_RR), 2 * NPART))) return rc;  // RR | BB, awaited behind the first cycle
+  int rc;
   // AMG-PCG: the r.z partials come out of the cycle's last sweep (one per product wave: ns of them); k_dot only when the
   // hierarchy has a single level and the cycle ends without a product
   int nrz = (int)vg;
@@ -1445,18 +1442,45 @@ extern "C" int pf_cg(pf_ctx* ctx, const double* vals, const double* b, double* x
     else { k_dot<<<vg, 256, 0, st>>>(n, r, z, nullptr, rz_part); nrz = (int)vg; }
     return PF_OK;
   };
-  if (amg) {  // z = M^-1 r by one V-cycle, p = z, r.z
-    if ((rc = cycle(part(ctx, PA_RZ0)))) return rc;
-    PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+  double rnorm = 0.0, rnorm_prev = 0.0, bnorm = 0.0;
+  // (re)start from the iterate in x: r = b - A x, z = M^-1 r, p = z, the partials of r.z / b.b / r.r
+  auto start = [&]() -> int {
+    if (int e = pf_launch_spmv(ctx, vals, x, Ap, nullptr)) return e;  // Ap = A x
+    k_cg_init<<<vg, 256, 0, st>>>(n, b, Ap, dinv, r, z, p, part(ctx, PA_RZ0), part(ctx, PA_BB), part(ctx, PA_RR));
     PF_LAUNCH_CHECK();
-  }
-  if ((rc = readback_wait(ctx))) return rc;
-  const double bnorm = sqrt(host_sum(ctx->pin + NPART, (int)vg));
+    if (int e = readback_queue(ctx, part(ctx, PA_RR), 2 * NPART)) return e;  // RR | BB, awaited behind the first cycle
+    nrz = (int)vg;
+    if (amg) {  // z = M^-1 r by one V-cycle, p = z, r.z
+      if (int e = cycle(part(ctx, PA_RZ0))) return e;
+      PF_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+      PF_LAUNCH_CHECK();
+    }
+    if (int e = readback_wait(ctx)) return e;
+    bnorm = sqrt(host_sum(ctx->pin + NPART, (int)vg));
+    rnorm = rnorm_prev = sqrt(host_sum(ctx->pin, (int)vg));
+    return PF_OK;
+  };
+  if ((rc = start())) return rc;
   const double tol = std::max(rtol * bnorm, atol);
-  double rnorm = sqrt(host_sum(ctx->pin, (int)vg)), rnorm_prev = rnorm;
   int it = 0;
   int cur = 0;  // which rz partial array is live
+  // A healthy AMG-PCG solve takes 10 - 40 iterations.  One that is still running after PF_AMG_RESCUE_AT has, in every case
+  // seen so far, a smoother or prolongator that over-relaxes because the power iteration under-estimated lambda_max(D^-1 A)
+  // by more than the 1.1 margin (the refined arm mesh with six instead of ten steps: 1 500 iterations instead of 28,
+  // profiles/r03_power_iteration_steps.txt).  Once per solve: redo the numeric setup with three times the power steps (the
+  // hierarchy keeps them from then on), say so in the warning, and restart the recurrence from the iterate reached.
+  bool rescued = false;
   while (rnorm > tol && it < maxiter) {
+    if (amg && !rescued && it >= PF_AMG_RESCUE_AT) {
+      rescued = true;
+      if ((rc = pf_amg_more_power_steps(ctx))) return rc;
+      if ((rc = pf_amg_setup(ctx, vals, 0))) return rc == PF_E_UNSUPPORTED ? pf_fail(ctx, rc, "pf_cg: the matrix is not definite") : rc;
+      ctx->warn = "pf_cg: AMG-PCG had not converged after " + std::to_string(it) + " iterations; the hierarchy was set up again with "
+                  "more power-iteration steps for its lambda_max estimates and the solve restarted from the iterate reached";
+      if ((rc = start())) return rc;
+      cur = 0;
+      if (!(rnorm > tol)) break;
+    }
     const int burst = std::min(check_every, maxiter - it);
     // Checked every iteration (AMG): when the residual's recent rate says THIS step probably ends the solve, the host
     // looks at |r|^2 before it queues the V-cycle and the direction update, and leaves them out if it does (they were a

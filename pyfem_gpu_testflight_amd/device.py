@@ -337,6 +337,11 @@ class HipContext:
         self._warn()
         return x, iters.value, relres.value
 
+    def amg_set_power_steps(self, steps):
+        """Power-iteration steps of the AMG hierarchy's lambda_max estimates from the next numeric setup on (default 10)."""
+        self._sync_stream()
+        self._call("pf_amg_set_power_steps", int(steps))
+
     def cg2(self, vals, b2, x0=None, rtol=1e-8, atol=0.0, maxiter=0, reuse=True):
         """AMG-PCG for two right-hand sides of a scalar matrix at once (pf_cg2): b2 is an (nnodes, 2) device array.
         Returns (x2, (iters0, iters1), (relres0, relres1)); raises like cg() when either fails to converge and

@@ -1543,7 +1543,12 @@ def test_amg_lag_keeps_the_setup_while_the_matrix_moves_slowly(pf):
     # a jump (another design altogether): the stale hierarchy still converges, to the same u, and is then replaced
     rho = np.random.default_rng(3).uniform(1e-3, 1.0, X.shape[0])
     n0 = lag.amg_setups
-    both(rho)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # a stale solve that passes 150 iterations is rescued, and says so
+        both(rho)
     assert lag.amg_setups == n0 and its_lag[-1] > 1.3 * its_fresh[-1] + 1, (its_lag, its_fresh)
-    both(rho)  # flagged by the slow solve: a fresh setup now, and the fresh solve's count
-    assert lag.amg_setups == n0 + 1 and its_lag[-1] == its_fresh[-1], (its_lag, its_fresh)
+    both(rho)  # flagged by the slow solve: a fresh setup now, and the fresh solve's count (+-2: if the stale solve ran into
+    # pf_cg's rescue, this hierarchy estimates lambda_max with more power steps from then on)
+    assert lag.amg_setups == n0 + 1 and abs(its_lag[-1] - its_fresh[-1]) <= 2, (its_lag, its_fresh)

@@ -324,6 +324,31 @@ def test_c4_refined_arm_properties_and_manufactured_solution(pf, orc, arm5):
     assert err < U_TOL, f"max error {err:.2e} after {it} iterations"
 
 
+def test_c4_refined_arm_under_estimated_lambda_is_rescued(pf, arm5):
+    """The refined arm is the mesh on which the AMG is most sensitive to its lambda_max estimates: with five power steps
+    instead of ten the smoother over-relaxes and PCG needs thousands of iterations (profiles/r03_power_iteration_steps.txt).
+    pf_cg notices after 150, sets the hierarchy up again with three times the steps, restarts from the iterate reached and
+    says so: the solve ends a few dozen iterations later with the same u as a healthy solve; the next solve is healthy."""
+    X, conn, dof_fixed, force, _ = arm5
+    q, b = _qb(pf, "tri")
+    healthy = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    asm0 = pf.Assembler(healthy)
+    u0 = asm0.solve(method="cg")
+    it0 = asm0.last_iters
+    assert it0 < 60
+    del healthy
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, b)
+    model.hctx.amg_set_power_steps(5)
+    asm = pf.Assembler(model)
+    with pytest.warns(RuntimeWarning, match="set up again"):
+        u = asm.solve(method="cg")
+    assert 150 < asm.last_iters <= 150 + 2 * it0, (asm.last_iters, it0)
+    assert np.abs(u - u0).max() <= 1e-8 * np.abs(u0).max()
+    u = asm.solve(method="cg")  # the hierarchy keeps its fifteen steps (a more accurate bound damps a little more: 38 against 35)
+    assert asm.last_iters <= 1.25 * it0, (asm.last_iters, it0)
+    assert np.abs(u - u0).max() <= 1e-8 * np.abs(u0).max()
+
+
 # ---- C5 ---------------------------------------------------------------------------------------------------------
 def test_c5_density_field_u_against_manufactured_solution(pf, orc):
     """2048x1024 quads with a filtered-looking nodal density in [1e-3, 1] and RAMP p = 5 (the matrix of a
