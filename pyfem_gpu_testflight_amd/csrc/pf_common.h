@@ -87,6 +87,7 @@ struct pf_ctx {
   double* pin = nullptr;       // pinned host buffer (2 * PF_NPART doubles) and event for the PCG loops' residual read-back: the
   hipEvent_t pin_ev = nullptr; //   copy is queued right after the update that produces |r|^2 and awaited after the rest of the
                                //   iteration has been queued, so the device never waits for the host (pf_solve.hip)
+  int dcg_par = 0;             // which of the two r.z / r.r partial-array sets the next k_dcg_update reads (pf_dist_update)
   double* cg_ap = nullptr;     // the product's output vector of pf_cg, placed by measurement (pf_solve.hip cg_place_ap)
   int64_t cg_ap_n = 0;
   void* scan_tmp = nullptr;

@@ -962,25 +962,25 @@ __global__ __launch_bounds__(256) void k_dcg_update(int64_t n, pf_halo_recv rc, 
   // scalars in the same order, so every rank stops at the same iteration): nothing is sent, waited for or updated.  (Read
   // above, tested here: the prefetch loads are harmless and need not wait for it.)
   if (stopped != 0.0) return;
-  if (blockIdx.x == 0) {  // 1. this rank's scalars to every rank (the partial arrays are overwritten at the END of this
-                          //    kernel by blocks that cannot get there before block 0 has read them: they wait for its flag)
-    double loc[3];
-    block_sum_partials3(gpart, ngpart, dpart, ndpart, rrpart, nrrpart, sh, loc);
-    const double g = loc[0], dl = loc[1], rr = loc[2];
-    if ((int)threadIdx.x < rc.world) {
-      double* pw = rc.peer_win[threadIdx.x];
-      double* dst = pw + halo_scal2_off(rc.world) + ((size_t)spar * rc.world + rc.rank) * PF_HALO_NSCAL;
-      pf_st_sys_f64(dst, g);
-      pf_st_sys_f64(dst + 1, dl);
-      pf_st_sys_f64(dst + 2, rr);
-      pf_release_sys();  // one wave of the whole launch
-      __hip_atomic_store(reinterpret_cast<uint64_t*>(pw) + halo_sflag_off(rc.world) + rc.rank, rc.sseq, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+  // 1. this rank's scalars: EVERY block sums the partial arrays itself (fixed order: the same bits in every block, and the
+  //    bits block 0 sends).  Round 3, late: until then only block 0 summed, stored the result into every window including
+  //    its own and all other blocks waited for that flag -- a serial 5-8 us at the head of a 27 us kernel on one rank's
+  //    share at N = 8.  The partial arrays this kernel WRITES at its end are therefore not the ones it reads (a fast block
+  //    would overwrite its slot while a slow one still sums): the host alternates two sets (pf_dist_update).
+  double loc[3];
+  block_sum_partials3(gpart, ngpart, dpart, ndpart, rrpart, nrrpart, sh, loc);
+  if (blockIdx.x == 0 && (int)threadIdx.x < rc.world && (int)threadIdx.x != rc.rank) {  // ... and block 0 sends them to the others
+    double* pw = rc.peer_win[threadIdx.x];
+    double* dst = pw + halo_scal2_off(rc.world) + ((size_t)spar * rc.world + rc.rank) * PF_HALO_NSCAL;
+    pf_st_sys_f64(dst, loc[0]);
+    pf_st_sys_f64(dst + 1, loc[1]);
+    pf_st_sys_f64(dst + 2, loc[2]);
+    pf_release_sys();  // one wave of the whole launch
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(pw) + halo_sflag_off(rc.world) + rc.rank, rc.sseq, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __syncthreads();
-  // 2. wait for every rank's scalars
-  if ((int)threadIdx.x < rc.world && !bad) {
+  // 2. wait for every OTHER rank's scalars
+  if ((int)threadIdx.x < rc.world && (int)threadIdx.x != rc.rank && !bad) {
     const uint64_t* flag = reinterpret_cast<const uint64_t*>(rc.win) + halo_sflag_off(rc.world) + threadIdx.x;
     if (pf_wait_flag(flag, rc.sseq, rc.timeout_ticks)) bad = 1;
   }
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256) void k_dcg_update(int64_t n, pf_halo_recv rc, 
   if (threadIdx.x < 3) {
     const double* sc = rc.win + halo_scal2_off(rc.world) + (size_t)spar * rc.world * PF_HALO_NSCAL + threadIdx.x;
     double t = 0.0;
-    for (int q = 0; q < rc.world; ++q) t += pf_ld_sys_f64(sc + (size_t)q * PF_HALO_NSCAL);
+    for (int q = 0; q < rc.world; ++q) t += (q == rc.rank) ? loc[threadIdx.x] : pf_ld_sys_f64(sc + (size_t)q * PF_HALO_NSCAL);
     gsum[threadIdx.x] = t;
   }
   __syncthreads();
@@ -1784,13 +1784,18 @@ int pf_dist_update(pf_ctx* ctx, pf_halo* halo, int plan, const double* w, const 
   const int ns = (int)spmv_grid_d(ctx->nnodes, ctx->d);
   pf_halo_recv rcv;
   pf_halo_fused_recv(halo, plan, true, &rcv);
-  // partial arrays: PA_GAMMA / PA_RR2 hold what the previous producer stored (k_cgcg_update_xrz or k_dot: vg blocks; this
-  // kernel: ug blocks); the r.z partials of a keep_z launch go to PA_RZ0, which nobody reads
-  k_dcg_update<<<ug, 256, 0, ctx->stream>>>(n, rcv, part(ctx, PA_GAMMA), (int)((gamma_from_dot || rr_from_init) ? vg : ug),
-                                            part(ctx, PA_RR2), (int)(rr_from_init ? vg : ug), part(ctx, PA_DELTA), ns, state_in,
+  // partial arrays: the r.z / r.r sets alternate (ctx->dcg_par): this launch reads what the previous producer stored
+  // (k_cgcg_update_xrz or k_dot: vg blocks; this kernel: ug blocks) and writes the OTHER set, because all its blocks sum the
+  // input arrays on their own (see the kernel).  keep_z: r.z comes from k_dot into the set this launch reads, the kernel's
+  // own r.z partials go to PA_RZ0, which nobody reads.
+  const int gin = ctx->dcg_par ? PA_RZ1 : PA_GAMMA, gout = ctx->dcg_par ? PA_GAMMA : PA_RZ1;
+  const int rin = ctx->dcg_par ? PA_RR : PA_RR2, rout = ctx->dcg_par ? PA_RR2 : PA_RR;
+  k_dcg_update<<<ug, 256, 0, ctx->stream>>>(n, rcv, part(ctx, gin), (int)((gamma_from_dot || rr_from_init) ? vg : ug),
+                                            part(ctx, rin), (int)(rr_from_init ? vg : ug), part(ctx, PA_DELTA), ns, state_in,
                                             state_out, redg, first ? 1 : 0, tol2, it, keep_z ? 1 : 0, w, dinv, F->flags8, z, p, s, x, r,
-                                            part(ctx, keep_z ? PA_RZ0 : PA_GAMMA), part(ctx, PA_RR2));
+                                            part(ctx, keep_z ? PA_RZ0 : gout), part(ctx, rout));
   PF_LAUNCH_CHECK();
+  ctx->dcg_par ^= 1;
   pf_halo_fused_scal(halo);
   return PF_OK;
 }
@@ -1798,7 +1803,7 @@ int pf_dist_update(pf_ctx* ctx, pf_halo* halo, int plan, const double* w, const 
 // r.z over the owned dofs into PA_GAMMA (vec_grid partials), for pf_dist_update(gamma_from_dot)
 int pf_dist_dot_gamma(pf_ctx* ctx, const double* r, const double* z, const double* own_w) {
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
-  k_dot<<<vec_grid(n), 256, 0, ctx->stream>>>(n, r, z, own_w, part(ctx, PA_GAMMA));
+  k_dot<<<vec_grid(n), 256, 0, ctx->stream>>>(n, r, z, own_w, part(ctx, ctx->dcg_par ? PA_RZ1 : PA_GAMMA));  // the set the next update reads
   PF_LAUNCH_CHECK();
   return PF_OK;
 }
@@ -1807,6 +1812,7 @@ int pf_dist_dot_gamma(pf_ctx* ctx, const double* r, const double* z, const doubl
 int pf_dist_init_partials(pf_ctx* ctx, const double* state0, const double* p, const double* s, const double* dinv,
                           const double* own_w, double* x, double* r, double* z) {
   const int64_t n = (int64_t)ctx->d * ctx->nnodes;
+  ctx->dcg_par = 0;  // a new solve: the first update reads PA_GAMMA / PA_RR2
   k_cgcg_update_xrz<<<vec_grid(n), 256, 0, ctx->stream>>>(n, state0, p, s, dinv, own_w, x, r, z, part(ctx, PA_GAMMA), part(ctx, PA_RR2));
   PF_LAUNCH_CHECK();
   return PF_OK;
