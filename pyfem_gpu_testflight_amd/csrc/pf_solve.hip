@@ -904,10 +904,11 @@ __global__ __launch_bounds__(256) void k_cgcg_fused(int64_t n, const double* __r
 
 // ------------------------------------------------------------------------------------------
 // The update kernel of the distributed single-reduction PCG (pf_dist_cg): everything between two products in ONE launch.
-//   1. block 0 sums this rank's partials (gamma = own r.z and r.r from the previous update, delta = z.Kz from the
-//      product) in a fixed order, stores the three scalars into EVERY rank's window and raises its scalar flag there;
-//   2. every block waits for the scalar flags of all ranks (bounded) and sums the scalars in rank order: the
-//      all-reduce of the iteration, deterministic, without a collective and without a launch of its own;
+//   1. every block sums this rank's partials (gamma = own r.z and r.r from the previous update, delta = z.Kz from the
+//      product) in a fixed order -- the same bits in every block; block 0 stores the three scalars into every OTHER rank's
+//      window and raises its scalar flag there;
+//   2. every block waits for the scalar flags of the other ranks (bounded) and sums the scalars in rank order, its own in
+//      its place: the all-reduce of the iteration, deterministic, without a collective and without a launch of its own;
 //   3. the first blocks wait for the row flags of the neighbours -- the rows left the neighbours' PRODUCT kernels
 //      (k_spmv<..., SEND>) while those were still computing their interior -- and form w on the interface entries as the
 //      sum over the sharing ranks in ascending rank order (same bits on every sharer), then update those entries;
@@ -915,8 +916,8 @@ __global__ __launch_bounds__(256) void k_cgcg_fused(int64_t n, const double* __r
 //      (flags8 bit 1), with the ownership weight of the dot products from bit 0.
 // keep_z (AMG-PCG, pf_dist_pcg_amg): z is the V-cycle's to write; this kernel leaves it alone, and the r.z partials it
 // stores are not used (the caller forms r.z after the cycle).
-// No thread of this kernel waits for another block of the same kernel except through block 0's flag, and block 0 never
-// waits before it has sent: the grid drains whenever every rank reaches its product launch (or the timeout fires).
+// No thread of this kernel waits for another block of the same kernel, and block 0 never waits before it has sent: the
+// grid drains whenever every rank reaches its update launch (or the timeout fires).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dcg_point(double wv, double zv, double beta, double alpha, double dv, bool has_d, double& p, double& s,
                                           double& x, double& r, double& zn) {
