@@ -1784,15 +1784,16 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
     return pf_launch_spmv(ctx, Lv.vals, x, y, dot_part, mode == AMG_SMOOTH ? dv : nullptr, mode == AMG_AX ? nullptr : b,
                           Lv.vals32, nullptr, nullptr, nv);
   }
+  const double* d2arg = mode == AMG_POW ? dot_part : Lv.dinv2;  // AMG_POW: the per-wave partials of |y|^2 travel in the dinv2 slot
   const bool small = Lv.n <= AMG_SMALL_LEVEL;
   const unsigned g = (unsigned)std::min<int64_t>(cdiv(Lv.n, small ? 16 : 64), 4096);
   if (nv == 2) {  // two vectors at once: scalar levels only (amg_cycle checks)
 #define PF_AS2(M_)                                                                                                  \
   do {                                                                                                              \
-    if (Lv.vals32 && small) k_amg_spmv<1, M_, float, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
-    else if (Lv.vals32) k_amg_spmv<1, M_, float, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
-    else if (small) k_amg_spmv<1, M_, double, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
-    else k_amg_spmv<1, M_, double, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
+    if (Lv.vals32 && small) k_amg_spmv<1, M_, float, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, d2arg, b); \
+    else if (Lv.vals32) k_amg_spmv<1, M_, float, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, d2arg, b); \
+    else if (small) k_amg_spmv<1, M_, double, 16, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, d2arg, b); \
+    else k_amg_spmv<1, M_, double, 64, 2><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, d2arg, b); \
   } while (0)
     if (mode == AMG_AX) PF_AS2(AMG_AX);
     else if (mode == AMG_SMOOTH) PF_AS2(AMG_SMOOTH);
@@ -1804,19 +1805,14 @@ static int amg_spmv(pf_ctx* ctx, AmgLevel& Lv, int level, const double* x, doubl
   }
 #define PF_AS(D_, M_)                                                                                               \
   do {                                                                                                              \
-    if (Lv.vals32 && small) k_amg_spmv<D_, M_, float, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
-    else if (Lv.vals32) k_amg_spmv<D_, M_, float><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, Lv.dinv2, b); \
-    else if (small) k_amg_spmv<D_, M_, double, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
-    else k_amg_spmv<D_, M_, double><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, Lv.dinv2, b); \
+    if (Lv.vals32 && small) k_amg_spmv<D_, M_, float, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, d2arg, b); \
+    else if (Lv.vals32) k_amg_spmv<D_, M_, float><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals32, x, y, dv, d2arg, b); \
+    else if (small) k_amg_spmv<D_, M_, double, 16><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, d2arg, b); \
+    else k_amg_spmv<D_, M_, double><<<g, 64, 0, ctx->stream>>>(Lv.n, Lv.ptr, Lv.idx, Lv.vals, x, y, dv, d2arg, b); \
   } while (0)
 #define PF_ASD(M_) do { if (Lv.dr == 1) PF_AS(1, M_); else if (Lv.dr == 6) PF_AS(6, M_); else PF_AS(3, M_); } while (0)
-  if (mode == AMG_POW) {  // dv = the raw diagonal, the partial array travels in the dinv2 slot
-    const double* dinv2_keep = Lv.dinv2;
-    Lv.dinv2 = dot_part;
-    PF_ASD(AMG_POW);
-    Lv.dinv2 = const_cast<double*>(dinv2_keep);
-  } else
-  if (mode == AMG_AX) PF_ASD(AMG_AX);
+  if (mode == AMG_POW) PF_ASD(AMG_POW);  // dv = the raw diagonal
+  else if (mode == AMG_AX) PF_ASD(AMG_AX);
   else if (mode == AMG_SMOOTH) PF_ASD(AMG_SMOOTH);
   else if (mode == AMG_RESID) PF_ASD(AMG_RESID);
   else PF_ASD(AMG_SMOOTH0);
