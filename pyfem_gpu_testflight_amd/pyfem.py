@@ -896,7 +896,6 @@ class Assembler:
         # topology-optimisation steps), where the setup is a quarter of the solve; 0 (default): a setup per matrix.
         self.amg_lag = 0
         self.amg_setups = 0  # numeric setups requested so far (amg_lag bookkeeping; tests read it)
-        self._lag = {}
 
     @time_this
     def solve(self, method="gmres"):
@@ -938,7 +937,7 @@ class Assembler:
             else:
                 pc, lag = _PRECOND[self.precond], None
                 if pc == _lib.PF_PRECOND_AMG:
-                    lag = self._lag.get(id(hctx))
+                    lag = getattr(hctx, "_amg_lag_state", None)  # kept on the context: that is what owns the hierarchy
                     if self.amg_lag > 0 and lag is not None and lag["age"] < self.amg_lag and not lag["refresh"]:
                         pc = _lib.PF_PRECOND_AMG_STALE
                 x, it, rr = hctx.cg(K.vals, b, rtol=rtol, precond=pc)
@@ -947,7 +946,7 @@ class Assembler:
                     lag["refresh"] = it > 1.3 * lag["fresh_iters"] + 1
                 elif pc == _lib.PF_PRECOND_AMG:
                     self.amg_setups += 1
-                    self._lag[id(hctx)] = {"fresh_iters": it, "age": 0, "refresh": False}
+                    hctx._amg_lag_state = {"fresh_iters": it, "age": 0, "refresh": False}
         except (_lib.PyfemHipError, DirectSolveError):
             raise  # a HIP / argument error is not a convergence failure, and method="direct"'s message is final
         except RuntimeError as e:  # PF_E_NOCONV: "<solver> failed with code <iters>" (pyfem.py:2421-2422)
