@@ -212,3 +212,43 @@ def test_jacobi_pcg_with_unreferenced_nodes_on_a_brick20_grid(pf, orc):
     ud = np.flatnonzero(np.repeat(used, 3))
     assert np.isfinite(u_jac).all()
     assert np.abs(u_jac[ud] - u_amg[ud]).max() <= 1e-7 * np.abs(u_amg[ud]).max()
+
+
+def test_two_vector_solve_error_behaviour(pf):
+    """pf_cg2 behind HipContext.cg2 (the pair of gradient filters, topo.py:73-74): the reference's failure message when the
+    iteration cap is hit (pyfem.py:2421-2422), ValueError for what the two-vector path does not cover (two dofs per node,
+    a right-hand side that is not an (nnodes, 2) array), a non-zero initial guess, and a pair of which one vector starts
+    converged."""
+    import torch
+
+    c = pf.ProblemCreator(65, 41)
+    conn, X, x0 = c.create_helmhotz_problem()
+    q = pf.QuadratureBilinear2D()
+    filtr = pf.Helmholtz(0.08, X, conn, q, pf.BasisBilinear2D(q))
+    h = filtr.hctx
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    B = torch.rand(h.nnodes, 2, generator=gen, dtype=torch.float64).to(h.device)
+    with pytest.raises(RuntimeError, match="failed with code 2"):
+        h.cg2(filtr.K.vals, B, rtol=1e-14, maxiter=2)
+    with pytest.raises(ValueError):
+        h.cg2(filtr.K.vals, B.t().contiguous().t())  # (nnodes, 2) but column-major
+    with pytest.raises(ValueError):
+        h.cg2(filtr.K.vals, B[:, 0].contiguous())
+    X2, its, rr = h.cg2(filtr.K.vals, B, rtol=1e-12)
+    assert max(rr) <= 1e-12 and min(its) > 3
+    for v in range(2):  # each column solves K y = b
+        assert float((filtr.K.dot(X2[:, v].contiguous()) - B[:, v]).norm() / B[:, v].norm()) < 1e-11
+    # restart from the solution of column 0 and zero for column 1: column 0 is done at once, column 1 is not disturbed
+    x0 = X2.clone()
+    x0[:, 1] = 0.0
+    X3, its3, _ = h.cg2(filtr.K.vals, B, x0=x0, rtol=1e-12)
+    assert its3[0] == 0 and its3[1] == its[1]
+    assert torch.equal(X3[:, 0], X2[:, 0]) and float((X3[:, 1] - X2[:, 1]).abs().max()) <= 1e-10 * float(X2[:, 1].abs().max())
+    # two dofs per node: refused (the caller solves one by one)
+    ce = pf.ProblemCreator(17, 13)
+    conn, X, dof_fixed, force = ce.create_linear_elasticity_problem()
+    model = pf.LinearElasticity(X, conn, dof_fixed, None, force, q, pf.BasisBilinear2D(q))
+    K = model.compute_jacobian()
+    K, rhs = model.apply_dirichlet_bcs(K, model.compute_rhs_device(), True)
+    with pytest.raises(ValueError):
+        model.hctx.cg2(K.vals, torch.zeros(model.hctx.nnodes, 2, dtype=torch.float64, device=model.hctx.device))
