@@ -31,10 +31,10 @@
 #define PF_SPMV2 2, 1, 3, 640
 #endif
 #ifndef PF_SPMV1F
-#define PF_SPMV1F 1, 2, 6, 1280   // fp32 value copy of scalar matrices
+#define PF_SPMV1F 1, 2, 9, 1280   // fp32 value copy of scalar matrices (nine in flight: a 128-row tile of a quad mesh in two batches; r03: filter solve -2 % against six)
 #endif
 #ifndef PF_SPMV2F
-#define PF_SPMV2F 2, 1, 6, 640  // fp32 value copy (AMG smoother): 16-byte blocks, so twice as many in flight for the same bytes
+#define PF_SPMV2F 2, 1, 9, 640  // fp32 value copy (AMG smoother): 16-byte blocks; nine in flight = a 64-row tile of a quad mesh in one batch (r03: elasticity solve -1.6 % against six)
 #endif
 static constexpr int SPMV_TILE1 = PF_SPMV_TILE1, SPMV_TILE2 = PF_SPMV_TILE2;  // nodes per wave tile (64 * rows per lane)
 // the Morton tile walk (pf_pattern.hip spmv_perm), the 16-bit column offsets and the fused exchange's tile walk
