@@ -390,6 +390,12 @@ __global__ __launch_bounds__(64) void k_amg_galerkin_wave(int64_t nc, const int3
 //   AMG_POW  y = (A x) ./ dinv  (one power-iteration step of D^-1 A during the numeric setup, when dinv still holds the RAW
 //            diagonal) and, if dinv2 != NULL, dinv2[wave] = this wave's share of |y|^2 (fixed order: reproducible)
 enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3, AMG_POW = 4 };
+#ifndef PF_AB_AS_U
+#define PF_AB_AS_U 4  // blocks per lane in flight in k_amg_spmv
+#endif
+#ifndef PF_AB_RS_U
+#define PF_AB_RS_U 4  // entries per lane in flight in k_sa_restrict_stream
+#endif
 // TR = rows per wave tile.  64 on the large levels (bandwidth); 16 on the small ones (n <= AMG_SMALL_LEVEL), where a tile's
 // ~25 x 64 entries took two to four dependent chunks and the kernel 8 - 9 us of pure latency against ~5.5 us with a
 // single chunk per wave and four times as many waves (r03).
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(64) void k_amg_spmv(int64_t n, const int32_t* __res
     for (int32_t c0 = base; c0 < end; c0 += CH) {
       const int32_t c1 = min(end, c0 + CH);
       // U blocks per lane in flight (column ids first, then blocks and gathers together): these levels wait for memory
-      constexpr int U = (D <= 3) ? 4 : 1;
+      constexpr int U = (D <= 3) ? PF_AB_AS_U : 1;
       for (int32_t g0 = c0 + lane; g0 < c1; g0 += 64 * U) {
         int32_t gg[U];
         int64_t mm[U];
@@ -894,7 +900,7 @@ __global__ __launch_bounds__(64) void k_sa_restrict_stream(int64_t nc, const int
       const int32_t c1 = min(end, c0 + CH);
       // U entries per lane in flight (the node ids first, then blocks and residual gathers together): the kernel waits
       // for memory 93 % of its time at 13 resident waves per CU (r02 counters)
-      constexpr int U = (DR * DC <= 9) ? 4 : 1;
+      constexpr int U = (DR * DC <= 9) ? PF_AB_RS_U : 1;
       for (int32_t e0 = c0 + lane; e0 < c1; e0 += 64 * U) {
         int32_t ee[U];
         int64_t nn[U];
