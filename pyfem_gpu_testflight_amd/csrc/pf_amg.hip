@@ -399,7 +399,10 @@ enum { AMG_AX = 0, AMG_SMOOTH = 1, AMG_RESID = 2, AMG_SMOOTH0 = 3, AMG_POW = 4 }
 // TR = rows per wave tile.  64 on the large levels (bandwidth); 16 on the small ones (n <= AMG_SMALL_LEVEL), where a tile's
 // ~25 x 64 entries took two to four dependent chunks and the kernel 8 - 9 us of pure latency against ~5.5 us with a
 // single chunk per wave and four times as many waves (r03).
-static constexpr int64_t AMG_SMALL_LEVEL = 65536;
+#ifndef PF_AB_SMALL_LEVEL
+#define PF_AB_SMALL_LEVEL 65536
+#endif
+static constexpr int64_t AMG_SMALL_LEVEL = PF_AB_SMALL_LEVEL;
 // NV > 1: NV vectors at once, interleaved per dof (entry (dof q, vector v) at q * NV + v); dinv is per dof.  The matrix
 // stream and the launch are shared by the NV products (the two gradient filters of a topology iteration, pf_cg2).
 template <int D, int MODE, typename VT, int TR = 64, int NV = 1>
